@@ -1,0 +1,123 @@
+"""ctypes binding of libartdeco_hip.so.
+
+The prototypes are derived from include/artdeco_hip.h (single source of truth
+for the C ABI), so a signature change in the header is a signature change here.
+There is deliberately NO fallback: if the library is missing or a launch fails,
+the caller gets an exception, never a silent CPU/eager path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "artdeco_hip.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libartdeco_hip.so")
+
+_CTYPE = {
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "double": ctypes.c_double,
+    "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
+    "int32_t": ctypes.c_int32,
+    "uint32_t": ctypes.c_uint32,
+    "size_t": ctypes.c_size_t,
+    "adk_stream_t": ctypes.c_void_p,
+}
+
+_ERRNAMES = {-1: "ADK_EINVAL (bad argument)", -2: "ADK_EWORKSPACE (workspace too small)",
+             -3: "ADK_EUNSUPPORTED"}
+
+
+class AdkError(RuntimeError):
+    pass
+
+
+def parse_header(path: str = HEADER) -> dict[str, list[tuple[str, str]]]:
+    """Return {symbol: [(ctype_name_or_'ptr', arg_name), ...]} for every `int adk_*(...)`."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    out: dict[str, list[tuple[str, str]]] = {}
+    for m in re.finditer(r"\bint\s+(adk_\w+)\s*\(([^)]*)\)\s*;", src):
+        name, args = m.group(1), m.group(2).strip()
+        parsed: list[tuple[str, str]] = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    parsed.append(("ptr", a.split("*")[-1].strip()))
+                else:
+                    toks = a.replace("const ", "").split()
+                    parsed.append((toks[0], toks[-1]))
+        out[name] = parsed
+    return out
+
+
+_lock = threading.Lock()
+_lib = None
+_protos = None
+
+
+def load():
+    """Load the shared library (once) and attach argtypes/restype from the header."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise AdkError(
+                f"{LIB_PATH} is missing: build it with `python -m artdeco_amd.build` "
+                "(hipcc, gfx950).  There is no CPU fallback for the artdeco_amd operators.")
+        # torch must own the HIP runtime that is already in the process (same SONAME
+        # libamdhip64.so.7), so import it first when it is available.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is a hard dependency of the wrappers anyway
+            pass
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        protos = parse_header()
+        for name, args in protos.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p if t == "ptr" else _CTYPE[t] for t, _ in args]
+        if lib.adk_abi_version() != _header_abi_version():
+            raise AdkError("libartdeco_hip.so ABI version does not match include/artdeco_hip.h; rebuild")
+        _lib, _protos = lib, protos
+    return _lib
+
+
+def _header_abi_version() -> int:
+    m = re.search(r"#define\s+ADK_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    return int(m.group(1))
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise AdkError(f"{what}: {_ERRNAMES.get(rc, rc)}")
+    raise AdkError(f"{what}: HIP error {rc}")
+
+
+def ptr(t) -> int | None:
+    """data_ptr of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t) -> int:
+    """hipStream_t of torch's current stream on t's device."""
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AdkError("artdeco_amd operators run on the MI355X only: got a CPU tensor "
+                           "(there is no CPU fallback; use oracle/ for CPU reference results)")

@@ -1,0 +1,332 @@
+// Fused SSIM forward / backward for gfx950 (CDNA4).
+//
+// Replaces Reconstruct/submodules/fused-ssim/ssim.cu (kernels :62-278 fwd,
+// :286-427 bwd; host entry points :434-473, :481-517).  Same math (11-tap
+// sigma=1.5 separable Gaussian, zero "same" padding, C1/C2 passed in), new
+// decomposition designed for 64-wide wavefronts:
+//
+//   * one wavefront per workgroup; lane = image column, the wave marches down
+//     a strip of RH output rows (+10 halo rows).  A single-wave workgroup makes
+//     __syncthreads() a free s_barrier, so there are no block-level stalls.
+//   * horizontal 11-tap pass: the input row (64+10 columns, both images) is
+//     staged in a tiny LDS row buffer; each lane reads its 11 neighbours with
+//     conflict-free consecutive-address ds_reads.
+//   * vertical 11-tap pass: an 11-row ring of the 5 (fwd) / 3 (bwd) horizontal
+//     sums lives in VGPRs (loop unrolled by 11 so every ring index is static);
+//     no second LDS round trip, no 26x16x5 scratch tile as in the reference.
+//   * all global loads/stores are 64-lane row-contiguous (256 B) and the next
+//     input row is prefetched into registers while the current one is reduced.
+//
+// HBM traffic per pixel-channel: fwd(train) 8 B in + 16 B out, bwd 24 B in +
+// 4 B out (+ halo re-reads that hit L2).  Roofline: HBM.
+#include "adk_common.hpp"
+
+namespace adk {
+
+// gaussian(11, 1.5) in fp32 -- identical to the table at ssim.cu:12-24 and to
+// fused-ssim/tests/test.py:14-16 evaluated in fp32.
+__constant__ float kGauss[11] = {
+    0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
+    0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
+    0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
+
+#define SSIM_HALO 5
+#define SSIM_ROWBUF 80 // 64 + 10 halo, padded
+
+template <int RH, bool TRAIN>
+__global__ __launch_bounds__(64) void ssim_fwd_kernel(
+    int H, int W, float C1, float C2,
+    const float* __restrict__ img1, const float* __restrict__ img2,
+    float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
+    float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12)
+{
+    __shared__ float rowbuf[2][2][SSIM_ROWBUF]; // [parity][image][column]
+
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64;
+    const int y0 = blockIdx.y * RH;
+    const int64_t plane = (int64_t)blockIdx.z * H * W;
+    const float* p1 = img1 + plane;
+    const float* p2 = img2 + plane;
+
+    float g[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) g[i] = kGauss[i];
+
+    // column this lane loads for the row buffer (main slot + 10 extra slots)
+    const int xa = x0 - SSIM_HALO + lane;
+    const int xb = x0 - SSIM_HALO + 64 + lane; // lanes 0..9 only
+    const bool xa_ok = (xa >= 0) && (xa < W);
+    const bool xb_ok = (lane < 2 * SSIM_HALO) && (xb < W);
+    const int x = x0 + lane; // output column
+
+    float win[11][5];
+
+    constexpr int NROWS = RH + 2 * SSIM_HALO;
+
+    // prefetch row 0
+    float a1, a2, b1, b2;
+    {
+        const int r = y0 - SSIM_HALO;
+        const bool rok = (r >= 0) && (r < H);
+        const int64_t off = (int64_t)r * W;
+        a1 = (rok && xa_ok) ? p1[off + xa] : 0.f;
+        a2 = (rok && xa_ok) ? p2[off + xa] : 0.f;
+        b1 = (rok && xb_ok) ? p1[off + xb] : 0.f;
+        b2 = (rok && xb_ok) ? p2[off + xb] : 0.f;
+    }
+
+    for (int base = 0; base < NROWS; base += 11) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const int i = base + k;
+            if (i < NROWS) {
+                const int par = k & 1; // two barriers per row make any slot choice safe; parity just
+                                       // lets the next row's ds_writes start without aliasing.
+                rowbuf[par][0][lane] = a1;
+                rowbuf[par][1][lane] = a2;
+                if (lane < 2 * SSIM_HALO) {
+                    rowbuf[par][0][64 + lane] = b1;
+                    rowbuf[par][1][64 + lane] = b2;
+                }
+                // prefetch next row while this one is being reduced
+                {
+                    const int r = y0 - SSIM_HALO + i + 1;
+                    const bool rok = (r >= 0) && (r < H) && (i + 1 < NROWS);
+                    const int64_t off = (int64_t)r * W;
+                    a1 = (rok && xa_ok) ? p1[off + xa] : 0.f;
+                    a2 = (rok && xa_ok) ? p2[off + xa] : 0.f;
+                    b1 = (rok && xb_ok) ? p1[off + xb] : 0.f;
+                    b2 = (rok && xb_ok) ? p2[off + xb] : 0.f;
+                }
+                __syncthreads();
+
+                // horizontal 11-tap pass (pairs around the centre, as ssim.cu:134-158)
+                float sX = 0.f, sX2 = 0.f, sY = 0.f, sY2 = 0.f, sXY = 0.f;
+                const float* rb1 = &rowbuf[par][0][lane];
+                const float* rb2 = &rowbuf[par][1][lane];
+#pragma unroll
+                for (int d = 1; d <= SSIM_HALO; ++d) {
+                    const float w = g[SSIM_HALO - d];
+                    const float Xl = rb1[SSIM_HALO - d], Xr = rb1[SSIM_HALO + d];
+                    const float Yl = rb2[SSIM_HALO - d], Yr = rb2[SSIM_HALO + d];
+                    sX += (Xl + Xr) * w;
+                    sX2 += (Xl * Xl + Xr * Xr) * w;
+                    sY += (Yl + Yr) * w;
+                    sY2 += (Yl * Yl + Yr * Yr) * w;
+                    sXY += (Xl * Yl + Xr * Yr) * w;
+                }
+                {
+                    const float Xc = rb1[SSIM_HALO], Yc = rb2[SSIM_HALO], wc = g[SSIM_HALO];
+                    sX += Xc * wc;
+                    sX2 += Xc * Xc * wc;
+                    sY += Yc * wc;
+                    sY2 += Yc * Yc * wc;
+                    sXY += Xc * Yc * wc;
+                }
+                win[k][0] = sX; win[k][1] = sX2; win[k][2] = sY; win[k][3] = sY2; win[k][4] = sXY;
+                __syncthreads(); // row buffer may be overwritten two rows later; keeps parity reuse safe
+
+                if (i >= 2 * SSIM_HALO) {
+                    const int yo = y0 + i - 2 * SSIM_HALO;
+                    // vertical 11-tap pass from the register ring; tap j sits in slot (k+1+j)%11
+                    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, o4 = 0.f;
+#pragma unroll
+                    for (int d = 1; d <= SSIM_HALO; ++d) {
+                        const float w = g[SSIM_HALO - d];
+                        const int st = (k + 1 + SSIM_HALO - d) % 11, sb = (k + 1 + SSIM_HALO + d) % 11;
+                        o0 += (win[st][0] + win[sb][0]) * w;
+                        o1 += (win[st][1] + win[sb][1]) * w;
+                        o2 += (win[st][2] + win[sb][2]) * w;
+                        o3 += (win[st][3] + win[sb][3]) * w;
+                        o4 += (win[st][4] + win[sb][4]) * w;
+                    }
+                    {
+                        const int sc = (k + 1 + SSIM_HALO) % 11;
+                        const float wc = g[SSIM_HALO];
+                        o0 += win[sc][0] * wc; o1 += win[sc][1] * wc; o2 += win[sc][2] * wc;
+                        o3 += win[sc][3] * wc; o4 += win[sc][4] * wc;
+                    }
+                    if (yo < H && x < W) {
+                        const float mu1 = o0, mu2 = o2;
+                        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+                        const float sigma1_sq = o1 - mu1_sq;
+                        const float sigma2_sq = o3 - mu2_sq;
+                        const float sigma12 = o4 - mu1 * mu2;
+                        const float A = mu1_sq + mu2_sq + C1;
+                        const float Bv = sigma1_sq + sigma2_sq + C2;
+                        const float C_ = 2.f * mu1 * mu2 + C1;
+                        const float D_ = 2.f * sigma12 + C2;
+                        const float inv_AB = 1.f / (A * Bv);
+                        const int64_t o = plane + (int64_t)yo * W + x;
+                        ssim_map[o] = (C_ * D_) * inv_AB;
+                        if (TRAIN) {
+                            // d(ssim)/d(mu1), d/d(sigma1^2), d/d(sigma12): ssim.cu:260-274
+                            const float inv_A = 1.f / A, inv_B = 1.f / Bv;
+                            const float d_mu1 = (mu2 * 2.f * D_) * inv_AB - (mu2 * 2.f * C_) * inv_AB
+                                              - (mu1 * 2.f * C_ * D_) * inv_AB * inv_A
+                                              + (mu1 * 2.f * C_ * D_) * inv_AB * inv_B;
+                            dm_dmu1[o] = d_mu1;
+                            dm_dsigma1_sq[o] = (-C_ * D_) * inv_AB * inv_B;
+                            dm_dsigma12[o] = (2.f * C_) * inv_AB;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int RH>
+__global__ __launch_bounds__(64) void ssim_bwd_kernel(
+    int H, int W,
+    const float* __restrict__ img1, const float* __restrict__ img2,
+    const float* __restrict__ dL_dmap,  // per-pixel map, or nullptr => uniform dL_scalar
+    float dL_scalar,
+    const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
+    const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1)
+{
+    __shared__ float rowbuf[2][3][SSIM_ROWBUF];
+
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64;
+    const int y0 = blockIdx.y * RH;
+    const int64_t plane = (int64_t)blockIdx.z * H * W;
+
+    float g[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) g[i] = kGauss[i];
+
+    const int xa = x0 - SSIM_HALO + lane;
+    const int xb = x0 - SSIM_HALO + 64 + lane;
+    const bool xa_ok = (xa >= 0) && (xa < W);
+    const bool xb_ok = (lane < 2 * SSIM_HALO) && (xb < W);
+    const int x = x0 + lane;
+
+    float win[11][3];
+    constexpr int NROWS = RH + 2 * SSIM_HALO;
+
+    // fused (dm_d* x dL_dmap) products for one row, main + extra slot
+    float fa[3], fb[3];
+    auto fetch = [&](int i) {
+        const int r = y0 - SSIM_HALO + i;
+        const bool rok = (r >= 0) && (r < H) && (i < NROWS);
+        const int64_t off = plane + (int64_t)r * W;
+        if (rok && xa_ok) {
+            const float c = dL_dmap ? dL_dmap[off + xa] : dL_scalar;
+            fa[0] = dm_dmu1[off + xa] * c; fa[1] = dm_dsigma1_sq[off + xa] * c; fa[2] = dm_dsigma12[off + xa] * c;
+        } else { fa[0] = fa[1] = fa[2] = 0.f; }
+        if (rok && xb_ok) {
+            const float c = dL_dmap ? dL_dmap[off + xb] : dL_scalar;
+            fb[0] = dm_dmu1[off + xb] * c; fb[1] = dm_dsigma1_sq[off + xb] * c; fb[2] = dm_dsigma12[off + xb] * c;
+        } else { fb[0] = fb[1] = fb[2] = 0.f; }
+    };
+    fetch(0);
+
+    for (int base = 0; base < NROWS; base += 11) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const int i = base + k;
+            if (i < NROWS) {
+                const int par = k & 1;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rowbuf[par][q][lane] = fa[q];
+                if (lane < 2 * SSIM_HALO) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) rowbuf[par][q][64 + lane] = fb[q];
+                }
+                fetch(i + 1);
+                __syncthreads();
+
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                const float* r0 = &rowbuf[par][0][lane];
+                const float* r1 = &rowbuf[par][1][lane];
+                const float* r2 = &rowbuf[par][2][lane];
+#pragma unroll
+                for (int d = 1; d <= SSIM_HALO; ++d) {
+                    const float w = g[SSIM_HALO - d];
+                    s0 += (r0[SSIM_HALO - d] + r0[SSIM_HALO + d]) * w;
+                    s1 += (r1[SSIM_HALO - d] + r1[SSIM_HALO + d]) * w;
+                    s2 += (r2[SSIM_HALO - d] + r2[SSIM_HALO + d]) * w;
+                }
+                s0 += r0[SSIM_HALO] * g[SSIM_HALO];
+                s1 += r1[SSIM_HALO] * g[SSIM_HALO];
+                s2 += r2[SSIM_HALO] * g[SSIM_HALO];
+                win[k][0] = s0; win[k][1] = s1; win[k][2] = s2;
+                __syncthreads();
+
+                if (i >= 2 * SSIM_HALO) {
+                    const int yo = y0 + i - 2 * SSIM_HALO;
+                    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int d = 1; d <= SSIM_HALO; ++d) {
+                        const float w = g[SSIM_HALO - d];
+                        const int st = (k + 1 + SSIM_HALO - d) % 11, sb = (k + 1 + SSIM_HALO + d) % 11;
+                        t0 += (win[st][0] + win[sb][0]) * w;
+                        t1 += (win[st][1] + win[sb][1]) * w;
+                        t2 += (win[st][2] + win[sb][2]) * w;
+                    }
+                    {
+                        const int sc = (k + 1 + SSIM_HALO) % 11;
+                        t0 += win[sc][0] * g[SSIM_HALO];
+                        t1 += win[sc][1] * g[SSIM_HALO];
+                        t2 += win[sc][2] * g[SSIM_HALO];
+                    }
+                    if (yo < H && x < W) {
+                        const int64_t o = plane + (int64_t)yo * W + x;
+                        const float px1 = img1[o], px2 = img2[o];
+                        // ssim.cu:420
+                        dL_dimg1[o] = t0 + (2.f * px1) * t1 + px2 * t2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace adk
+
+extern "C" int adk_fused_ssim_fwd(const float* img1, const float* img2, int B, int CH, int H, int W,
+                                  float C1, float C2, float* ssim_map, float* dm_dmu1,
+                                  float* dm_dsigma1_sq, float* dm_dsigma12, hipStream_t stream)
+{
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return ADK_EINVAL;
+    if ((int64_t)B * CH * H * W == 0) return 0;
+    if (!img1 || !img2 || !ssim_map) return ADK_EINVAL;
+    const bool train = dm_dmu1 != nullptr;
+    if (train && (!dm_dsigma1_sq || !dm_dsigma12)) return ADK_EINVAL;
+    if ((int64_t)B * CH > 65535) return ADK_EUNSUPPORTED;
+    // Strip height: 32 rows when that still yields >= ~4 waves per SIMD, else 16.
+    const int64_t waves32 = adk::ceil_div(W, 64) * adk::ceil_div(H, 32) * B * CH;
+    const dim3 block(64);
+    if (waves32 >= 4096) {
+        const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 32), (unsigned)(B * CH));
+        if (train) hipLaunchKernelGGL((adk::ssim_fwd_kernel<32, true>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+        else hipLaunchKernelGGL((adk::ssim_fwd_kernel<32, false>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, nullptr, nullptr, nullptr);
+    } else {
+        const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 16), (unsigned)(B * CH));
+        if (train) hipLaunchKernelGGL((adk::ssim_fwd_kernel<16, true>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+        else hipLaunchKernelGGL((adk::ssim_fwd_kernel<16, false>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, nullptr, nullptr, nullptr);
+    }
+    ADK_RETURN_LAST_ERROR();
+}
+
+extern "C" int adk_fused_ssim_bwd(const float* img1, const float* img2, const float* dL_dmap, float dL_scalar,
+                                  const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                                  int B, int CH, int H, int W, float* dL_dimg1, hipStream_t stream)
+{
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return ADK_EINVAL;
+    if ((int64_t)B * CH * H * W == 0) return 0;
+    if (!img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return ADK_EINVAL;
+    if ((int64_t)B * CH > 65535) return ADK_EUNSUPPORTED;
+    const int64_t waves32 = adk::ceil_div(W, 64) * adk::ceil_div(H, 32) * B * CH;
+    const dim3 block(64);
+    if (waves32 >= 4096) {
+        const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 32), (unsigned)(B * CH));
+        hipLaunchKernelGGL((adk::ssim_bwd_kernel<32>), grid, block, 0, stream, H, W, img1, img2, dL_dmap, dL_scalar, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+    } else {
+        const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 16), (unsigned)(B * CH));
+        hipLaunchKernelGGL((adk::ssim_bwd_kernel<16>), grid, block, 0, stream, H, W, img1, img2, dL_dmap, dL_scalar, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+    }
+    ADK_RETURN_LAST_ERROR();
+}

@@ -1,0 +1,76 @@
+"""Drop-in for `diff_gaussian_rasterization` (on-the-fly-nvs fork [UPSTREAM, not vendored]).
+
+Symbols ARTDECO imports:
+  * adamUpdate, adamUpdateBasic           -- Reconstruct/scene/optimizers.py:14
+  * GaussianRasterizationSettings,
+    GaussianRasterizer                    -- Reconstruct/webviewer/scene_models.py:33-36
+
+All of them run on the HIP kernels of libartdeco_hip.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from artdeco_amd import _lib
+
+from ._rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401
+
+
+def _check_adam(param, grad, exp_avg, exp_avg_sq):
+    _lib.require_cuda(param, grad, exp_avg, exp_avg_sq)
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if t.dtype != torch.float32:
+            raise TypeError(f"adamUpdate: {n} must be float32")
+        if t.numel() != param.numel():
+            raise ValueError(f"adamUpdate: {n} has {t.numel()} elements, param has {param.numel()}")
+    for t, n in ((param, "param"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if not t.is_contiguous():
+            raise ValueError(f"adamUpdate: {n} must be contiguous (it is updated in place)")
+
+
+@torch.no_grad()
+def adamUpdate(param, param_grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps, N, M):
+    """In-place sparse Adam: only rows with visible[row] are touched (optimizers.py:116-128,144-156).
+
+    lr: 0-dim tensor, [N] tensor or tensor with param.numel() elements (per-Gaussian lr of
+    optimizers.py:212-219 / h3dgsv3.py:1240-1247).  No bias correction.
+    """
+    _check_adam(param, param_grad, exp_avg, exp_avg_sq)
+    N, M = int(N), int(M)
+    if N * M != param.numel():
+        raise ValueError(f"adamUpdate: N*M = {N * M} != param.numel() = {param.numel()}")
+    if N == 0 or M == 0:
+        return
+    _lib.require_cuda(visible)
+    if visible.numel() != N:
+        raise ValueError(f"adamUpdate: visible has {visible.numel()} entries, expected N = {N}")
+    if visible.dtype != torch.bool:
+        visible = visible != 0
+    visible = visible.contiguous()
+    if not torch.is_tensor(lr):
+        lr = torch.tensor(float(lr), dtype=torch.float32, device=param.device)
+    lr = lr.to(device=param.device, dtype=torch.float32).contiguous()
+    if lr.numel() not in (1, N, N * M):
+        raise ValueError(f"adamUpdate: lr has {lr.numel()} elements; expected 1, N or N*M")
+    grad = param_grad.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(param.device):
+        rc = lib.adk_adam_update(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                 visible.data_ptr(), lr.data_ptr(), lr.numel(), float(b1), float(b2), float(eps),
+                                 N, M, _lib.stream_of(param))
+    _lib.check(rc, "adk_adam_update")
+
+
+@torch.no_grad()
+def adamUpdateBasic(param, param_grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
+    """In-place dense Adam with a python-float lr (optimizers.py:48-57, :90-99)."""
+    _check_adam(param, param_grad, exp_avg, exp_avg_sq)
+    if param.numel() == 0:
+        return
+    grad = param_grad.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(param.device):
+        rc = lib.adk_adam_update_basic(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                       float(lr), float(b1), float(b2), float(eps), param.numel(),
+                                       _lib.stream_of(param))
+    _lib.check(rc, "adk_adam_update_basic")

@@ -1,0 +1,118 @@
+"""fused-SSIM: oracle vs the reference-generated golden vectors (CPU) and HIP vs oracle (GPU).
+
+Tolerances mirror the reference's own test (fused-ssim/tests/test.py:82,90): torch.isclose
+defaults rtol=1e-5 / atol=1e-8 on the scalar, and on the gradient.  For per-pixel maps we use
+rtol 1e-4 / atol 1e-6 (fp32 stencil sums in a different association order).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ssim_oracle
+
+from conftest import GOLDEN
+
+CASES = ["ssim_small", "ssim_ragged", "ssim_tiny"]
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_golden(name):
+    z = _load(name)
+    x = z["img1"].clone().requires_grad_(True)
+    val = ssim_oracle.fused_ssim_oracle(x, z["img2"])
+    val.backward()
+    assert torch.isclose(val.detach(), z["ssim"])
+    assert torch.allclose(x.grad, z["grad"], rtol=1e-5, atol=1e-8)
+
+
+def test_oracle_window_matches_kernel_table():
+    # the constants at ssim.cu:12-24 are gaussian(11, 1.5) in fp32
+    table = torch.tensor([0.001028380123898387, 0.0075987582094967365, 0.036000773310661316,
+                          0.10936068743467331, 0.21300552785396576, 0.26601171493530273,
+                          0.21300552785396576, 0.10936068743467331, 0.036000773310661316,
+                          0.0075987582094967365, 0.001028380123898387], dtype=torch.float32)
+    assert torch.equal(ssim_oracle.gaussian(11, 1.5), table)
+
+
+# ----------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_golden(name, dev):
+    from fused_ssim import fused_ssim
+    z = _load(name)
+    x = z["img1"].to(dev).requires_grad_(True)
+    val = fused_ssim(x, z["img2"].to(dev))
+    val.backward()
+    assert torch.isclose(val.detach().cpu(), z["ssim"])
+    assert torch.isclose(x.grad.cpu(), z["grad"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 384, 512), (2, 3, 100, 77), (1, 1, 1, 1), (1, 3, 5, 300),
+                                   (1, 2, 33, 64), (1, 1, 64, 65), (3, 5, 216, 384)])
+@pytest.mark.parametrize("padding", ["same", "valid"])
+def test_hip_matches_oracle(shape, padding, dev):
+    from fused_ssim import fused_ssim
+    B, CH, H, W = shape
+    if padding == "valid" and (H <= 10 or W <= 10):
+        pytest.skip("valid crop needs > 10 px")
+    g = torch.Generator().manual_seed(1234)
+    a, b = torch.rand(shape, generator=g), torch.rand(shape, generator=g)
+    xo = a.clone().requires_grad_(True)
+    vo = ssim_oracle.fused_ssim_oracle(xo, b, padding)
+    vo.backward()
+    xh = a.to(dev).requires_grad_(True)
+    vh = fused_ssim(xh, b.to(dev), padding)
+    vh.backward()
+    assert torch.isclose(vh.detach().cpu(), vo.detach())
+    assert torch.isclose(xh.grad.cpu(), xo.grad).all()
+
+
+@pytest.mark.gpu
+def test_hip_maps_match_oracle_per_pixel(dev):
+    from fused_ssim_cuda import fusedssim
+    g = torch.Generator().manual_seed(7)
+    a, b = torch.rand(2, 3, 150, 203, generator=g), torch.rand(2, 3, 150, 203, generator=g)
+    m = ssim_oracle.ssim_map(a, b)
+    mh, d1, d2, d3 = fusedssim(ssim_oracle.C1, ssim_oracle.C2, a.to(dev), b.to(dev), True)
+    assert torch.allclose(mh.cpu(), m, rtol=1e-4, atol=1e-6)
+    assert d1.shape == a.shape and d2.shape == a.shape and d3.shape == a.shape
+    # inference mode returns the same map and empty derivative tensors (ssim.cu:458-460)
+    mi, e1, e2, e3 = fusedssim(ssim_oracle.C1, ssim_oracle.C2, a.to(dev), b.to(dev), False)
+    assert torch.equal(mi, mh) and e1.numel() == e2.numel() == e3.numel() == 0
+
+
+@pytest.mark.gpu
+def test_hip_weighted_map_gradient(dev):
+    """Non-uniform dL/dmap (not just .mean()) through the custom backward."""
+    from fused_ssim import FusedSSIMMap
+    g = torch.Generator().manual_seed(9)
+    a, b, w = (torch.rand(1, 3, 90, 120, generator=g) for _ in range(3))
+    xo = a.clone().requires_grad_(True)
+    (ssim_oracle.ssim_map(xo, b) * w).sum().backward()
+    xh = a.to(dev).requires_grad_(True)
+    (FusedSSIMMap.apply(ssim_oracle.C1, ssim_oracle.C2, xh, b.to(dev), "same", True) * w.to(dev)).sum().backward()
+    assert torch.allclose(xh.grad.cpu(), xo.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_full_resolution_properties(dev):
+    """1080p x 3ch (BASELINE config 3): size-independent properties instead of an oracle run.
+    ssim(x, x) == 1 everywhere; symmetric in its arguments; in [-1, 1]."""
+    from fused_ssim import fused_ssim
+    from fused_ssim_cuda import fusedssim
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(1, 3, 1080, 1920, generator=g).to(dev)
+    b = torch.rand(1, 3, 1080, 1920, generator=g).to(dev)
+    assert torch.isclose(fused_ssim(a, a, train=False), torch.tensor(1.0, device=dev), atol=1e-5)
+    mab = fusedssim(1e-4, 9e-4, a, b, False)[0]
+    mba = fusedssim(1e-4, 9e-4, b, a, False)[0]
+    assert torch.allclose(mab, mba, rtol=1e-5, atol=1e-6)
+    assert mab.max() <= 1.0 + 1e-5 and mab.min() >= -1.0 - 1e-5
