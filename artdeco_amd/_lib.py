@@ -37,13 +37,15 @@ class AdkError(RuntimeError):
 
 
 def parse_header(path: str = HEADER) -> dict[str, list[tuple[str, str]]]:
-    """Return {symbol: [(ctype_name_or_'ptr', arg_name), ...]} for every `int adk_*(...)`."""
+    """Return {symbol: [(ctype_name_or_'ptr', arg_name), ...]} for every `int|int64_t adk_*(...)`.
+    The return type is kept in RETURN_TYPES[symbol]."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     out: dict[str, list[tuple[str, str]]] = {}
-    for m in re.finditer(r"\bint\s+(adk_\w+)\s*\(([^)]*)\)\s*;", src):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"\b(int|int64_t)\s+(adk_\w+)\s*\(([^)]*)\)\s*;", src):
+        rtype, name, args = m.group(1), m.group(2), m.group(3).strip()
+        RETURN_TYPES[name] = rtype
         parsed: list[tuple[str, str]] = []
         if args and args != "void":
             for a in args.split(","):
@@ -56,6 +58,8 @@ def parse_header(path: str = HEADER) -> dict[str, list[tuple[str, str]]]:
         out[name] = parsed
     return out
 
+
+RETURN_TYPES: dict[str, str] = {}
 
 _lock = threading.Lock()
 _lib = None
@@ -84,7 +88,7 @@ def load():
         protos = parse_header()
         for name, args in protos.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
-            fn.restype = ctypes.c_int
+            fn.restype = _CTYPE[RETURN_TYPES[name]]
             fn.argtypes = [ctypes.c_void_p if t == "ptr" else _CTYPE[t] for t, _ in args]
         if lib.adk_abi_version() != _header_abi_version():
             raise AdkError("libartdeco_hip.so ABI version does not match include/artdeco_hip.h; rebuild")

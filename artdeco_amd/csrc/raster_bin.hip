@@ -1,0 +1,371 @@
+// Tile binning + depth ordering for gfx950.
+//
+// Replaces gsplat's isect_tiles + cub::DeviceRadixSort over 64-bit (tile | depth) keys +
+// isect_offset_encode [UPSTREAM gsplat >= 1.5, not vendored; SURVEY.md App. A item 3].
+// The OUTPUT is bit-identical to that pipeline (sorted isect_ids / flatten_ids, tile offsets),
+// the ROUTE is different and chosen for HBM traffic:
+//
+//   upstream : emit I (key64,val32) pairs, 6 LSD radix passes over I items of 12 B
+//              (~144 B of traffic per intersection);
+//   here     : (1) LSD radix sort of the N per-Gaussian (depth bits, id) pairs -- 4 passes over
+//              N items of 8 B; (2) exclusive scan of tiles-per-Gaussian in depth order;
+//              (3) emit (tile id, Gaussian id) in depth order; (4) a STABLE radix sort on the
+//              tile id alone -- 2 passes over I items of 8 B.  Stability makes the final order
+//              (tile, depth, id) == the order of a stable sort on (tile<<32 | depth) with ties in
+//              emit order, i.e. exactly upstream's.  ~48 B of traffic per intersection at I ~ 3.5 N.
+//
+// Radix pass = 3 launches (per-block digit histogram, per-digit scan over blocks, stable
+// scatter).  The scatter ranks keys inside a wavefront with 8 ballots (wave64 match-any),
+// so a round of 256 keys costs ~3 barriers and no LDS atomics, and preserves input order.
+#include "adk_common.hpp"
+
+namespace adk {
+
+#define RS_BLOCK 256
+#define RS_ITEMS 16
+#define RS_CHUNK (RS_BLOCK * RS_ITEMS)
+
+__global__ __launch_bounds__(RS_BLOCK) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+                                                              uint32_t* __restrict__ block_hist, int nblocks)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int64_t i = base + r * RS_BLOCK + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    block_hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// One block per digit: exclusive scan of that digit's per-block counts, in place; digit total out.
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks,
+                                                         uint32_t* __restrict__ digit_total)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = block_hist + (int64_t)blockIdx.x * nblocks;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? row[i] : 0u;
+        uint32_t s = v; // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) row[i] = carry + woff + s - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ block_hist, int nblocks,
+    const uint32_t* __restrict__ digit_total)
+{
+    __shared__ uint32_t base[256];      // running global offset per digit for this block
+    __shared__ uint32_t wave_cnt[4][256];
+    __shared__ uint32_t wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // exclusive scan of the 256 digit totals (every block redoes it: 256 values, trivial)
+    {
+        const uint32_t v = digit_total[tid];
+        uint32_t s = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+        if (lane == 63) wtot[wv] = s;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wtot[w];
+        base[tid] = woff + s - v + block_hist[(int64_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
+    }
+    __syncthreads();
+
+    const unsigned long long lanes_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t blk_base = (int64_t)blockIdx.x * RS_CHUNK;
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int64_t i = blk_base + r * RS_BLOCK + tid;
+        if (blk_base + r * RS_BLOCK >= n) break; // uniform
+        const bool ok = i < n;
+        uint32_t key = 0, val = 0;
+        if (ok) { key = keys_in[i]; val = vals_in[i]; }
+        const uint32_t d = (key >> shift) & 255u;
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & lanes_lt);
+        if (ok && rank == 0) wave_cnt[wv][d] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (ok) {
+            uint32_t off = base[d] + rank;
+            for (int w = 0; w < wv; ++w) off += wave_cnt[w][d];
+            keys_out[off] = key;
+            vals_out[off] = val;
+        }
+        __syncthreads();
+        {
+            const uint32_t c = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+            base[tid] += c;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// Scratch needed by one radix sort over n items: histogram table + digit totals.
+static inline int64_t radix_scratch_bytes(int64_t n) {
+    const int64_t nb = ceil_div(n > 0 ? n : 1, RS_CHUNK);
+    return (256 * nb + 256) * (int64_t)sizeof(uint32_t);
+}
+
+// LSD sort of (key,val) pairs on bits [bit_lo, bit_hi).  Ping-pongs between (k0,v0) and (k1,v1);
+// the first pass reads (k_src,v_src) which is left untouched.  Returns index (0/1) of the buffer
+// holding the result.
+static int radix_sort_pairs(const uint32_t* k_src, const uint32_t* v_src, uint32_t* k0, uint32_t* v0, uint32_t* k1,
+                            uint32_t* v1, int64_t n, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t stream)
+{
+    const int nb = (int)ceil_div(n, RS_CHUNK);
+    uint32_t* hist = scratch;
+    uint32_t* dtot = scratch + (int64_t)256 * nb;
+    const uint32_t* ki = k_src;
+    const uint32_t* vi = v_src;
+    int dst = 0;
+    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        uint32_t* ko = dst ? k1 : k0;
+        uint32_t* vo = dst ? v1 : v0;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_BLOCK), 0, stream, ki, n, shift, hist, nb);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, stream, hist, nb, dtot);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(RS_BLOCK), 0, stream, ki, vi, ko, vo, n, shift, hist, nb, dtot);
+        ki = ko; vi = vo;
+        dst ^= 1;
+    }
+    return dst ^ 1;
+}
+
+// ------------------------------------------------------------------ tiles-per-Gaussian scan (depth order)
+__global__ __launch_bounds__(256) void count_block_sums_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                               const int32_t* __restrict__ tiles_per_gauss, int N,
+                                                               uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t ws[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t c = (i < N) ? (uint32_t)tiles_per_gauss[sorted_ids[i]] : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// Single block: exclusive scan of block_sums (in place) + grand total.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nb,
+                                                               int64_t* __restrict__ total_out)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const uint32_t v = (i < nb) ? block_sums[i] : 0u;
+        uint32_t s = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < nb) block_sums[i] = carry + woff + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = (int64_t)carry_s;
+}
+
+__device__ __forceinline__ void tile_range_bin(float mx, float my, float rx, float ry, int tile_w, int tile_h,
+                                               int& x0, int& x1, int& y0, int& y1)
+{
+    const float ts = 16.0f;
+    const float tx = mx / ts, ty = my / ts, trx = rx / ts, try_ = ry / ts;
+    x0 = (int)fminf(fmaxf(floorf(tx - trx), 0.f), (float)tile_w);
+    x1 = (int)fminf(fmaxf(ceilf(tx + trx), 0.f), (float)tile_w);
+    y0 = (int)fminf(fmaxf(floorf(ty - try_), 0.f), (float)tile_h);
+    y1 = (int)fminf(fmaxf(ceilf(ty + try_), 0.f), (float)tile_h);
+}
+
+// Thread i handles the i-th Gaussian in depth order and writes its (tile id, Gaussian id) pairs
+// at the exclusive-scan offset, tiles in row-major order (y outer) like upstream's emit loop.
+__global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                   const int32_t* __restrict__ tiles_per_gauss,
+                                                   const float* __restrict__ rec, int N, int tile_w, int tile_h,
+                                                   const uint32_t* __restrict__ block_offs, int64_t capacity,
+                                                   uint32_t* __restrict__ tile_ids, uint32_t* __restrict__ gauss_ids)
+{
+    __shared__ uint32_t ws[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t g = 0, c = 0;
+    if (i < N) { g = sorted_ids[i]; c = (uint32_t)tiles_per_gauss[g]; }
+    uint32_t s = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+    if (lane == 63) ws[wv] = s;
+    __syncthreads();
+    uint32_t off = block_offs[blockIdx.x] + s - c;
+    for (int w = 0; w < wv; ++w) off += ws[w];
+    if (c == 0) return;
+    const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
+    const float4 a = r4[0], b = r4[1];
+    int x0, x1, y0, y1;
+    tile_range_bin(a.x, a.y, a.w, b.w, tile_w, tile_h, x0, x1, y0, y1);
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            if ((int64_t)off < capacity) { tile_ids[off] = (uint32_t)(ty * tile_w + tx); gauss_ids[off] = g; }
+            ++off;
+        }
+}
+
+// offsets[t] = first index in the tile-sorted list whose tile id >= t (isect_offset_encode).
+__global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ tile_sorted, int64_t n_isects,
+                                                           int n_tiles, int32_t* __restrict__ offsets)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n_isects == 0) { if (i < n_tiles) offsets[i] = 0; return; }
+    if (i >= n_isects) return;
+    const int cur = (int)tile_sorted[i];
+    const int prev = (i == 0) ? -1 : (int)tile_sorted[i - 1];
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+    if (i == n_isects - 1)
+        for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
+}
+
+__global__ __launch_bounds__(256) void make_isect_ids_kernel(const uint32_t* __restrict__ tile_sorted,
+                                                             const int32_t* __restrict__ flatten_ids,
+                                                             const uint32_t* __restrict__ depth_keys, int64_t n,
+                                                             int64_t* __restrict__ isect_ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    isect_ids[i] = ((int64_t)tile_sorted[i] << 32) | (int64_t)depth_keys[flatten_ids[i]];
+}
+
+} // namespace adk
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+// ---- stage 1: depth order of the Gaussians + scan of their tile counts --------------------------
+extern "C" int64_t adk_bin_depth_workspace_bytes(int N)
+{
+    if (N < 0) return ADK_EINVAL;
+    const int64_t n = N > 0 ? N : 1;
+    return 4 * align256(n * 4) + align256(adk::radix_scratch_bytes(n)) + 256;
+}
+
+// In : depth_keys[N] (u32, 0xFFFFFFFF = culled), gauss_ids[N] (= 0..N-1), tiles_per_gauss[N].
+// Out: sorted_ids[N] (Gaussian ids, front to back, ties by id), block_offs[ceil(N/256)] (exclusive
+//      scan of the per-256 sums of tiles_per_gauss in that order), *n_isects (int64, device).
+extern "C" int adk_bin_depth_order(int N, const uint32_t* depth_keys, const uint32_t* gauss_ids,
+                                   const int32_t* tiles_per_gauss, uint32_t* sorted_ids, uint32_t* block_offs,
+                                   int64_t* n_isects, void* workspace, int64_t workspace_bytes, hipStream_t stream)
+{
+    if (N < 0) return ADK_EINVAL;
+    if (!n_isects) return ADK_EINVAL;
+    if (N == 0) { return (int)hipMemsetAsync(n_isects, 0, sizeof(int64_t), stream); }
+    if (!depth_keys || !gauss_ids || !tiles_per_gauss || !sorted_ids || !block_offs || !workspace) return ADK_EINVAL;
+    if (workspace_bytes < adk_bin_depth_workspace_bytes(N) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
+    char* w = (char*)workspace;
+    const int64_t seg = align256((int64_t)N * 4);
+    uint32_t* k0 = (uint32_t*)w; uint32_t* v0 = (uint32_t*)(w + seg);
+    uint32_t* k1 = (uint32_t*)(w + 2 * seg); uint32_t* v1 = (uint32_t*)(w + 3 * seg);
+    uint32_t* scratch = (uint32_t*)(w + 4 * seg);
+    // depth bits of a positive float are < 0x7F800000 and the cull sentinel is 0xFFFFFFFF: 32 bits, 4 passes
+    const int res = adk::radix_sort_pairs(depth_keys, gauss_ids, k0, v0, k1, v1, N, 0, 32, scratch, stream);
+    const uint32_t* vres = res ? v1 : v0;
+    hipError_t e = hipMemcpyAsync(sorted_ids, vres, (size_t)N * 4, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    const int nb = (int)adk::ceil_div(N, 256);
+    hipLaunchKernelGGL(adk::count_block_sums_kernel, dim3(nb), dim3(256), 0, stream, sorted_ids, tiles_per_gauss, N, block_offs);
+    hipLaunchKernelGGL(adk::scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, block_offs, nb, n_isects);
+    ADK_RETURN_LAST_ERROR();
+}
+
+// ---- stage 2: emit in depth order, stable sort by tile, per-tile offsets -----------------------------
+extern "C" int64_t adk_bin_tiles_workspace_bytes(int64_t n_isects)
+{
+    if (n_isects < 0) return ADK_EINVAL;
+    const int64_t n = n_isects > 0 ? n_isects : 1;
+    return 4 * align256(n * 4) + align256(adk::radix_scratch_bytes(n)) + 256;
+}
+
+// n_isects is the HOST copy of the value stage 1 produced (the caller sized flatten_ids/tile_ids
+// with it).  Out: flatten_ids[I] (int32 Gaussian ids in (tile, depth, id) order), tile_ids[I]
+// (u32 tile of each entry, same order), offsets[tile_h*tile_w].
+extern "C" int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids, const uint32_t* block_offs,
+                             const int32_t* tiles_per_gauss, const float* rec, int width, int height,
+                             int32_t* flatten_ids, uint32_t* tile_ids, int32_t* offsets, void* workspace,
+                             int64_t workspace_bytes, hipStream_t stream)
+{
+    if (N < 0 || n_isects < 0 || width <= 0 || height <= 0 || !offsets) return ADK_EINVAL;
+    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    if (n_isects >= (int64_t)1 << 31) return ADK_EUNSUPPORTED;
+    if (n_isects == 0 || N == 0) {
+        hipLaunchKernelGGL(adk::tile_offsets_kernel, dim3((unsigned)adk::ceil_div(n_tiles, 256)), dim3(256), 0, stream, nullptr, (int64_t)0, n_tiles, offsets);
+        ADK_RETURN_LAST_ERROR();
+    }
+    if (!sorted_ids || !block_offs || !tiles_per_gauss || !rec || !flatten_ids || !tile_ids || !workspace) return ADK_EINVAL;
+    if (workspace_bytes < adk_bin_tiles_workspace_bytes(n_isects) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
+    char* w = (char*)workspace;
+    const int64_t seg = align256(n_isects * 4);
+    uint32_t* k0 = (uint32_t*)w; uint32_t* v0 = (uint32_t*)(w + seg);
+    uint32_t* k1 = (uint32_t*)(w + 2 * seg); uint32_t* v1 = (uint32_t*)(w + 3 * seg);
+    uint32_t* scratch = (uint32_t*)(w + 4 * seg);
+    const int nb = (int)adk::ceil_div(N, 256);
+    hipLaunchKernelGGL(adk::emit_kernel, dim3(nb), dim3(256), 0, stream, sorted_ids, tiles_per_gauss, rec, N, tile_w, tile_h, block_offs, n_isects, k0, v0);
+    int bits = 0;
+    while ((1 << bits) < n_tiles) ++bits;
+    const int bit_hi = ((bits + 7) / 8) * 8; // whole 8-bit digits covering the tile id
+    // source = (k0,v0); ping-pong between (k1,v1) and (k0,v0)
+    const int res = adk::radix_sort_pairs(k0, v0, k1, v1, k0, v0, n_isects, 0, bit_hi > 0 ? bit_hi : 8, scratch, stream);
+    // res==0 -> result in the "first" pair passed (k1,v1); res==1 -> (k0,v0)
+    const uint32_t* kres = res ? k0 : k1;
+    const uint32_t* vres = res ? v0 : v1;
+    hipError_t e = hipMemcpyAsync(tile_ids, kres, (size_t)n_isects * 4, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(flatten_ids, vres, (size_t)n_isects * 4, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(adk::tile_offsets_kernel, dim3((unsigned)adk::ceil_div(n_isects, 256)), dim3(256), 0, stream, tile_ids, n_isects, n_tiles, offsets);
+    ADK_RETURN_LAST_ERROR();
+}
+
+// Optional (meta parity): upstream's sorted 64-bit keys, rebuilt from the tile-sorted list.
+extern "C" int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int32_t* flatten_ids,
+                                      const uint32_t* depth_keys, int64_t* isect_ids, hipStream_t stream)
+{
+    if (n_isects < 0) return ADK_EINVAL;
+    if (n_isects == 0) return 0;
+    if (!tile_ids || !flatten_ids || !depth_keys || !isect_ids) return ADK_EINVAL;
+    hipLaunchKernelGGL(adk::make_isect_ids_kernel, dim3((unsigned)adk::ceil_div(n_isects, 256)), dim3(256), 0, stream, tile_ids, flatten_ids, depth_keys, n_isects, isect_ids);
+    ADK_RETURN_LAST_ERROR();
+}

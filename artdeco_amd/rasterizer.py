@@ -1,0 +1,203 @@
+"""Host side of the MI355X Gaussian rasteriser: one fused autograd node over the C-ABI stages.
+
+Mirrors what gsplat.rendering.rasterization does for ARTDECO's call
+(Reconstruct/scene/scene_models/h3dgsv3.py:664-680) but as ONE torch.autograd.Function per
+camera instead of upstream's chain (projection -> SH -> isect -> rasterize): the intermediate
+per-Gaussian tensors live in one packed 48 B record that both the tile kernels and the
+backward consume, and the only host synchronisation is the single read of n_isects that sizes
+the intersection list (upstream has the same one).
+"""
+from __future__ import annotations
+
+import threading
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+_COLOR_SH, _COLOR_RGB, _COLOR_DEPTH = 0, 1, 2
+
+
+@dataclass(frozen=True)
+class RasterConfig:
+    width: int
+    height: int
+    sh_degree: int            # used when color_mode == SH
+    sh_K: int
+    color_mode: int
+    eps2d: float
+    near_plane: float
+    far_plane: float
+    radius_clip: float
+    want_isect_ids: bool = False
+
+
+class _Workspace:
+    """Grow-only scratch per (device, stream); handed to the library as pointer + size."""
+
+    def __init__(self):
+        self._buf: dict[tuple, torch.Tensor] = {}
+        self._lock = threading.Lock()
+
+    def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        with self._lock:
+            buf = self._buf.get(key)
+            if buf is None or buf.numel() < nbytes:
+                # 288 GB of HBM: over-allocate by 1.5x so a slowly growing map never reallocates per step
+                buf = torch.empty(int(nbytes * 1.5) + 4096, dtype=torch.uint8, device=device)
+                self._buf[key] = buf
+            return buf
+
+
+_WS = _Workspace()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"rasterization: {name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class RasterizeGaussians(torch.autograd.Function):
+    """(means, quats, scales, opacities, colors, viewmat[4,4], K[3,3], backgrounds|None) ->
+    render_colors [H,W,4], render_alphas [H,W,1], + non-differentiable aux tensors."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmat, K, backgrounds, cfg: RasterConfig):
+        lib = _lib.load()
+        _lib.require_cuda(means, quats, scales, opacities, viewmat, K)
+        dev = means.device
+        N = means.shape[0]
+        W, H = cfg.width, cfg.height
+        tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
+        means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
+        opacities = _f32c(opacities, "opacities")
+        colors_c = _f32c(colors, "colors") if colors is not None else None
+        viewmat, K = _f32c(viewmat, "viewmats"), _f32c(K, "Ks")
+        bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            i32 = dict(dtype=torch.int32, device=dev)
+            rec = torch.empty(N, 12, dtype=torch.float32, device=dev)
+            radii = torch.empty(N, 2, **i32)
+            depth_keys = torch.empty(N, **i32)
+            gauss_ids = torch.empty(N, **i32)
+            tiles_per_gauss = torch.empty(N, **i32)
+            rc = lib.adk_project_fwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), opacities.data_ptr(),
+                                     _lib.ptr(colors_c), cfg.sh_K, cfg.sh_degree, cfg.color_mode, viewmat.data_ptr(),
+                                     K.data_ptr(), W, H, cfg.eps2d, cfg.near_plane, cfg.far_plane, cfg.radius_clip,
+                                     rec.data_ptr(), radii.data_ptr(), depth_keys.data_ptr(), gauss_ids.data_ptr(),
+                                     tiles_per_gauss.data_ptr(), stream)
+            _lib.check(rc, "adk_project_fwd")
+
+            sorted_ids = torch.empty(N, **i32)
+            block_offs = torch.empty((N + 255) // 256 + 1, **i32)
+            n_isects_dev = torch.empty(1, dtype=torch.int64, device=dev)
+            ws_bytes = lib.adk_bin_depth_workspace_bytes(N)
+            ws = _WS.get(dev, ws_bytes)
+            rc = lib.adk_bin_depth_order(N, depth_keys.data_ptr(), gauss_ids.data_ptr(), tiles_per_gauss.data_ptr(),
+                                         sorted_ids.data_ptr(), block_offs.data_ptr(), n_isects_dev.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), stream)
+            _lib.check(rc, "adk_bin_depth_order")
+            n_isects = int(n_isects_dev.item())  # the one host sync of the pipeline (sizes the list)
+
+            flatten_ids = torch.empty(n_isects, **i32)
+            tile_ids = torch.empty(n_isects, **i32)
+            offsets = torch.empty(tile_h, tile_w, **i32)
+            ws_bytes = lib.adk_bin_tiles_workspace_bytes(n_isects)
+            ws = _WS.get(dev, ws_bytes)
+            rc = lib.adk_bin_tiles(N, n_isects, sorted_ids.data_ptr(), block_offs.data_ptr(),
+                                   tiles_per_gauss.data_ptr(), rec.data_ptr(), W, H, flatten_ids.data_ptr(),
+                                   tile_ids.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            _lib.check(rc, "adk_bin_tiles")
+
+            render_colors = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
+            render_alphas = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
+            last_ids = torch.empty(H, W, **i32)
+            rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
+                                    _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(),
+                                    last_ids.data_ptr(), stream)
+            _lib.check(rc, "adk_raster_fwd")
+
+            isect_ids = torch.empty(0, dtype=torch.int64, device=dev)
+            if cfg.want_isect_ids:
+                isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+                rc = lib.adk_bin_make_isect_ids(n_isects, tile_ids.data_ptr(), flatten_ids.data_ptr(),
+                                                depth_keys.data_ptr(), isect_ids.data_ptr(), stream)
+                _lib.check(rc, "adk_bin_make_isect_ids")
+
+        ctx.cfg = cfg
+        ctx.n_isects = n_isects
+        ctx.has_bg = bg is not None
+        ctx.save_for_backward(means, quats, scales, colors_c if colors_c is not None else means.new_empty(0),
+                              viewmat, K, bg if bg is not None else means.new_empty(0), rec, radii, flatten_ids,
+                              offsets, render_alphas, last_ids)
+        aux = (radii, rec, tiles_per_gauss, flatten_ids, offsets, isect_ids, last_ids)
+        ctx.mark_non_differentiable(*aux)
+        return (render_colors, render_alphas) + aux
+
+    @staticmethod
+    def backward(ctx, v_colors, v_alphas, *unused):
+        lib = _lib.load()
+        cfg: RasterConfig = ctx.cfg
+        (means, quats, scales, colors, viewmat, K, bg, rec, radii, flatten_ids, offsets, render_alphas,
+         last_ids) = ctx.saved_tensors
+        dev = means.device
+        N = means.shape[0]
+        W, H = cfg.width, cfg.height
+        needs = ctx.needs_input_grad
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            v_colors = (v_colors if v_colors is not None else torch.zeros(H, W, 4, device=dev)).contiguous()
+            v_alphas = (v_alphas if v_alphas is not None else torch.zeros(H, W, 1, device=dev)).contiguous()
+            v_rec = torch.zeros(N, 12, dtype=torch.float32, device=dev)
+            rc = lib.adk_raster_bwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), ctx.n_isects,
+                                    bg.data_ptr() if ctx.has_bg else None, render_alphas.data_ptr(),
+                                    last_ids.data_ptr(), v_colors.data_ptr(), v_alphas.data_ptr(), v_rec.data_ptr(),
+                                    stream)
+            _lib.check(rc, "adk_raster_bwd")
+
+            v_means = torch.empty_like(means) if needs[0] else None
+            v_quats = torch.empty_like(quats) if needs[1] else None
+            v_scales = torch.empty_like(scales) if needs[2] else None
+            v_opac = torch.empty(N, dtype=torch.float32, device=dev) if needs[3] else None
+            has_colors = cfg.color_mode != _COLOR_DEPTH
+            v_cols = torch.empty_like(colors) if (needs[4] and has_colors) else None
+            v_viewmat = cam_grad = None
+            if needs[5]:
+                v_viewmat = torch.empty(4, 4, dtype=torch.float32, device=dev)
+                cam_grad = torch.zeros(16, dtype=torch.float32, device=dev)
+            rc = lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
+                                     colors.data_ptr() if has_colors else None, cfg.sh_K, cfg.sh_degree,
+                                     cfg.color_mode, viewmat.data_ptr(), K.data_ptr(), W, H, cfg.eps2d,
+                                     cfg.near_plane, cfg.far_plane, radii.data_ptr(), v_rec.data_ptr(),
+                                     _lib.ptr(v_means), _lib.ptr(v_quats), _lib.ptr(v_scales), _lib.ptr(v_opac),
+                                     _lib.ptr(v_cols), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), stream)
+            _lib.check(rc, "adk_project_bwd")
+        return v_means, v_quats, v_scales, v_opac, v_cols, v_viewmat, None, None, None
+
+
+def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,
+                  eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, backgrounds=None,
+                  depth_only=False, want_isect_ids=False):
+    """One camera.  colors: SH coefficients [N,K,3] when sh_degree is not None, else RGB [N,3]
+    (ignored when depth_only).  backgrounds: [4] (RGB+D channel order) or None."""
+    if depth_only:
+        mode, K_sh, deg, cols = _COLOR_DEPTH, 0, 0, None
+    elif sh_degree is not None:
+        if colors.dim() != 3 or colors.shape[-1] != 3:
+            raise ValueError(f"SH colours must be [N,K,3], got {tuple(colors.shape)}")
+        K_sh, deg, mode, cols = colors.shape[1], int(sh_degree), _COLOR_SH, colors
+        if not 0 <= deg <= 3:
+            raise NotImplementedError("sh_degree must be in 0..3")
+        if (deg + 1) ** 2 > K_sh:
+            raise ValueError(f"sh_degree {deg} needs {(deg + 1) ** 2} coefficients, colors has {K_sh}")
+    else:
+        if colors.dim() != 2 or colors.shape[-1] != 3:
+            raise NotImplementedError(f"post-activation colours must be [N,3], got {tuple(colors.shape)}")
+        mode, K_sh, deg, cols = _COLOR_RGB, 0, 0, colors
+    cfg = RasterConfig(int(width), int(height), deg, K_sh, mode, float(eps2d), float(near_plane),
+                       float(far_plane), float(radius_clip), bool(want_isect_ids))
+    return RasterizeGaussians.apply(means, quats, scales, opacities, cols, viewmat, K, backgrounds, cfg)

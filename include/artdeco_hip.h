@@ -82,6 +82,67 @@ int adk_adam_update(float* param, const float* grad, float* exp_avg, float* exp_
 int adk_adam_update_basic(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                           float b1, float b2, float eps, int64_t numel, adk_stream_t stream);
 
+/* ---------------------------------------------------------------------- gsplat
+ * The five stages behind gsplat.rendering.rasterization(...) [UPSTREAM gsplat >= 1.5, not
+ * vendored] as called at Reconstruct/scene/scene_models/h3dgsv3.py:664-680 (one camera per
+ * call; packed=False; rasterize_mode="classic"; tile 16).  Stage boundaries are where the
+ * caller must size a tensor (n_isects) -- everything else is fused.
+ *
+ * Packed per-Gaussian "splat record" rec[N][12] (three float4, 16 B aligned):
+ *   [0] mean2d.x [1] mean2d.y [2] opacity [3] radius_x | [4..6] conic a,b,c [7] radius_y |
+ *   [8..11] colour channels (color_mode 0/1: r,g,b,depth; 2: depth,0,0,0)
+ * Gradient record v_rec[N][12] mirrors it ([2] = v_opacity, [3],[7] unused).
+ */
+
+/* Replaces fully_fused_projection fwd + spherical_harmonics fwd + the counting half of
+ * isect_tiles.  colors_in: SH coefficients [N,sh_K,3] (color_mode 0), RGB [N,3] (1) or NULL (2).
+ * viewmat [4,4] world->camera and Kmat [3,3], row-major, DEVICE memory.
+ * Out: rec, radii int32 [N,2], depth_keys u32 [N] (float bits of z, 0xFFFFFFFF if culled),
+ * gauss_ids u32 [N] (0..N-1), tiles_per_gauss int32 [N]. */
+int adk_project_fwd(int N, const float* means, const float* quats, const float* scales,
+                    const float* opacities, const float* colors_in, int sh_K, int sh_degree, int color_mode,
+                    const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                    float near_plane, float far_plane, float radius_clip, float* rec, int32_t* radii,
+                    uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, adk_stream_t stream);
+
+/* Replaces fully_fused_projection bwd + spherical_harmonics bwd (+ the torch.inverse(viewmats)
+ * autograd edge of rasterization()).  Any v_* output may be NULL.  cam_grad: 16 zeroed floats of
+ * scratch, required iff v_viewmat [4,4] is requested. */
+int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
+                    const float* colors_in, int sh_K, int sh_degree, int color_mode, const float* viewmat,
+                    const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane,
+                    const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
+                    float* v_scales, float* v_opacities, float* v_colors, float* cam_grad,
+                    float* v_viewmat, adk_stream_t stream);
+
+/* Replaces isect_tiles + radix sort + isect_offset_encode, in two calls around the single
+ * point where the caller needs a size (n_isects).  Output order is bit-identical to a stable
+ * sort of upstream's 64-bit (tile<<32 | depth bits) keys. */
+int64_t adk_bin_depth_workspace_bytes(int N);
+int adk_bin_depth_order(int N, const uint32_t* depth_keys, const uint32_t* gauss_ids,
+                        const int32_t* tiles_per_gauss, uint32_t* sorted_ids, uint32_t* block_offs,
+                        int64_t* n_isects, void* workspace, int64_t workspace_bytes, adk_stream_t stream);
+int64_t adk_bin_tiles_workspace_bytes(int64_t n_isects);
+int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids, const uint32_t* block_offs,
+                  const int32_t* tiles_per_gauss, const float* rec, int width, int height,
+                  int32_t* flatten_ids, uint32_t* tile_ids, int32_t* offsets, void* workspace,
+                  int64_t workspace_bytes, adk_stream_t stream);
+/* Optional: rebuild upstream's sorted int64 isect_ids for meta['isect_ids']. */
+int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int32_t* flatten_ids,
+                           const uint32_t* depth_keys, int64_t* isect_ids, adk_stream_t stream);
+
+/* Replaces rasterize_to_pixels fwd: render_colors [H,W,4], render_alphas [H,W], last_ids [H,W];
+ * backgrounds [4] or NULL. */
+int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
+                   const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                   float* render_colors, float* render_alphas, int32_t* last_ids, adk_stream_t stream);
+
+/* Replaces rasterize_to_pixels bwd: accumulates into v_rec [N,12] (caller zero-fills it). */
+int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,
+                   const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                   const float* render_alphas, const int32_t* last_ids, const float* v_render_colors,
+                   const float* v_render_alphas, float* v_rec, adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
