@@ -34,10 +34,19 @@ SH_C0 = 0.2820947917738781
 SH_C1 = 0.48860251190292
 
 
+def _sqrt(t):
+    """Correctly rounded sqrt.  torch's CPU sqrt goes through MKL VML (<= 1 ulp, NOT correctly
+    rounded, and CPU-model dependent), which breaks bit-exactness of the fp32 integer path; numpy's
+    sqrt is the IEEE instruction.  The fp64 / autograd path keeps torch.sqrt."""
+    if t.dtype == torch.float32 and not t.requires_grad:
+        return torch.from_numpy(np.sqrt(t.detach().numpy()))
+    return torch.sqrt(t)
+
+
 # ----------------------------------------------------------------------------- projection
 def _quat_to_rotmat(q):
     w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-    inv_norm = 1.0 / torch.sqrt(((x * x + y * y) + z * z) + w * w)
+    inv_norm = 1.0 / _sqrt(((x * x + y * y) + z * z) + w * w)
     x, y, z, w = x * inv_norm, y * inv_norm, z * inv_norm, w * inv_norm
     x2, y2, z2 = x * x, y * y, z * z
     xy, xz, yz = x * y, x * z, y * z
@@ -128,14 +137,14 @@ def project(means, quats, scales, opacities, viewmat, K, width, height, eps2d=0.
         valid = valid & ~(op < thr)
         ratio = torch.where(valid, op / thr, torch.ones_like(op))
         lg = torch.log(ratio.double()).to(dt)
-        extend = torch.minimum(torch.tensor(3.33, dtype=dt), torch.sqrt(2.0 * lg))
+        extend = torch.minimum(torch.tensor(3.33, dtype=dt), _sqrt(2.0 * lg))
         d00, d11, dd = c00.detach(), c11.detach(), dets.detach()
         b = 0.5 * (d00 + d11)
-        tmp = torch.sqrt(torch.clamp_min(b * b - dd, 0.01))
+        tmp = _sqrt(torch.clamp_min(b * b - dd, 0.01))
         v1 = b + tmp
-        r1 = extend * torch.sqrt(v1)
-        rad_x = torch.ceil(torch.minimum(extend * torch.sqrt(torch.clamp_min(d00, 0)), r1))
-        rad_y = torch.ceil(torch.minimum(extend * torch.sqrt(torch.clamp_min(d11, 0)), r1))
+        r1 = extend * _sqrt(v1)
+        rad_x = torch.ceil(torch.minimum(extend * _sqrt(torch.clamp_min(d00, 0)), r1))
+        rad_y = torch.ceil(torch.minimum(extend * _sqrt(torch.clamp_min(d11, 0)), r1))
         valid = valid & ~((rad_x <= radius_clip) & (rad_y <= radius_clip))
         mx, my = m2x.detach(), m2y.detach()
         outside = (mx + rad_x <= 0) | (mx - rad_x >= width) | (my + rad_y <= 0) | (my - rad_y >= height)
@@ -174,7 +183,7 @@ def camera_position(viewmat):
 def sh_to_rgb(degree, dirs, coeffs):
     """spherical_harmonics() + the `clamp_min(colors + 0.5, 0)` of rasterization(): [N,3].
     dirs [N,3] (not normalised), coeffs [N,K,3] with K >= (degree+1)^2."""
-    inorm = 1.0 / torch.sqrt((dirs[:, 0] * dirs[:, 0] + dirs[:, 1] * dirs[:, 1]) + dirs[:, 2] * dirs[:, 2])
+    inorm = 1.0 / _sqrt((dirs[:, 0] * dirs[:, 0] + dirs[:, 1] * dirs[:, 1]) + dirs[:, 2] * dirs[:, 2])
     x, y, z = (dirs[:, 0] * inorm)[:, None], (dirs[:, 1] * inorm)[:, None], (dirs[:, 2] * inorm)[:, None]
     c = coeffs
     res = SH_C0 * c[:, 0]
