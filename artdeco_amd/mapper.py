@@ -1,0 +1,357 @@
+"""Host-side mirror of ARTDECO's mapper hot path, used by bench.py, smoke() and the tests.
+
+ARTDECO's own host code (Reconstruct/scene/scene_models/h3dgsv3.py, scene/optimizers.py,
+scene/keyframe.py) cannot travel to the GPU box and must not be copied, so this module restates
+JUST the hot-path operator interface with the same names, argument meaning and call order:
+
+  MapperScene.render(width, height, view_matrix, bg)      <- SceneModel.render           h3dgsv3.py:617-700
+  MapperScene.render_from_id(...)                         <- SceneModel.render_from_id   h3dgsv3.py:595-615
+  MapperScene.optimization_step(is_important)             <- SceneModel.optimization_step h3dgsv3.py:401-469
+  SparseGaussianAdam.step(vis, N, gvis, Ng) / BaseAdam    <- scene/optimizers.py:17-161
+  Keyframe (6D pose + t + 3x4 exposure, own BaseAdam)     <- scene/keyframe.py:103-125, 150-155, 186-191
+
+Every native call goes through the drop-in modules exactly as the reference's imports do
+(`gsplat.rendering.rasterization`, `fused_ssim`, `diff_gaussian_rasterization.adamUpdate*`), so what
+is timed here is the path `run_system.py` would exercise.  One deliberate deviation: the radial
+decay weights are cached per resolution (the reference rebuilds them on the CPU and uploads them
+every step, h3dgsv3.py:431 -> utils.py:818-827).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import artdeco_amd
+
+artdeco_amd.install_dropins()
+
+import gsplat  # noqa: E402  (drop-in)
+from diff_gaussian_rasterization import adamUpdate, adamUpdateBasic  # noqa: E402
+from fused_ssim import fused_ssim  # noqa: E402
+
+
+# ------------------------------------------------------------------------------- optimisers
+class BaseAdam:
+    """scene/optimizers.py:17-57: dense Adam over {name: {"val","lr"}} via adamUpdateBasic."""
+
+    @torch.no_grad()
+    def __init__(self, params, betas=(0.9, 0.999), eps=1e-15):
+        self.params, self.betas, self.eps = params, betas, eps
+        for p in self.params.values():
+            if "exp_avg" not in p:
+                p["exp_avg"] = torch.zeros_like(p["val"], memory_format=torch.preserve_format)
+                p["exp_avg_sq"] = torch.zeros_like(p["val"], memory_format=torch.preserve_format)
+
+    def zero_grad(self):
+        for p in self.params.values():
+            p["val"].grad = None
+
+    @torch.no_grad()
+    def step(self):
+        for p in self.params.values():
+            v = p["val"]
+            if v.grad is None:
+                continue
+            adamUpdateBasic(v, v.grad, p["exp_avg"], p["exp_avg_sq"], p["lr"], self.betas[0], self.betas[1], self.eps)
+
+
+_NO_OPT = ("id", "cls_id", "d_max")
+
+
+class SparseGaussianAdam(BaseAdam):
+    """scene/optimizers.py:59-161: visibility-gated Adam; lr is a 0-dim device tensor, or a
+    per-element tensor for keys in lr_dict (xyz), python floats for the mlp_* entries."""
+
+    def __init__(self, params, betas=(0.9, 0.999), eps=1e-15, lr_dict=None, device="cuda:0"):
+        super().__init__({k: v for k, v in params.items() if k not in _NO_OPT}, betas, eps)
+        self.all_params = params
+        self.lr_dict = lr_dict or {}
+        for key, p in self.params.items():
+            if key.startswith("mlp"):
+                continue
+            if key not in self.lr_dict:
+                p["lr"] = torch.tensor(p["lr"], dtype=torch.float, device=device)
+            else:
+                p["lr"] = torch.ones_like(p["val"]) * self.lr_dict[key]["lr_init"]
+
+    @torch.no_grad()
+    def step(self, visibility, N, global_visibility, N_global):
+        b1, b2 = self.betas
+        for key, p in self.params.items():
+            v = p["val"]
+            if v.grad is None:
+                continue
+            if key.startswith("mlp"):
+                adamUpdateBasic(v, v.grad, p["exp_avg"], p["exp_avg_sq"], p["lr"], b1, b2, self.eps)
+                if key in self.lr_dict:
+                    p["lr"] = max(p["lr"] * self.lr_dict[key]["lr_decay"], self.lr_dict[key]["lr_init"] * 0.1)
+                continue
+            vis, n = (global_visibility, N_global) if key == "global_feat" else (visibility, N)
+            adamUpdate(v, v.grad, p["exp_avg"], p["exp_avg_sq"], vis, p["lr"], b1, b2, self.eps, n, v.numel() // n)
+            if key in self.lr_dict:
+                p["lr"][vis] *= self.lr_dict[key]["lr_decay"]
+                p["lr"].clamp_min_(self.lr_dict[key]["lr_init"] * 0.1)
+
+
+# ------------------------------------------------------------------------------- keyframe
+def sixD2mtx(r):
+    """Reconstruct/utils.py:223-229."""
+    b1 = r[..., 0]
+    b1 = b1 / torch.norm(b1, dim=-1, keepdim=True)
+    b2 = r[..., 1] - torch.sum(b1 * r[..., 1], dim=-1, keepdim=True) * b1
+    b2 = b2 / torch.norm(b2, dim=-1, keepdim=True)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack([b1, b2, b3], dim=-1)
+
+
+def radial_decay_kernel(H, W, sigma=0.5):
+    """Reconstruct/utils.py:818-827."""
+    y = torch.linspace(-1, 1, steps=H)
+    x = torch.linspace(-1, 1, steps=W)
+    yy, xx = torch.meshgrid(y, x, indexing="ij")
+    return torch.exp(-(xx ** 2 + yy ** 2) / (2 * sigma ** 2))
+
+
+class Keyframe:
+    """The optimisable part of scene/keyframe.py: 6D rotation + translation + 3x4 exposure."""
+
+    def __init__(self, image, mono_idepth, Rt, device, lr_poses=1e-4, lr_exposure=1e-3, depth_loss_weight=1e-2,
+                 depth_loss_weight_decay=0.9, is_test=False):
+        self.device = device
+        self.image_pyr = [image]            # [3,H,W] at the training level
+        self.idepth_pyr = [mono_idepth]     # [1,H,W]
+        self.pyr_lvl = 0
+        self.is_test = is_test
+        self.depth_loss_weight = depth_loss_weight
+        self.depth_loss_weight_decay = depth_loss_weight_decay
+        self.rW2C = nn.Parameter(Rt[:3, :2].clone().contiguous())
+        self.tW2C = nn.Parameter(Rt[:3, 3].clone().contiguous())
+        self.exposure = nn.Parameter(torch.eye(3, 4, device=device))
+        params = {"rW2C": {"val": self.rW2C, "lr": lr_poses}, "tW2C": {"val": self.tW2C, "lr": lr_poses}}
+        if not is_test:
+            params["exposure"] = {"val": self.exposure, "lr": lr_exposure}
+        self.optimizer = BaseAdam(params, betas=(0.8, 0.99))
+        self.latest_invdepth = None
+
+    def get_Rt(self):
+        Rt = torch.eye(4, device=self.device)
+        Rt[:3, :3] = sixD2mtx(self.rW2C)
+        Rt[:3, 3] = self.tW2C
+        return Rt
+
+    def get_mono_idepth(self, lvl=0):
+        return self.idepth_pyr[lvl]
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    @torch.no_grad()
+    def step(self):
+        self.optimizer.step()
+        self.depth_loss_weight *= self.depth_loss_weight_decay
+
+
+# ------------------------------------------------------------------------------- scene
+class MapperScene:
+    """Parameter dictionary + render + optimisation step of the LoD Gaussian scene model."""
+
+    def __init__(self, width, height, fx, device, *, sh_degree=3, local_feat_dim=16, global_feat_dim=16,
+                 lambda_dssim=0.2, eps2d=0.01, rad_decay=math.sqrt(5.0), scaling_reg_factor=0.0,
+                 position_lr_init=5e-5, position_lr_decay=1 - 2e-5, feature_lr=5e-3, opacity_lr=0.1,
+                 scaling_lr=0.01, rotation_lr=2e-3, feat_lr=4e-3, mlp_cov_lr_init=4e-3, mlp_cov_lr_decay=1 - 2e-5):
+        self.device = torch.device(device)
+        self.width, self.height = width, height
+        self.tanfovx = width / (2 * fx)
+        self.tanfovy = height / (2 * fx)
+        self.active_sh_degree = sh_degree
+        self.lambda_dssim, self.eps2d, self.rad_decay = lambda_dssim, eps2d, rad_decay
+        self.scaling_reg_factor = scaling_reg_factor
+        self._lr = dict(xyz=position_lr_init, f_dc=feature_lr, f_rest=feature_lr / 20.0, scaling=scaling_lr,
+                        rotation=rotation_lr, opacity=opacity_lr, local_feat=feat_lr, global_feat=feat_lr)
+        self.lr_dict = {"xyz": {"lr_init": position_lr_init, "lr_decay": position_lr_decay}}
+        d = local_feat_dim + global_feat_dim
+        self.mlp_cov = nn.Sequential(nn.Linear(d, d), nn.ReLU(True), nn.Linear(d, 7)).to(self.device)
+        self.mlp_params = {}
+        for n, p in self.mlp_cov.named_parameters():
+            name = "mlp_cov_" + n.replace(".", "_")
+            self.mlp_params[name] = {"val": p, "lr": mlp_cov_lr_init}
+            self.lr_dict[name] = {"lr_init": mlp_cov_lr_init, "lr_decay": mlp_cov_lr_decay}
+        self.gaussian_params = {}
+        self.keyframes: list[Keyframe] = []
+        self._rdk = {}
+        self.local_feat_dim, self.global_feat_dim = local_feat_dim, global_feat_dim
+
+    # -- population ---------------------------------------------------------------------------
+    def set_gaussians(self, means, quats, log_scales, opacity_logits, sh, d_max=1e3, n_voxels=None, seed=0):
+        """Install N Gaussians (the state add_new_gaussians would have built, h3dgsv3.py:766-940)."""
+        dev = self.device
+        N = means.shape[0]
+        n_vox = n_voxels or max(1, N // 8)
+        g = torch.Generator().manual_seed(seed)
+        val = lambda t: t.to(dev).contiguous().requires_grad_(True)
+        P = self.gaussian_params = {
+            "cls_id": {"val": torch.randint(0, n_vox, (N, 1), generator=g).to(dev)},
+            "d_max": {"val": torch.full((N, 1), float(d_max), device=dev)},
+            "xyz": {"val": val(means)},
+            "f_dc": {"val": val(sh[:, :1, :])},
+            "f_rest": {"val": val(sh[:, 1:, :])},
+            "scaling": {"val": val(log_scales)},
+            "rotation": {"val": val(quats)},
+            "opacity": {"val": val(opacity_logits.reshape(N, 1))},
+            "local_feat": {"val": val(torch.zeros(N, self.local_feat_dim))},
+            "global_feat": {"val": val(torch.zeros(n_vox, self.global_feat_dim))},
+        }
+        for k, lr in self._lr.items():
+            P[k]["lr"] = lr
+        self.optimizer = SparseGaussianAdam({**P, **self.mlp_params}, (0.5, 0.99), lr_dict=self.lr_dict, device=dev)
+
+    def add_keyframe(self, kf: Keyframe):
+        self.keyframes.append(kf)
+
+    # -- reference-named accessors (h3dgsv3.py:332-372) --------------------------------------------
+    xyz = property(lambda s: s.gaussian_params["xyz"]["val"])
+    f_dc = property(lambda s: s.gaussian_params["f_dc"]["val"])
+    f_rest = property(lambda s: s.gaussian_params["f_rest"]["val"])
+    scaling = property(lambda s: torch.exp(s.gaussian_params["scaling"]["val"]))
+    rotation = property(lambda s: s.gaussian_params["rotation"]["val"])
+    opacity = property(lambda s: torch.sigmoid(s.gaussian_params["opacity"]["val"]))
+    cls_id = property(lambda s: s.gaussian_params["cls_id"]["val"])
+    d_max = property(lambda s: s.gaussian_params["d_max"]["val"])
+    local_feat = property(lambda s: s.gaussian_params["local_feat"]["val"])
+    global_feat = property(lambda s: s.gaussian_params["global_feat"]["val"])
+
+    # -- render: h3dgsv3.py:617-700 -------------------------------------------------------------------
+    def render(self, width, height, view_matrix, bg=None):
+        dev = self.device
+        bg = torch.zeros(3, device=dev) if bg is None else bg
+        xyz = self.xyz
+        cam_centre = view_matrix.detach().inverse()[:3, 3].to(dev)
+        ob_dist = (xyz - cam_centre).norm(dim=1, keepdim=True)
+        selection_mask = (ob_dist < 2 * self.d_max).squeeze(-1)
+        alpha_mask = torch.logical_and(ob_dist > self.d_max, ob_dist < 2 * self.d_max).squeeze(-1)
+        alpha_ratio = (2 * self.d_max - ob_dist) / self.d_max
+        alpha_ratio[~alpha_mask] = 1.0
+
+        xyz = xyz[selection_mask]
+        opacity = (self.opacity * alpha_ratio)[selection_mask]
+        scaling = self.scaling[selection_mask]
+        rotation = self.rotation[selection_mask]
+        feats = torch.concat([self.f_dc[selection_mask], self.f_rest[selection_mask]], dim=1)
+        fl_x, fl_y = width / (2 * self.tanfovx), height / (2 * self.tanfovy)
+        Ks = torch.tensor([[fl_x, 0, width / 2.0], [0, fl_y, height / 2.0], [0, 0, 1]], device=dev)[None]
+        local_feat = self.local_feat[selection_mask]
+        ids = self.cls_id[selection_mask].squeeze(-1).long()
+        scale_rot = self.mlp_cov(torch.cat([self.global_feat[ids], local_feat], dim=1))
+        scaling = scaling * torch.sigmoid(scale_rot[:, :3])
+        rotation = F.normalize(rotation * scale_rot[:, 3:])
+
+        colors, alphas, meta = gsplat.rendering.rasterization(
+            means=xyz, quats=rotation, scales=scaling, opacities=opacity.squeeze(-1), colors=feats,
+            viewmats=view_matrix.unsqueeze(0), Ks=Ks, width=width, height=height, render_mode="RGB+D",
+            rasterize_mode="classic", absgrad=False, packed=False, sh_degree=self.active_sh_degree, eps2d=self.eps2d)
+
+        rendered_color = colors[..., 0:3].permute([0, 3, 1, 2])
+        rendered_depth = colors[..., 3:4].permute([0, 3, 1, 2])
+        rendered_alpha = alphas.permute([0, 3, 1, 2])
+        rendered_color = rendered_color + (1.0 - rendered_alpha) * bg[None, :, None, None]
+        invdepth = 1.0 / rendered_depth
+        visible_mask = torch.zeros_like(selection_mask, dtype=torch.bool, device=dev)
+        visible_mask[selection_mask.clone()] = meta["radii"][0].max(dim=1).values > 0
+        global_visible_mask = torch.zeros(len(self.global_feat), dtype=torch.bool, device=dev)
+        global_visible_mask[self.cls_id[visible_mask].squeeze(-1)] = True
+        return {"render": rendered_color[0], "invdepth": invdepth[0], "visibility_filter": visible_mask,
+                "global_visibility_filter": global_visible_mask, "scale": scaling}
+
+    def render_from_id(self, keyframe_id, pyr_lvl=0, bg=None):
+        kf = self.keyframes[keyframe_id]
+        view_matrix = kf.get_Rt().to(self.device)
+        scale = 2 ** pyr_lvl
+        width, height = self.width // scale, self.height // scale
+        pkg = self.render(width, height, view_matrix, bg)
+        pkg["render"] = (kf.exposure[:3, :3] @ pkg["render"].view(3, -1)) + kf.exposure[:3, 3, None]
+        pkg["render"] = pkg["render"].clamp(0, 1).view(3, height, width)
+        return pkg
+
+    def _rdk_for(self, h, w):
+        key = (h, w)
+        if key not in self._rdk:
+            self._rdk[key] = radial_decay_kernel(h, w, self.rad_decay).to(self.device)
+        return self._rdk[key]
+
+    # -- optimisation step: h3dgsv3.py:401-469 ------------------------------------------------------------
+    def optimization_step(self, keyframe_id=-1, is_important=True):
+        if len(self.xyz) == 0:
+            return None
+        kf = self.keyframes[keyframe_id]
+        lvl = kf.pyr_lvl
+        kf.zero_grad()
+        self.optimizer.zero_grad()
+        pkg = self.render_from_id(keyframe_id, pyr_lvl=lvl, bg=torch.rand(3, device=self.device))
+        image, invdepth, scale = pkg["render"], pkg["invdepth"], pkg["scale"]
+        gt_image = kf.image_pyr[lvl]
+        mono_idepth = kf.get_mono_idepth(lvl)
+        c, h, w = image.shape
+        rdk = self._rdk_for(h, w)
+        if not is_important:
+            error_map = rdk * (image - gt_image).abs()
+            alpha_mask = ~((error_map[0] > 0.2) | (error_map[1] > 0.2) | (error_map[1] > 0.2))
+            image, gt_image = image * alpha_mask, gt_image * alpha_mask
+            invdepth, mono_idepth = invdepth * alpha_mask, mono_idepth * alpha_mask
+        l1_loss = (rdk * (image - gt_image).abs()).mean()
+        ssim_loss = 1 - fused_ssim(image[None], gt_image[None])
+        depth_loss = (rdk * (invdepth - mono_idepth).abs()).mean()
+        scaling_reg = scale.prod(dim=1).mean()
+        loss = (self.lambda_dssim * ssim_loss + (1 - self.lambda_dssim) * l1_loss
+                + kf.depth_loss_weight * depth_loss + self.scaling_reg_factor * scaling_reg)
+        loss.backward()
+        with torch.no_grad():
+            kf.step()
+            if not kf.is_test:
+                self.optimizer.step(pkg["visibility_filter"], pkg["visibility_filter"].shape[0],
+                                    pkg["global_visibility_filter"], pkg["global_visibility_filter"].shape[0])
+            kf.latest_invdepth = pkg["invdepth"].detach()
+        return loss.detach()
+
+
+# ------------------------------------------------------------------------------- synthetic workload
+def synthetic_cloud(N, width, height, seed=0, sh_k=16, z_range=(2.0, 6.0), sigma_px=2.0):
+    """Seeded frustum-uniform Gaussian cloud of SURVEY.md 8(d) (camera = identity, fx = fy = 0.8 W)."""
+    g = torch.Generator().manual_seed(seed)
+    fx = 0.8 * width
+    z = torch.rand(N, generator=g) * (z_range[1] - z_range[0]) + z_range[0]
+    u = torch.rand(N, generator=g) * 2.1 - 1.05
+    v = torch.rand(N, generator=g) * 2.1 - 1.05
+    means = torch.stack([u * z * width / (2 * fx), v * z * height / (2 * fx), z], -1)
+    s0 = sigma_px * 4.0 / fx
+    scales = torch.exp(math.log(s0) + 0.3 * torch.randn(N, 3, generator=g))
+    quats = torch.randn(N, 4, generator=g)
+    quats = quats / quats.norm(dim=1, keepdim=True)
+    opacities = torch.sigmoid(torch.randn(N, generator=g))
+    sh = 0.3 * torch.randn(N, sh_k, 3, generator=g)
+    return dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, fx=fx)
+
+
+def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4):
+    """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height)."""
+    c = synthetic_cloud(N, width, height, seed)
+    scene = MapperScene(width, height, c["fx"], device)
+    # Features start at zero (h3dgsv3.py:873-877), so mlp_cov initially outputs its last bias.
+    # Pin that bias so the effective scale = exp(scaling) * sigmoid(0) and rotation * 1: the raw
+    # log-scales are stored 2x larger and the rendered cloud has exactly the 8(d) statistics.
+    with torch.no_grad():
+        last = scene.mlp_cov[2]
+        last.weight.mul_(0.01)
+        last.bias.copy_(torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0]))
+    op = c["opacities"].clamp(1e-4, 1 - 1e-4)
+    scene.set_gaussians(c["means"], c["quats"], torch.log(2.0 * c["scales"]), torch.log(op / (1 - op)), c["sh"], seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for i in range(n_keyframes):
+        Rt = torch.eye(4)
+        Rt[:3, 3] = 0.02 * torch.randn(3, generator=g)
+        img = torch.rand(3, height, width, generator=g).to(device)
+        idepth = (0.15 + 0.35 * torch.rand(1, height, width, generator=g)).to(device)
+        scene.add_keyframe(Keyframe(img, idepth, Rt.to(device), torch.device(device)))
+    return scene

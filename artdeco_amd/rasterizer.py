@@ -9,6 +9,7 @@ the intersection list (upstream has the same one).
 """
 from __future__ import annotations
 
+import contextlib
 import threading
 from dataclasses import dataclass
 
@@ -17,6 +18,51 @@ import torch
 from . import _lib
 
 _COLOR_SH, _COLOR_RGB, _COLOR_DEPTH = 0, 1, 2
+
+
+class StageTimer:
+    """HIP-event timing of the native stages, recorded on the stream the kernels are launched on
+    (torch's current stream).  bench.py installs one with set_stage_timer() for the timed region;
+    when none is installed the stages run without any event overhead."""
+
+    def __init__(self):
+        self.events: dict[str, list] = {}
+
+    @contextlib.contextmanager
+    def stage(self, name: str):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        try:
+            yield
+        finally:
+            e1.record()
+            self.events.setdefault(name, []).append((e0, e1))
+
+    def summary_ms(self) -> dict[str, dict]:
+        torch.cuda.synchronize()
+        out = {}
+        for k, evs in self.events.items():
+            ts = [a.elapsed_time(b) for a, b in evs]
+            out[k] = {"mean_ms": sum(ts) / len(ts), "min_ms": min(ts), "count": len(ts)}
+        return out
+
+
+_TIMER: StageTimer | None = None
+_NULL = contextlib.nullcontext()
+
+
+def set_stage_timer(t: StageTimer | None) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+def _stage(name: str):
+    return _TIMER.stage(name) if _TIMER is not None else _NULL
+
+
+# Sizes of the most recent forward on this process (N Gaussians in, I tile intersections) --
+# bench.py reads them to turn kernel times into algorithmic bytes/s.
+LAST_STATS: dict[str, int] = {}
 
 
 @dataclass(frozen=True)
@@ -85,7 +131,8 @@ class RasterizeGaussians(torch.autograd.Function):
             depth_keys = torch.empty(N, **i32)
             gauss_ids = torch.empty(N, **i32)
             tiles_per_gauss = torch.empty(N, **i32)
-            rc = lib.adk_project_fwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), opacities.data_ptr(),
+            with _stage("project_fwd"):
+              rc = lib.adk_project_fwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), opacities.data_ptr(),
                                      _lib.ptr(colors_c), cfg.sh_K, cfg.sh_degree, cfg.color_mode, viewmat.data_ptr(),
                                      K.data_ptr(), W, H, cfg.eps2d, cfg.near_plane, cfg.far_plane, cfg.radius_clip,
                                      rec.data_ptr(), radii.data_ptr(), depth_keys.data_ptr(), gauss_ids.data_ptr(),
@@ -97,18 +144,21 @@ class RasterizeGaussians(torch.autograd.Function):
             n_isects_dev = torch.empty(1, dtype=torch.int64, device=dev)
             ws_bytes = lib.adk_bin_depth_workspace_bytes(N)
             ws = _WS.get(dev, ws_bytes)
-            rc = lib.adk_bin_depth_order(N, depth_keys.data_ptr(), gauss_ids.data_ptr(), tiles_per_gauss.data_ptr(),
+            with _stage("bin_depth_order"):
+              rc = lib.adk_bin_depth_order(N, depth_keys.data_ptr(), gauss_ids.data_ptr(), tiles_per_gauss.data_ptr(),
                                          sorted_ids.data_ptr(), block_offs.data_ptr(), n_isects_dev.data_ptr(),
                                          ws.data_ptr(), ws.numel(), stream)
             _lib.check(rc, "adk_bin_depth_order")
             n_isects = int(n_isects_dev.item())  # the one host sync of the pipeline (sizes the list)
+            LAST_STATS.update(N=N, I=n_isects, width=W, height=H)
 
             flatten_ids = torch.empty(n_isects, **i32)
             tile_ids = torch.empty(n_isects, **i32)
             offsets = torch.empty(tile_h, tile_w, **i32)
             ws_bytes = lib.adk_bin_tiles_workspace_bytes(n_isects)
             ws = _WS.get(dev, ws_bytes)
-            rc = lib.adk_bin_tiles(N, n_isects, sorted_ids.data_ptr(), block_offs.data_ptr(),
+            with _stage("bin_tiles"):
+              rc = lib.adk_bin_tiles(N, n_isects, sorted_ids.data_ptr(), block_offs.data_ptr(),
                                    tiles_per_gauss.data_ptr(), rec.data_ptr(), W, H, flatten_ids.data_ptr(),
                                    tile_ids.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), stream)
             _lib.check(rc, "adk_bin_tiles")
@@ -116,7 +166,8 @@ class RasterizeGaussians(torch.autograd.Function):
             render_colors = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
             render_alphas = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
             last_ids = torch.empty(H, W, **i32)
-            rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
+            with _stage("raster_fwd"):
+              rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
                                     _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(),
                                     last_ids.data_ptr(), stream)
             _lib.check(rc, "adk_raster_fwd")
@@ -153,7 +204,8 @@ class RasterizeGaussians(torch.autograd.Function):
             v_colors = (v_colors if v_colors is not None else torch.zeros(H, W, 4, device=dev)).contiguous()
             v_alphas = (v_alphas if v_alphas is not None else torch.zeros(H, W, 1, device=dev)).contiguous()
             v_rec = torch.zeros(N, 12, dtype=torch.float32, device=dev)
-            rc = lib.adk_raster_bwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), ctx.n_isects,
+            with _stage("raster_bwd"):
+              rc = lib.adk_raster_bwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), ctx.n_isects,
                                     bg.data_ptr() if ctx.has_bg else None, render_alphas.data_ptr(),
                                     last_ids.data_ptr(), v_colors.data_ptr(), v_alphas.data_ptr(), v_rec.data_ptr(),
                                     stream)
@@ -169,7 +221,8 @@ class RasterizeGaussians(torch.autograd.Function):
             if needs[5]:
                 v_viewmat = torch.empty(4, 4, dtype=torch.float32, device=dev)
                 cam_grad = torch.zeros(16, dtype=torch.float32, device=dev)
-            rc = lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
+            with _stage("project_bwd"):
+              rc = lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
                                      colors.data_ptr() if has_colors else None, cfg.sh_K, cfg.sh_degree,
                                      cfg.color_mode, viewmat.data_ptr(), K.data_ptr(), W, H, cfg.eps2d,
                                      cfg.near_plane, cfg.far_plane, radii.data_ptr(), v_rec.data_ptr(),

@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- mapper hot path on MI355X (see DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, one independent scene per rank)
+
+Workload (BASELINE.json metric "on-the-fly frames/sec + raster fwd+bwd ms @1M Gaussians 1080p"):
+config[2] -- 1 M Gaussians, 1920x1080, SH degree 3, RGB+D, L1 + fused-SSIM + inverse-depth loss,
+sparse Adam -- as a seeded synthetic cloud.  One "step" = one mapper optimisation
+step (render -> loss -> backward -> keyframe Adam -> sparse Gaussian Adam), exactly the body of
+SceneModel.optimization_step (h3dgsv3.py:401-469) driven through the reference's binding surface.
+frames/s = steps/s / steps_per_frame with steps_per_frame = 10 (run.sh --num_common_iterations 10).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+STEPS_PER_FRAME = 10   # run.sh: --num_common_iterations 10 (key frames use 20)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-detail", action="store_true", help="print per-stage timings to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle ("port") timed on this box's host cores on a bounded sample of the same workload:
+    a 1/16-area window (480x270, N/16 Gaussians => same splat density per pixel), one render +
+    fp32 autograd backward + SSIM + Adam in torch-CPU.  Scaled by 16 to the full frame."""
+    from oracle import gsplat_oracle as go
+    from oracle import ssim_oracle
+    W, H, N = args.width // 4, args.height // 4, args.gaussians // 16
+    torch.manual_seed(0)
+    sc = go.synthetic_scene(N, W, H, seed=0)
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    gt = torch.rand(3, H, W)
+    t0 = time.time()
+    r, a, _ = go.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
+                               sc["viewmat"], sc["K"], W, H, eps2d=0.01, grad_dtype=torch.float32)
+    img = r[..., :3].permute(2, 0, 1)
+    loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1 - ssim_oracle.fused_ssim_oracle(img[None], gt[None]))
+    loss.backward()
+    with torch.no_grad():
+        for v in leaves.values():  # dense torch Adam-style update as the CPU stand-in for adamUpdate
+            g = v.grad
+            m, s = 0.5 * g, 0.01 * g * g
+            v -= 1e-3 * m / (s.sqrt() + 1e-15)
+    dt = time.time() - t0
+    step_s_full = dt * 16.0
+    return {"value": 1.0 / (step_s_full * STEPS_PER_FRAME), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle (torch-CPU) render+loss+backward+update of a 1/16-area window ({W}x{H}, {N} Gaussians, "
+                      f"same density) = {dt:.1f} s, x16 to the full frame, /{STEPS_PER_FRAME} steps per frame"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; used for barrier + metric all-reduce only
+
+    from artdeco_amd import _lib, mapper, rasterizer
+    _lib.load()
+    torch.manual_seed(rank)
+    scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=rank)
+    nkf = len(scene.keyframes)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        scene.optimization_step(i % nkf)
+    timer = rasterizer.StageTimer()
+    rasterizer.set_stage_timer(timer)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        scene.optimization_step(i % nkf)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    rasterizer.set_stage_timer(None)
+    stages = timer.summary_ms()
+
+    # workload size seen by the kernels (last step): I intersections, V visible, P pixels
+    with torch.no_grad():
+        pkg = scene.render_from_id(0)
+    I, P = rasterizer.LAST_STATS["I"], args.width * args.height
+    V = int(pkg["visibility_filter"].sum())
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(args.steps), float(I), float(V)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)  # the ~24 B metric all-reduce
+    elapsed_max = float(t_max.item())
+    total_steps = float(agg[0].item())
+
+    if rank == 0:
+        frames_per_s = total_steps / STEPS_PER_FRAME / elapsed_max
+        bwd_ms = stages["raster_bwd"]["mean_ms"]
+        alg_bytes_bwd = 44.0 * I + 28.0 * P + 40.0 * V  # raster bwd
+        achieved = alg_bytes_bwd / (bwd_ms * 1e-3) / 1e9
+        out = {
+            "metric": "on-the-fly frames/sec (mapper hot path; raster fwd+bwd + L1 + fused-SSIM + sparse Adam) @1M Gaussians 1080p",
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 1M-Gaussian map, 1920x1080 render, RGB+D SH3, L1+fused-SSIM+invdepth loss, sparse Adam; one independent scene per GPU",
+                       "gaussians": args.gaussians, "width": args.width, "height": args.height,
+                       "steps_per_frame": STEPS_PER_FRAME, "intersections_I": I, "visible_V": V, "pixels_P": P,
+                       "parallelism": f"scene-per-gpu x{world}"},
+            "raster_fwd_ms": stages["raster_fwd"]["mean_ms"], "raster_bwd_ms": bwd_ms,
+            "stage_ms": {k: round(v["mean_ms"], 4) for k, v in stages.items()},
+            "roofline": {"bound": "hbm", "kernel": "raster_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profile(args),
+                         "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        if args.stage_detail:
+            print(json.dumps(stages, indent=1), file=sys.stderr)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _traffic_from_profile(args):
+    """HBM bytes per raster_bwd launch from the committed rocprofv3 PMC pass (profiles/), when it was
+    taken on this exact workload; otherwise null."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(p))
+        if (t.get("gaussians"), t.get("width"), t.get("height")) == (args.gaussians, args.width, args.height):
+            return t.get("raster_bwd_hbm_bytes")
+    except Exception:
+        pass
+    return None
+
+
+if __name__ == "__main__":
+    main()
