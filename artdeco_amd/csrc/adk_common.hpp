@@ -56,4 +56,28 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// ---- DPP cross-lane adds (VALU only: no LDS crossbar, no s_waitcnt) --------------------------------
+// dpp_ctrl encodings (GFX9): quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast:15 0x142, row_bcast:31 0x143.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(t);
+}
+// After this every lane of each 16-lane DPP row holds that row's sum (4 VALU instructions).
+__device__ __forceinline__ float row16_allreduce_sum(float v) {
+    v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v); // row_half_mirror
+    v = dpp_add<0x140>(v); // row_mirror
+    return v;
+}
+// Full 64-lane sum, valid in lane 63 only (6 VALU instructions).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = row16_allreduce_sum(v);
+    v = dpp_add<0x142, 0xa>(v); // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xc>(v); // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 } // namespace adk

@@ -243,13 +243,16 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
                     }
                     b0 += col.x * fac; b1 += col.y * fac; b2 += col.z * fac; b3 += col.w * fac;
                 }
+// 64 -> 4 with DPP row reductions (VALU only), then ONE ds_add_f32 in which lane
+                // (row*16 + k) adds row `row`'s partial of value k: the 4 rows meet in the LDS atomic.
 #pragma unroll
-                for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
-                if (lane < NACC) {
+                for (int k = 0; k < NACC; ++k) acc[k] = row16_allreduce_sum(acc[k]);
+                {
+                    const int kk = lane & 15;
                     float v = acc[0];
 #pragma unroll
-                    for (int k = 1; k < NACC; ++k) v = (lane == k) ? acc[k] : v;
-                    unsafeAtomicAdd(&sacc[t][lane], v);
+                    for (int k = 1; k < NACC; ++k) v = (kk == k) ? acc[k] : v;
+                    if (kk < NACC && v != 0.f) unsafeAtomicAdd(&sacc[t][kk], v);
                 }
             }
         }
