@@ -143,6 +143,22 @@ int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatt
                    const float* render_alphas, const int32_t* last_ids, const float* v_render_colors,
                    const float* v_render_alphas, float* v_rec, adk_stream_t stream);
 
+/* -------------------------------------------------------------- mast3r_slam_backends
+ * Replaces iter_proj(rays_img_with_grad, pts_3d_norm, p_init, max_iter, lambda_init, cost_thresh)
+ * -- VSLAM/backend/src/gn.cpp:84-99 -> matching_kernels.cu:119-316.
+ * rays [batch,h,w,9], pts [batch,n,3], p_init [batch,n,2] -> p_new [batch,n,2] float,
+ * converged [batch,n] (1 byte per entry, 0/1). */
+int adk_iter_proj(const float* rays_img_with_grad, const float* pts_3d_norm, const float* p_init, int batch,
+                  int h, int w, int n, int max_iter, float lambda_init, float cost_thresh, float* p_new,
+                  uint8_t* converged, adk_stream_t stream);
+
+/* Replaces refine_matches(D11, D21, p1, radius, dilation_max) -- gn.cpp:101-114 ->
+ * matching_kernels.cu:25-116.  dtype 0 = float16, 1 = float32 descriptors (score accumulates in
+ * that type).  D11 [batch,h,w,fdim], D21 [batch,n,fdim], p1/p1_new [batch,n,2] int64 (u,v). */
+int adk_refine_matches(const void* D11, const void* D21, const int64_t* p1, int dtype, int batch, int h,
+                       int w, int n, int fdim, int radius, int dilation_max, int64_t* p1_new,
+                       adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
