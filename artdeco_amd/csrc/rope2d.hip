@@ -1,0 +1,125 @@
+// In-place 2-D rotary position embedding for gfx950.
+//
+// Replaces rope_2d(tokens, positions, base, fwd) of the `curope` extension --
+// VSLAM/thirdparty/mast3r/dust3r/croco/models/curope/curope.cpp:49-65, kernels.cu:17-108
+// (wrapper curope2d.py:12-39): tokens [B,N,H,D] are rotated in place, the first D/2 channels by
+// the token's y position and the last D/2 by its x position; within a half, channel m (< D/4)
+// pairs with m + D/4 and turns by angle pos * fwd / base^(m / (D/4)).
+//
+// The reference uses one block per token with D (=64) threads and an LDS round trip per head.
+// Here a thread owns 4 consecutive rotation pairs of one token (two 16 B accesses per head),
+// computes its 4 (cos, sin) once and streams over all heads: no LDS, fully coalesced 16 B
+// traffic, 8 B of HBM traffic per element (read + write) -- a pure streaming kernel.
+#include "adk_common.hpp"
+#include <hip/hip_fp16.h>
+
+namespace adk {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4<__half> {
+    float v[4];
+    __device__ __forceinline__ void load(const __half* p) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        const __half2 a = *reinterpret_cast<const __half2*>(&t.x), b = *reinterpret_cast<const __half2*>(&t.y);
+        v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+    }
+    __device__ __forceinline__ void store(__half* p) const {
+        const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+        uint2 t; t.x = *reinterpret_cast<const unsigned*>(&a); t.y = *reinterpret_cast<const unsigned*>(&b);
+        *reinterpret_cast<uint2*>(p) = t;
+    }
+};
+
+// VEC path: D % 16 == 0.  One thread = (token, half X, group of 4 pair indices).
+template <typename T>
+__global__ __launch_bounds__(256) void rope2d_vec_kernel(T* __restrict__ tokens, const int64_t* __restrict__ pos,
+                                                         int64_t n_tokens, int N, int64_t stride_b, int64_t stride_n, int H, int D, float base, float fwd)
+{
+    const int Q = D >> 2, groups = Q >> 2, per_token = 2 * groups;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n_tokens * per_token) return;
+    const int64_t tok = tid / per_token;
+    const int r = (int)(tid - tok * per_token);
+    const int X = r / groups, m0 = (r - X * groups) * 4;
+    const float p = (float)pos[tok * 2 + X];
+    float c[4], s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float inv_freq = fwd / powf(base, (float)(m0 + j) / (float)Q);
+        const float f = p * inv_freq;
+        c[j] = cosf(f); s[j] = sinf(f);
+    }
+    T* tp = tokens + (tok / N) * stride_b + (tok % N) * stride_n + X * (D >> 1) + m0;
+    for (int h = 0; h < H; ++h, tp += D) {
+        Vec4<T> u, v, ou, ov;
+        u.load(tp); v.load(tp + Q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ou.v[j] = u.v[j] * c[j] - v.v[j] * s[j]; ov.v[j] = v.v[j] * c[j] + u.v[j] * s[j]; }
+        ou.store(tp); ov.store(tp + Q);
+    }
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<__half>(__half x) { return __half2float(x); }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ __half from_f<__half>(float x) { return __float2half(x); }
+
+// Generic path (D % 4 == 0): one thread = (token, half, pair).
+template <typename T>
+__global__ __launch_bounds__(256) void rope2d_scalar_kernel(T* __restrict__ tokens, const int64_t* __restrict__ pos,
+                                                            int64_t n_tokens, int N, int64_t stride_b, int64_t stride_n, int H, int D, float base, float fwd)
+{
+    const int Q = D >> 2, per_token = 2 * Q;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n_tokens * per_token) return;
+    const int64_t tok = tid / per_token;
+    const int r = (int)(tid - tok * per_token);
+    const int X = r / Q, m = r - X * Q;
+    const float f = (float)pos[tok * 2 + X] * (fwd / powf(base, (float)m / (float)Q));
+    const float c = cosf(f), s = sinf(f);
+    T* tp = tokens + (tok / N) * stride_b + (tok % N) * stride_n + X * (D >> 1) + m;
+    for (int h = 0; h < H; ++h, tp += D) {
+        const float u = to_f<T>(tp[0]), v = to_f<T>(tp[Q]);
+        tp[0] = from_f<T>(u * c - v * s);
+        tp[Q] = from_f<T>(v * c + u * s);
+    }
+}
+
+template <typename T>
+static int launch_rope(T* tokens, const int64_t* pos, int64_t n_tokens, int N, int64_t stride_b, int64_t stride_n, int H, int D, float base, float fwd, hipStream_t stream)
+{
+    const int epv = 16 / (int)sizeof(float); // elements per 4-wide access
+    const bool vec = (D % 16 == 0) && (((uintptr_t)tokens & 15) == 0) && (stride_b % epv == 0) && (stride_n % epv == 0);
+    if (vec) {
+        const int64_t work = n_tokens * 2 * (D / 16);
+        hipLaunchKernelGGL((rope2d_vec_kernel<T>), dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, tokens, pos, n_tokens, N, stride_b, stride_n, H, D, base, fwd);
+    } else {
+        const int64_t work = n_tokens * 2 * (D / 4);
+        hipLaunchKernelGGL((rope2d_scalar_kernel<T>), dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, tokens, pos, n_tokens, N, stride_b, stride_n, H, D, base, fwd);
+    }
+    ADK_RETURN_LAST_ERROR();
+}
+
+} // namespace adk
+
+// dtype: 0 = float16, 1 = float32.  tokens [B,N,H,D] with the last two dims dense (stride D, 1) and
+// arbitrary element strides for batch / token (the reference passes a transposed qkv view),
+// positions [B,N,2] int64 (y, x) contiguous.
+extern "C" int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, int B, int N, int64_t stride_b,
+                           int64_t stride_n, int H, int D, float base, float fwd, hipStream_t stream)
+{
+    if (B < 0 || N < 0 || H < 0 || D < 0 || (D & 3)) return ADK_EINVAL;
+    const int64_t n_tokens = (int64_t)B * N;
+    if (n_tokens == 0 || H == 0 || D == 0) return 0;
+    if (!tokens || !positions) return ADK_EINVAL;
+    if (dtype == 1) return adk::launch_rope<float>((float*)tokens, positions, n_tokens, N, stride_b, stride_n, H, D, base, fwd, stream);
+    if (dtype == 0) return adk::launch_rope<__half>((__half*)tokens, positions, n_tokens, N, stride_b, stride_n, H, D, base, fwd, stream);
+    return ADK_EUNSUPPORTED;
+}
