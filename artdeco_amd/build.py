@@ -29,6 +29,7 @@ EXTRA_FLAGS = {
     "adam.hip": ["-ffp-contract=off"],
     "raster_project.hip": ["-ffp-contract=off"],
     "matching.hip": ["-ffp-contract=off"],
+    "knn.hip": ["-ffp-contract=off"],
 }
 
 

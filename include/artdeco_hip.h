@@ -169,6 +169,30 @@ int adk_refine_matches(const void* D11, const void* D21, const int64_t* p1, int 
 int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, int B, int N, int64_t stride_b,
                 int64_t stride_n, int H, int D, float base, float fwd, adk_stream_t stream);
 
+/* -------------------------------------------------------------------- simple-knn
+ * Exact K nearest neighbours, squared distances, self excluded by index.  Workspace sized by the
+ * number of points the search structure is built over (P for the first two, N for indexQ).
+ * Unlike the reference (simple_knn.cu:200,203,480,483) nothing is copied to the host. */
+int64_t adk_knn_workspace_bytes(int64_t n_struct_points);
+
+/* Replaces distIndex2(points, K) = SimpleKNN::knn_index2 -- spatial.cu:28-41, simple_knn.cu:468-522.
+ * points [P,3]; dists float [P*K], indices int32 [P*K], row = input point; neighbour order within
+ * a row unspecified (ascending here); fewer than K neighbours leaves (FLT_MAX, -1).  K in 1..8, 12, 16. */
+int adk_knn_index2(const float* points, int P, int K, float* dists, int32_t* indices, void* workspace,
+                   int64_t workspace_bytes, adk_stream_t stream);
+
+/* Replaces distCUDA2(points) = SimpleKNN::knn -- spatial.cu:14-25, simple_knn.cu:188-227:
+ * mean_dists[P] = mean of the 3 smallest squared distances. */
+int adk_knn_mean_dist3(const float* points, int P, float* mean_dists, void* workspace,
+                       int64_t workspace_bytes, adk_stream_t stream);
+
+/* Replaces distIndexQ(points, q_idx, n_idx, K) = SimpleKNN::knn_indexQ -- spatial.cu:43-58,
+ * simple_knn.cu:592-651: queries points[q_idx[i]], candidates only points[n_idx[*]];
+ * dists/indices [Q*K] in query order. */
+int adk_knn_indexQ(const float* points, int P, const int32_t* q_idx, int Q, const int32_t* n_idx, int N,
+                   int K, float* dists, int32_t* indices, void* workspace, int64_t workspace_bytes,
+                   adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
