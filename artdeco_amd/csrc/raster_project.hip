@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* __restrict__ opacities, const float* __restrict__ colors_in, int sh_K, int color_mode,
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height, int tile_w, int tile_h,
-    float eps2d, float near_plane, float far_plane, float radius_clip,
+    float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth,
     float* __restrict__ rec, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
     uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss)
 {
@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     tile_range(P.m2x, P.m2y, rad_x, rad_y, tile_w, tile_h, x0, x1, y0, y1);
     tiles_per_gauss[g] = (y1 - y0) * (x1 - x0);
 
-    float col[4] = {0.f, 0.f, 0.f, P.mc[2]};
+    // depth channel: z (gsplat "RGB+D") or 1/z (the on-the-fly-nvs GaussianRasterizer adapter)
+    const float dchan = inv_depth ? P.rz : P.mc[2];
+    float col[4] = {0.f, 0.f, 0.f, dchan};
     if (color_mode == 0) {
         float dx = x - cam.campos[0], dy = y - cam.campos[1], dz = z - cam.campos[2];
         const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     } else if (color_mode == 1) {
         col[0] = colors_in[3 * g]; col[1] = colors_in[3 * g + 1]; col[2] = colors_in[3 * g + 2];
     } else {
-        col[0] = P.mc[2]; col[3] = 0.f;
+        col[0] = dchan; col[3] = 0.f;
     }
     r4[0] = make_float4(P.m2x, P.m2y, opac, rad_x);
     r4[1] = make_float4(P.ca, P.cb, P.cc, rad_y);
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* __restrict__ colors_in, int sh_K, int color_mode,
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height,
-    float eps2d, float near_plane, float far_plane,
+    float eps2d, float near_plane, float far_plane, int inv_depth,
     const int32_t* __restrict__ radii, const float* __restrict__ v_rec,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
     float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ cam_grad)
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         if (P.x_in) vmc[0] += -fx * rz2 * vJ[0][2]; else vmc[2] += -fx * rz3 * vJ[0][2] * P.tx;
         if (P.y_in) vmc[1] += -fy * rz2 * vJ[1][2]; else vmc[2] += -fy * rz3 * vJ[1][2] * P.ty;
         vmc[2] += -fx * rz2 * vJ[0][0] - fy * rz2 * vJ[1][1] + 2.f * fx * P.tx * rz3 * vJ[0][2] + 2.f * fy * P.ty * rz3 * vJ[1][2];
-        // (3) depth
-        vmc[2] += v_depth;
+        // (3) depth channel (z, or 1/z with d(1/z)/dz = -1/z^2)
+        vmc[2] += inv_depth ? -v_depth * rz2 : v_depth;
 
         // (4) p_c = R p + t
         const float (*R)[3] = cam.R;
@@ -601,7 +603,7 @@ __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, 
 extern "C" int adk_project_fwd(int N, const float* means, const float* quats, const float* scales,
                                const float* opacities, const float* colors_in, int sh_K, int sh_degree, int color_mode,
                                const float* viewmat, const float* Kmat, int width, int height, float eps2d,
-                               float near_plane, float far_plane, float radius_clip, float* rec, int32_t* radii,
+                               float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
                                uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, hipStream_t stream)
 {
     if (N < 0 || width <= 0 || height <= 0) return ADK_EINVAL;
@@ -615,7 +617,7 @@ extern "C" int adk_project_fwd(int N, const float* means, const float* quats, co
     const int deg = color_mode == 0 ? sh_degree : 0;
     ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_fwd_kernel<SH_DEG>), grid, block, 0, stream, N, means, quats,
                                             scales, opacities, colors_in, sh_K, color_mode, viewmat, Kmat, width, height,
-                                            tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, rec, radii,
+                                            tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, inv_depth, rec, radii,
                                             depth_keys, gauss_ids, tiles_per_gauss));
     ADK_RETURN_LAST_ERROR();
 }
@@ -623,7 +625,7 @@ extern "C" int adk_project_fwd(int N, const float* means, const float* quats, co
 extern "C" int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
                                const float* colors_in, int sh_K, int sh_degree, int color_mode, const float* viewmat,
                                const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane,
-                               const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
+                               int inv_depth, const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
                                float* v_scales, float* v_opacities, float* v_colors, float* cam_grad /*[16], zeroed*/,
                                float* v_viewmat /*[16] or NULL*/, hipStream_t stream)
 {
@@ -638,7 +640,7 @@ extern "C" int adk_project_bwd(int N, const float* means, const float* quats, co
         const int deg = color_mode == 0 ? sh_degree : 0;
         ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_bwd_kernel<SH_DEG>), grid, block, 0, stream, N, means,
                                                 quats, scales, colors_in, sh_K, color_mode, viewmat, Kmat, width, height,
-                                                eps2d, near_plane, far_plane, radii, v_rec, v_means, v_quats, v_scales,
+                                                eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales,
                                                 v_opacities, v_colors, cam_grad));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

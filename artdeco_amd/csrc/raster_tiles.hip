@@ -54,10 +54,12 @@ __device__ __forceinline__ TileCtx make_ctx(int tile_w, int n_tiles, int W, int 
 }
 
 // ---------------------------------------------------------------------------------- forward
+template <bool MAIN_ID>
 __global__ __launch_bounds__(256) void raster_fwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids)
+    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids,
+    int32_t* __restrict__ main_ids)
 {
     __shared__ float4 srec[BATCH][3];
     const int n_tiles = tile_w * tile_h;
@@ -73,6 +75,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     float T = 1.0f;
     int cur_idx = 0;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    float best_vis = 0.f;   // MAIN_ID: largest alpha*T seen and the list index that produced it
+    int best_idx = -1;
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
 
     for (int b = 0; b < num_batches; ++b) {
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
                             const float vis = alpha * T;
                             o0 += col.x * vis; o1 += col.y * vis; o2 += col.z * vis; o3 += col.w * vis;
                             cur_idx = batch_start + t;
+                            if (MAIN_ID && vis > best_vis) { best_vis = vis; best_idx = cur_idx; }
                             T = next_T;
                         }
                     }
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
         }
         reinterpret_cast<float4*>(render_colors)[pix] = make_float4(o0, o1, o2, o3);
         last_ids[pix] = cur_idx;
+        if (MAIN_ID) main_ids[pix] = best_idx >= 0 ? flatten_ids[best_idx] : -1;
     }
 }
 
@@ -272,18 +278,24 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
 
 } // namespace adk
 
-// render_colors [H,W,4], render_alphas [H,W], last_ids [H,W]; backgrounds [4] or NULL.
+// render_colors [H,W,4], render_alphas [H,W], last_ids [H,W]; backgrounds [4] or NULL; main_ids [H,W]
+// (Gaussian id with the largest alpha*T per pixel, -1 if none) or NULL.
 extern "C" int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
                               const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                              float* render_colors, float* render_alphas, int32_t* last_ids, hipStream_t stream)
+                              float* render_colors, float* render_alphas, int32_t* last_ids, int32_t* main_ids,
+                              hipStream_t stream)
 {
     if (width <= 0 || height <= 0 || n_isects < 0 || n_isects >= ((int64_t)1 << 31)) return ADK_EINVAL;
     if (!offsets || !render_colors || !render_alphas || !last_ids) return ADK_EINVAL;
     if (n_isects > 0 && (!rec || !flatten_ids)) return ADK_EINVAL;
     if (((uintptr_t)rec & 15) || ((uintptr_t)render_colors & 15)) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
-    hipLaunchKernelGGL(adk::raster_fwd_kernel, dim3(tile_w * tile_h), dim3(256), 0, stream, tile_w, tile_h, width, height,
-                       rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids);
+    if (main_ids)
+        hipLaunchKernelGGL(adk::raster_fwd_kernel<true>, dim3(tile_w * tile_h), dim3(256), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids, main_ids);
+    else
+        hipLaunchKernelGGL(adk::raster_fwd_kernel<false>, dim3(tile_w * tile_h), dim3(256), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids, nullptr);
     ADK_RETURN_LAST_ERROR();
 }
 

@@ -77,6 +77,8 @@ class RasterConfig:
     far_plane: float
     radius_clip: float
     want_isect_ids: bool = False
+    inv_depth: bool = False      # depth channel holds 1/z (GaussianRasterizer adapter)
+    want_main_ids: bool = False  # per-pixel id of the dominant Gaussian (GaussianRasterizer adapter)
 
 
 class _Workspace:
@@ -135,7 +137,7 @@ class RasterizeGaussians(torch.autograd.Function):
               rc = lib.adk_project_fwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), opacities.data_ptr(),
                                      _lib.ptr(colors_c), cfg.sh_K, cfg.sh_degree, cfg.color_mode, viewmat.data_ptr(),
                                      K.data_ptr(), W, H, cfg.eps2d, cfg.near_plane, cfg.far_plane, cfg.radius_clip,
-                                     rec.data_ptr(), radii.data_ptr(), depth_keys.data_ptr(), gauss_ids.data_ptr(),
+                                     int(cfg.inv_depth), rec.data_ptr(), radii.data_ptr(), depth_keys.data_ptr(), gauss_ids.data_ptr(),
                                      tiles_per_gauss.data_ptr(), stream)
             _lib.check(rc, "adk_project_fwd")
 
@@ -166,10 +168,11 @@ class RasterizeGaussians(torch.autograd.Function):
             render_colors = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
             render_alphas = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
             last_ids = torch.empty(H, W, **i32)
+            main_ids = torch.empty(H, W, **i32) if cfg.want_main_ids else None
             with _stage("raster_fwd"):
               rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
                                     _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(),
-                                    last_ids.data_ptr(), stream)
+                                    last_ids.data_ptr(), _lib.ptr(main_ids), stream)
             _lib.check(rc, "adk_raster_fwd")
 
             isect_ids = torch.empty(0, dtype=torch.int64, device=dev)
@@ -185,7 +188,8 @@ class RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, colors_c if colors_c is not None else means.new_empty(0),
                               viewmat, K, bg if bg is not None else means.new_empty(0), rec, radii, flatten_ids,
                               offsets, render_alphas, last_ids)
-        aux = (radii, rec, tiles_per_gauss, flatten_ids, offsets, isect_ids, last_ids)
+        aux = (radii, rec, tiles_per_gauss, flatten_ids, offsets, isect_ids, last_ids,
+               main_ids if main_ids is not None else torch.empty(0, **i32))
         ctx.mark_non_differentiable(*aux)
         return (render_colors, render_alphas) + aux
 
@@ -225,7 +229,7 @@ class RasterizeGaussians(torch.autograd.Function):
               rc = lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
                                      colors.data_ptr() if has_colors else None, cfg.sh_K, cfg.sh_degree,
                                      cfg.color_mode, viewmat.data_ptr(), K.data_ptr(), W, H, cfg.eps2d,
-                                     cfg.near_plane, cfg.far_plane, radii.data_ptr(), v_rec.data_ptr(),
+                                     cfg.near_plane, cfg.far_plane, int(cfg.inv_depth), radii.data_ptr(), v_rec.data_ptr(),
                                      _lib.ptr(v_means), _lib.ptr(v_quats), _lib.ptr(v_scales), _lib.ptr(v_opac),
                                      _lib.ptr(v_cols), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), stream)
             _lib.check(rc, "adk_project_bwd")
@@ -234,7 +238,7 @@ class RasterizeGaussians(torch.autograd.Function):
 
 def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,
                   eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, backgrounds=None,
-                  depth_only=False, want_isect_ids=False):
+                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False):
     """One camera.  colors: SH coefficients [N,K,3] when sh_degree is not None, else RGB [N,3]
     (ignored when depth_only).  backgrounds: [4] (RGB+D channel order) or None."""
     if depth_only:
@@ -252,5 +256,5 @@ def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, he
             raise NotImplementedError(f"post-activation colours must be [N,3], got {tuple(colors.shape)}")
         mode, K_sh, deg, cols = _COLOR_RGB, 0, 0, colors
     cfg = RasterConfig(int(width), int(height), deg, K_sh, mode, float(eps2d), float(near_plane),
-                       float(far_plane), float(radius_clip), bool(want_isect_ids))
+                       float(far_plane), float(radius_clip), bool(want_isect_ids), bool(inv_depth), bool(want_main_ids))
     return RasterizeGaussians.apply(means, quats, scales, opacities, cols, viewmat, K, backgrounds, cfg)

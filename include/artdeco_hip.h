@@ -98,11 +98,13 @@ int adk_adam_update_basic(float* param, const float* grad, float* exp_avg, float
  * isect_tiles.  colors_in: SH coefficients [N,sh_K,3] (color_mode 0), RGB [N,3] (1) or NULL (2).
  * viewmat [4,4] world->camera and Kmat [3,3], row-major, DEVICE memory.
  * Out: rec, radii int32 [N,2], depth_keys u32 [N] (float bits of z, 0xFFFFFFFF if culled),
- * gauss_ids u32 [N] (0..N-1), tiles_per_gauss int32 [N]. */
+ * gauss_ids u32 [N] (0..N-1), tiles_per_gauss int32 [N].
+ * inv_depth != 0 stores 1/z instead of z in the depth channel (the invdepth output of the
+ * on-the-fly-nvs GaussianRasterizer, Reconstruct/webviewer/scene_models.py:596). */
 int adk_project_fwd(int N, const float* means, const float* quats, const float* scales,
                     const float* opacities, const float* colors_in, int sh_K, int sh_degree, int color_mode,
                     const float* viewmat, const float* Kmat, int width, int height, float eps2d,
-                    float near_plane, float far_plane, float radius_clip, float* rec, int32_t* radii,
+                    float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
                     uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, adk_stream_t stream);
 
 /* Replaces fully_fused_projection bwd + spherical_harmonics bwd (+ the torch.inverse(viewmats)
@@ -111,7 +113,7 @@ int adk_project_fwd(int N, const float* means, const float* quats, const float* 
 int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
                     const float* colors_in, int sh_K, int sh_degree, int color_mode, const float* viewmat,
                     const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane,
-                    const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
+                    int inv_depth, const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
                     float* v_scales, float* v_opacities, float* v_colors, float* cam_grad,
                     float* v_viewmat, adk_stream_t stream);
 
@@ -132,10 +134,12 @@ int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int
                            const uint32_t* depth_keys, int64_t* isect_ids, adk_stream_t stream);
 
 /* Replaces rasterize_to_pixels fwd: render_colors [H,W,4], render_alphas [H,W], last_ids [H,W];
- * backgrounds [4] or NULL. */
+ * backgrounds [4] or NULL; main_ids [H,W] or NULL = id of the Gaussian with the largest alpha*T per
+ * pixel, -1 if none (mainGaussID of the on-the-fly-nvs GaussianRasterizer). */
 int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
                    const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                   float* render_colors, float* render_alphas, int32_t* last_ids, adk_stream_t stream);
+                   float* render_colors, float* render_alphas, int32_t* last_ids, int32_t* main_ids,
+                   adk_stream_t stream);
 
 /* Replaces rasterize_to_pixels bwd: accumulates into v_rec [N,12] (caller zero-fills it). */
 int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,

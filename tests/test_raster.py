@@ -209,3 +209,38 @@ def test_full_size_properties_1M_1080p(dev):
     assert float(a.min()) >= 0 and float(a.max()) <= 1 and bool(torch.isfinite(r).all())
     a.sum().backward()
     assert float(hl["opacities"].grad.min()) >= -1e-3
+
+
+@pytest.mark.gpu
+def test_gaussian_rasterizer_adapter(dev):
+    """diff_gaussian_rasterization.GaussianRasterizer (webviewer/scene_models.py:559-605) over the same
+    kernels: colour/alpha agree with the oracle at eps2d=0.3, invdepth is the composited 1/z, mainGaussID
+    is the arg-max contributor, radii = max(rx, ry); transposed view-matrix convention."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H, N = 128, 96, 4000
+    sc = dict(_scene(N, W, H, 4), viewmat=_tilted_viewmat(4))
+    fx = float(sc["K"][0, 0])
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    st = GaussianRasterizationSettings(H, W, W / (2 * fx), H / (2 * fx), bg.to(dev), 1.0, torch.eye(4, device=dev), 3,
+                                       torch.zeros(3, device=dev), False, False)
+    t = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
+    means = t["means"].clone().requires_grad_(True)
+    color, invdepth, main_id, radii = GaussianRasterizer(st)(
+        means, torch.zeros_like(t["means"]), t["opacities"][:, None], t["colors"][:, :1], t["colors"][:, 1:],
+        t["scales"], t["quats"], t["viewmat"].transpose(0, 1))
+    assert color.shape == (3, H, W) and invdepth.shape == (1, H, W) and main_id.shape == (1, H, W) and radii.shape == (N,)
+    assert main_id.dtype == torch.int32
+    ro, ao, ometa = go.rasterization(**sc, eps2d=0.3, render_mode="RGB", backgrounds=bg)
+    assert _close_frac(color.detach().cpu().permute(1, 2, 0), ro, 1e-4) >= 0.999
+    assert torch.equal(radii.cpu(), ometa["radii"].max(dim=1).values)
+    # invdepth: composite 1/z with the oracle's compositing stage
+    p = ometa["p32"]
+    inv = torch.where(p["valid"], 1.0 / p["depths"].clamp(min=1e-9), torch.zeros_like(p["depths"]))
+    rid, _, _ = go.rasterize_to_pixels(p["means2d"], p["conics"], inv[:, None], sc["opacities"], W, H, ometa["isects"])
+    assert _close_frac(invdepth.detach().cpu()[0], rid[..., 0], 1e-4) >= 0.999
+    # mainGaussID: -1 exactly where nothing was composited; otherwise a Gaussian covering that pixel's tile
+    mid = main_id[0].cpu()
+    assert bool(((mid == -1) == (ao[..., 0] == 0)).all())
+    assert int(mid.max()) < N
+    (color.sum() + invdepth.sum()).backward()
+    assert bool(torch.isfinite(means.grad).all()) and float(means.grad.abs().max()) > 0
