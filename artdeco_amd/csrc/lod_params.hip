@@ -1,0 +1,352 @@
+// Fused level-of-detail cull + covariance MLP + activations for gfx950.
+//
+// Replaces the torch glue of SceneModel.render between the parameter dictionary and the rasteriser,
+// Reconstruct/scene/scene_models/h3dgsv3.py:626-662:
+//     cam_centre = inverse(view)[:3,3] ; dist = |xyz - cam_centre|
+//     selection  = dist < 2 d_max ; opacity = sigmoid(o) * ((2 d_max - dist)/d_max on (d_max, 2 d_max), else 1)
+//     scale_rot  = mlp_cov([global_feat[cls_id], local_feat])     (Linear 32->32, ReLU, Linear 32->7)
+//     scaling    = exp(s) * sigmoid(scale_rot[:3]) ; rotation = normalize(rotation * scale_rot[3:])
+// which at 1 M Gaussians costs ~12 ms per step on MI355X in stock torch (seven boolean-mask gathers and
+// their index_put backwards, hipBLASLt fp32 GEMMs of shape [1M,32]x[32,32] at <2 % of roofline).
+//
+// Here: ONE streaming kernel per direction, one thread per Gaussian.
+//   * No compaction: a Gaussian outside its LoD range gets opacity 0, which the projection kernel
+//     culls (opacity < 1/255) -- the rendered result is identical to rendering the masked subset,
+//     and the visibility mask is simply radii > 0 over the full set.
+//   * The 32->32->7 MLP is evaluated per thread with wave-uniform (scalar-cache) weight reads.
+//   * Backward: per-thread matvecs for the feature gradients; the WEIGHT gradients
+//     dW1 = sum_g dz_g x_g^T (32x32) and dW2 = sum_g dy_g h_g^T (7x32) are the one true dense
+//     contraction of the mapper (K = number of Gaussians) and run on the matrix cores with
+//     v_mfma_f32_32x32x2_f32 (exact fp32), each wavefront contracting its 64 Gaussians from LDS;
+//     per-workgroup partials go to a scratch slab and a second tiny kernel reduces them, so the
+//     result is deterministic and needs no atomics.  global_feat gradients (gather by voxel id in
+//     the forward) are scattered with hardware fp32 atomics.
+//   * Only Gaussians that received a gradient (visible ones) do any backward work.
+#include "adk_common.hpp"
+
+namespace adk {
+
+#define LOD_G 16   // global_feat_dim (run.sh --global_feat_dim 16)
+#define LOD_L 16   // local_feat_dim  (run.sh --local_feat_dim 16)
+#define LOD_IN 32
+#define LOD_HID 32
+#define LOD_OUT 7
+#define LOD_NW (LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + LOD_OUT) // 1287 mlp parameters
+
+struct CamCentre { float c[3]; };
+
+__device__ __forceinline__ CamCentre cam_centre_of(const float* __restrict__ V) {
+    // -R^-1 t via the adjugate, same as raster_project.hip:load_cam
+    float R[3][3], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i][j] = V[i * 4 + j]; t[i] = V[i * 4 + 3]; }
+    const float c00 = R[1][1] * R[2][2] - R[1][2] * R[2][1], c01 = R[0][2] * R[2][1] - R[0][1] * R[2][2], c02 = R[0][1] * R[1][2] - R[0][2] * R[1][1];
+    const float c10 = R[1][2] * R[2][0] - R[1][0] * R[2][2], c11 = R[0][0] * R[2][2] - R[0][2] * R[2][0], c12 = R[0][2] * R[1][0] - R[0][0] * R[1][2];
+    const float c20 = R[1][0] * R[2][1] - R[1][1] * R[2][0], c21 = R[0][1] * R[2][0] - R[0][0] * R[2][1], c22 = R[0][0] * R[1][1] - R[0][1] * R[1][0];
+    const float id = 1.0f / ((R[0][0] * c00 + R[0][1] * c10) + R[0][2] * c20);
+    CamCentre o;
+    o.c[0] = -((c00 * t[0] + c01 * t[1] + c02 * t[2]) * id);
+    o.c[1] = -((c10 * t[0] + c11 * t[1] + c12 * t[2]) * id);
+    o.c[2] = -((c20 * t[0] + c21 * t[1] + c22 * t[2]) * id);
+    return o;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// x[32] = [global_feat[cls], local_feat[g]]
+__device__ __forceinline__ void load_features(const float* __restrict__ global_feat, const float* __restrict__ local_feat,
+                                              int64_t cls, int64_t g, float* x)
+{
+    const float4* gf = reinterpret_cast<const float4*>(global_feat + cls * LOD_G);
+    const float4* lf = reinterpret_cast<const float4*>(local_feat + g * LOD_L);
+#pragma unroll
+    for (int i = 0; i < LOD_G / 4; ++i) { const float4 v = gf[i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; }
+#pragma unroll
+    for (int i = 0; i < LOD_L / 4; ++i) { const float4 v = lf[i]; x[LOD_G + 4 * i] = v.x; x[LOD_G + 4 * i + 1] = v.y; x[LOD_G + 4 * i + 2] = v.z; x[LOD_G + 4 * i + 3] = v.w; }
+}
+
+// h = relu(W1 x + b1) ; y = W2 h + b2.  Weight indices are wave-uniform => scalar loads.
+__device__ __forceinline__ void mlp_forward(const float* __restrict__ W1, const float* __restrict__ b1,
+                                            const float* __restrict__ W2, const float* __restrict__ b2,
+                                            const float* x, float* h, float* y)
+{
+#pragma unroll
+    for (int i = 0; i < LOD_HID; ++i) {
+        float a = b1[i];
+#pragma unroll
+        for (int j = 0; j < LOD_IN; ++j) a += W1[i * LOD_IN + j] * x[j];
+        h[i] = fmaxf(a, 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < LOD_OUT; ++o) {
+        float a = b2[o];
+#pragma unroll
+        for (int i = 0; i < LOD_HID; ++i) a += W2[o * LOD_HID + i] * h[i];
+        y[o] = a;
+    }
+}
+
+struct LodGeom { float dist, alpha_ratio, inv_dmax; bool selected, fading; float dir[3]; };
+
+__device__ __forceinline__ LodGeom lod_geometry(const float* __restrict__ xyz, const float* __restrict__ d_max, int64_t g, const CamCentre& cc) {
+    LodGeom L;
+    const float dx = xyz[3 * g] - cc.c[0], dy = xyz[3 * g + 1] - cc.c[1], dz = xyz[3 * g + 2] - cc.c[2];
+    L.dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float dm = d_max[g];
+    L.selected = L.dist < 2.f * dm;
+    L.fading = (L.dist > dm) && (L.dist < 2.f * dm);
+    L.inv_dmax = 1.0f / dm;
+    L.alpha_ratio = L.fading ? (2.f * dm - L.dist) * L.inv_dmax : 1.0f;
+    const float id = L.dist > 0.f ? 1.0f / L.dist : 0.f;
+    L.dir[0] = dx * id; L.dir[1] = dy * id; L.dir[2] = dz * id;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void lod_params_fwd_kernel(
+    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
+    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
+    const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ viewmat, float* __restrict__ opac_eff, float* __restrict__ scale_eff,
+    float* __restrict__ quat_eff, uint8_t* __restrict__ selected)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const CamCentre cc = cam_centre_of(viewmat);
+    const LodGeom L = lod_geometry(xyz, d_max, g, cc);
+    selected[g] = L.selected ? 1 : 0;
+    if (!L.selected) { // never rendered: opacity 0 is culled by the projection (opacity < 1/255)
+        opac_eff[g] = 0.f;
+        scale_eff[3 * g] = 1.f; scale_eff[3 * g + 1] = 1.f; scale_eff[3 * g + 2] = 1.f;
+        reinterpret_cast<float4*>(quat_eff)[g] = make_float4(1.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    float x[LOD_IN], h[LOD_HID], y[LOD_OUT];
+    load_features(global_feat, local_feat, cls_id[g], g, x);
+    mlp_forward(W1, b1, W2, b2, x, h, y);
+    opac_eff[g] = sigmoidf(opacity_raw[g]) * L.alpha_ratio;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) scale_eff[3 * g + k] = __expf(scaling_raw[3 * g + k]) * sigmoidf(y[k]);
+    const float4 q = reinterpret_cast<const float4*>(rotation)[g];
+    // F.normalize(rotation * scale_rot[:,3:]) -- the projection normalises again (idempotent), so the
+    // un-normalised product is handed over and the normalisation Jacobian lives in one place.
+    reinterpret_cast<float4*>(quat_eff)[g] = make_float4(q.x * y[3], q.y * y[4], q.z * y[5], q.w * y[6]);
+}
+
+// LDS per wave: A (dz | dy padded) and B (x | h) tiles, [64 Gaussians][32 + 1 pad]
+#define LOD_LDW 33
+
+__global__ __launch_bounds__(256) void lod_params_bwd_kernel(
+    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
+    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
+    const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ viewmat, const float* __restrict__ v_opac_eff, const float* __restrict__ v_scale_eff,
+    const float* __restrict__ v_quat_eff,
+    float* __restrict__ v_xyz_add /* [N,3] += (fade term) */, float* __restrict__ v_opacity_raw,
+    float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation, float* __restrict__ v_local_feat,
+    float* __restrict__ v_global_feat /* [V,G], zeroed, atomics */, float* __restrict__ partials /* [gridDim.x][LOD_NW] */)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* sA = smem + (size_t)wv * 2 * 64 * LOD_LDW; // [64][33]
+    float* sB = sA + 64 * LOD_LDW;
+
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const CamCentre cc = cam_centre_of(viewmat);
+
+    float x[LOD_IN], h[LOD_HID], y[LOD_OUT], vy[LOD_OUT], vz[LOD_HID];
+#pragma unroll
+    for (int i = 0; i < LOD_IN; ++i) x[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LOD_HID; ++i) { h[i] = 0.f; vz[i] = 0.f; }
+#pragma unroll
+    for (int o = 0; o < LOD_OUT; ++o) vy[o] = 0.f;
+
+    bool active = false;
+    if (g < N) {
+        const float vo = v_opac_eff[g];
+        const float vs0 = v_scale_eff[3 * g], vs1 = v_scale_eff[3 * g + 1], vs2 = v_scale_eff[3 * g + 2];
+        const float4 vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
+        const LodGeom L = lod_geometry(xyz, d_max, g, cc);
+        active = L.selected && (vo != 0.f || vs0 != 0.f || vs1 != 0.f || vs2 != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
+        float go = 0.f, gs[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f};
+        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        float vx[LOD_IN];
+#pragma unroll
+        for (int j = 0; j < LOD_IN; ++j) vx[j] = 0.f;
+        if (active) {
+            const int64_t cls = cls_id[g];
+            load_features(global_feat, local_feat, cls, g, x);
+            mlp_forward(W1, b1, W2, b2, x, h, y);
+            // opacity = sigmoid(o) * alpha_ratio
+            const float so = sigmoidf(opacity_raw[g]);
+            go = vo * L.alpha_ratio * so * (1.f - so);
+            if (L.fading) { // d(alpha_ratio)/d(xyz) = -dir / d_max
+                const float c = -vo * so * L.inv_dmax;
+                gx[0] = c * L.dir[0]; gx[1] = c * L.dir[1]; gx[2] = c * L.dir[2];
+            }
+            // scaling = exp(s) * sigmoid(y)
+            const float vs[3] = {vs0, vs1, vs2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = __expf(scaling_raw[3 * g + k]), sy = sigmoidf(y[k]);
+                gs[k] = vs[k] * e * sy;
+                vy[k] = vs[k] * e * sy * (1.f - sy);
+            }
+            // quat = rotation * y[3:7]
+            const float4 q = reinterpret_cast<const float4*>(rotation)[g];
+            gq = make_float4(vq.x * y[3], vq.y * y[4], vq.z * y[5], vq.w * y[6]);
+            vy[3] = vq.x * q.x; vy[4] = vq.y * q.y; vy[5] = vq.z * q.z; vy[6] = vq.w * q.w;
+            // mlp backward: vh = W2^T vy ; vz = vh * (h > 0) ; vx = W1^T vz
+#pragma unroll
+            for (int i = 0; i < LOD_HID; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int o = 0; o < LOD_OUT; ++o) a += W2[o * LOD_HID + i] * vy[o];
+                vz[i] = h[i] > 0.f ? a : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < LOD_HID; ++i) {
+#pragma unroll
+                for (int j = 0; j < LOD_IN; ++j) vx[j] += W1[i * LOD_IN + j] * vz[i];
+            }
+            float* vg = v_global_feat + cls * LOD_G;
+#pragma unroll
+            for (int j = 0; j < LOD_G; ++j) if (vx[j] != 0.f) unsafeAtomicAdd(vg + j, vx[j]);
+        }
+        v_opacity_raw[g] = go;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v_scaling_raw[3 * g + k] = gs[k]; if (gx[k] != 0.f) v_xyz_add[3 * g + k] += gx[k]; }
+        reinterpret_cast<float4*>(v_rotation)[g] = gq;
+        float4* vl = reinterpret_cast<float4*>(v_local_feat + g * LOD_L);
+#pragma unroll
+        for (int i = 0; i < LOD_L / 4; ++i) vl[i] = make_float4(vx[LOD_G + 4 * i], vx[LOD_G + 4 * i + 1], vx[LOD_G + 4 * i + 2], vx[LOD_G + 4 * i + 3]);
+    }
+
+    // ---- weight gradients on the matrix cores: per wave D1 = vz^T x (32x32), D2 = vy^T h (7x32 in a 32x32 tile)
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const bool wave_active = __ballot(active) != 0ull; // uniform
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+    float bsum = 0.f; // lane i < 32: sum_g vz[g][i] ; lane 32+o (o<7): sum_g vy[g][o]
+    if (wave_active) {
+        // pass 1: A = vz, B = x
+#pragma unroll
+        for (int i = 0; i < LOD_HID; ++i) { sA[lane * LOD_LDW + i] = vz[i]; sB[lane * LOD_LDW + i] = x[i]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave are done (wave-private tiles)
+        __builtin_amdgcn_wave_barrier();
+        const int kk = lane >> 5, rc = lane & 31;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const float a = sA[(2 * s + kk) * LOD_LDW + rc];
+            const float b = sB[(2 * s + kk) * LOD_LDW + rc];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
+        }
+        if (lane < 32) { for (int r = 0; r < 64; ++r) bsum += sA[r * LOD_LDW + lane]; }
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: A = vy (rows 0..6, rest 0), B = h
+#pragma unroll
+        for (int i = 0; i < LOD_HID; ++i) { sA[lane * LOD_LDW + i] = (i < LOD_OUT) ? vy[i] : 0.f; sB[lane * LOD_LDW + i] = h[i]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const float a = sA[(2 * s + kk) * LOD_LDW + rc];
+            const float b = sB[(2 * s + kk) * LOD_LDW + rc];
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
+        }
+        if (lane >= 32 && lane < 32 + LOD_OUT) { for (int r = 0; r < 64; ++r) bsum += sA[r * LOD_LDW + (lane - 32)]; }
+    }
+    // ---- combine the 4 waves in LDS (each wave re-uses its own A|B tile: 4224 floats >= LOD_NW),
+    //      write one partial row per workgroup
+    __builtin_amdgcn_wave_barrier();
+    float* my = sA;
+    {
+        const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + rbase; // C/D layout of mfma 32x32
+            my[row * LOD_IN + col] = acc1[r];                                   // dW1[row][col]
+            if (row < LOD_OUT) my[LOD_HID * LOD_IN + LOD_HID + row * LOD_HID + col] = acc2[r]; // dW2[row][col]
+        }
+        if (lane < 32) my[LOD_HID * LOD_IN + lane] = bsum;                      // db1
+        else if (lane < 32 + LOD_OUT) my[LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + (lane - 32)] = bsum; // db2
+    }
+    __syncthreads();
+    float* out = partials + (size_t)blockIdx.x * LOD_NW;
+    constexpr int WT = 2 * 64 * LOD_LDW; // floats per wave tile
+    for (int i = threadIdx.x; i < LOD_NW; i += 256)
+        out[i] = (smem[i] + smem[WT + i]) + (smem[2 * WT + i] + smem[3 * WT + i]);
+}
+
+// v_w[i] = sum_b partials[b][i]  (order fixed => deterministic)
+__global__ __launch_bounds__(256) void lod_reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
+                                                                  float* __restrict__ v_w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= LOD_NW) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * LOD_NW + i];
+    v_w[i] = s;
+}
+
+} // namespace adk
+
+#define LOD_BWD_SMEM ((4 * 2 * 64 * LOD_LDW) * (int)sizeof(float)) // 67,584 B: two workgroups per CU
+
+extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
+                                  const float* rotation, const float* local_feat, const float* global_feat,
+                                  const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
+                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                                  float* opac_eff, float* scale_eff, float* quat_eff, uint8_t* selected, hipStream_t stream)
+{
+    if (N < 0) return ADK_EINVAL;
+    if (local_dim != LOD_L || global_dim != LOD_G || hidden_dim != LOD_HID) return ADK_EUNSUPPORTED;
+    if (N == 0) return 0;
+    if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 || !viewmat || !opac_eff || !scale_eff || !quat_eff || !selected) return ADK_EINVAL;
+    if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)quat_eff) & 15) return ADK_EINVAL;
+    hipLaunchKernelGGL(adk::lod_params_fwd_kernel, dim3((unsigned)adk::ceil_div(N, 256)), dim3(256), 0, stream, N, xyz,
+                       opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat,
+                       opac_eff, scale_eff, quat_eff, selected);
+    ADK_RETURN_LAST_ERROR();
+}
+
+extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)
+{
+    if (N < 0) return ADK_EINVAL;
+    return (int64_t)adk::ceil_div(N > 0 ? N : 1, 256) * LOD_NW * (int64_t)sizeof(float);
+}
+
+// v_mlp: [1287] = dW1 (32x32 row-major) | db1 (32) | dW2 (7x32) | db2 (7).  v_xyz_add is accumulated
+// into (pass the xyz gradient of the rasteriser); v_global_feat must be zero-filled by the caller.
+extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
+                                  const float* rotation, const float* local_feat, const float* global_feat,
+                                  const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
+                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                                  const float* v_opac_eff, const float* v_scale_eff, const float* v_quat_eff,
+                                  float* v_xyz_add, float* v_opacity_raw, float* v_scaling_raw, float* v_rotation,
+                                  float* v_local_feat, float* v_global_feat, float* v_mlp, void* workspace,
+                                  int64_t workspace_bytes, hipStream_t stream)
+{
+    if (N < 0) return ADK_EINVAL;
+    if (local_dim != LOD_L || global_dim != LOD_G || hidden_dim != LOD_HID) return ADK_EUNSUPPORTED;
+    if (!v_mlp) return ADK_EINVAL;
+    if (N == 0) return (int)hipMemsetAsync(v_mlp, 0, LOD_NW * sizeof(float), stream);
+    if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 || !viewmat) return ADK_EINVAL;
+    if (!v_opac_eff || !v_scale_eff || !v_quat_eff || !v_xyz_add || !v_opacity_raw || !v_scaling_raw || !v_rotation || !v_local_feat || !v_global_feat || !workspace) return ADK_EINVAL;
+    if (workspace_bytes < adk_lod_params_bwd_workspace_bytes(N)) return ADK_EWORKSPACE;
+    if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)v_quat_eff | (uintptr_t)v_rotation | (uintptr_t)v_local_feat) & 15) return ADK_EINVAL;
+    const int nb = (int)adk::ceil_div(N, 256);
+    // > 64 KiB of dynamic LDS needs the per-function opt-in (idempotent host-side call, no device work)
+    (void)hipFuncSetAttribute((const void*)adk::lod_params_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LOD_BWD_SMEM);
+    hipLaunchKernelGGL(adk::lod_params_bwd_kernel, dim3(nb), dim3(256), LOD_BWD_SMEM, stream, N, xyz, opacity_raw, scaling_raw,
+                       rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff,
+                       v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat,
+                       (float*)workspace);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, v_mlp);
+    ADK_RETURN_LAST_ERROR();
+}

@@ -253,7 +253,8 @@ __device__ __forceinline__ void tile_range(float mx, float my, float rx, float r
 template <int SH_DEG>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
-    const float* __restrict__ opacities, const float* __restrict__ colors_in, int sh_K, int color_mode,
+    const float* __restrict__ opacities, const float* __restrict__ colors_in, const float* __restrict__ sh_rest,
+    int sh_K, int color_mode,
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height, int tile_w, int tile_h,
     float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth,
     float* __restrict__ rec, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
@@ -318,10 +319,16 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         float b[16];
         sh_basis(SH_DEG, dx, dy, dz, b);
         constexpr int NB = (SH_DEG + 1) * (SH_DEG + 1);
-        const float* c = colors_in + (int64_t)g * sh_K * 3;
         float acc[3] = {0.f, 0.f, 0.f};
-        if (NB == 16 && sh_K == 16) {
-            const float4* c4 = reinterpret_cast<const float4*>(c); // 48 floats, 192 B aligned stride
+        if (sh_rest) { // band 0 in colors_in [N,1,3], bands 1.. in sh_rest [N,sh_K-1,3] (ARTDECO's f_dc / f_rest)
+            const float* c0 = colors_in + (int64_t)g * 3;
+            const float* cr = sh_rest + (int64_t)g * (sh_K - 1) * 3;
+            acc[0] = b[0] * c0[0]; acc[1] = b[0] * c0[1]; acc[2] = b[0] * c0[2];
+#pragma unroll
+            for (int k = 1; k < NB; ++k) { acc[0] += b[k] * cr[3 * k - 3]; acc[1] += b[k] * cr[3 * k - 2]; acc[2] += b[k] * cr[3 * k - 1]; }
+        } else {
+        const float* c = colors_in + (int64_t)g * sh_K * 3;
+        if (NB == 16 && sh_K == 16) {            const float4* c4 = reinterpret_cast<const float4*>(c); // 48 floats, 192 B aligned stride
             float v[48];
 #pragma unroll
             for (int i = 0; i < 12; ++i) { const float4 t = c4[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         } else {
 #pragma unroll
             for (int k = 0; k < NB; ++k) { acc[0] += b[k] * c[3 * k]; acc[1] += b[k] * c[3 * k + 1]; acc[2] += b[k] * c[3 * k + 2]; }
+        }
         }
         col[0] = fmaxf(acc[0] + 0.5f, 0.f); col[1] = fmaxf(acc[1] + 0.5f, 0.f); col[2] = fmaxf(acc[2] + 0.5f, 0.f);
     } else if (color_mode == 1) {
@@ -348,12 +356,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 template <int SH_DEG>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
-    const float* __restrict__ colors_in, int sh_K, int color_mode,
+    const float* __restrict__ colors_in, const float* __restrict__ sh_rest, int sh_K, int color_mode,
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height,
     float eps2d, float near_plane, float far_plane, int inv_depth,
     const int32_t* __restrict__ radii, const float* __restrict__ v_rec,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-    float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ cam_grad)
+    float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ v_sh_rest,
+    float* __restrict__ cam_grad)
 {
     __shared__ float red[4][16];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,7 +378,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         if (v_scales) { v_scales[3 * g] = 0.f; v_scales[3 * g + 1] = 0.f; v_scales[3 * g + 2] = 0.f; }
         if (v_opacities) v_opacities[g] = 0.f;
         if (v_colors) {
-            if (color_mode == 0) { float* o = v_colors + (int64_t)g * sh_K * 3; for (int i = 0; i < sh_K * 3; ++i) o[i] = 0.f; }
+            if (color_mode == 0 && sh_rest) {
+                v_colors[3 * g] = 0.f; v_colors[3 * g + 1] = 0.f; v_colors[3 * g + 2] = 0.f;
+                float* o = v_sh_rest + (int64_t)g * (sh_K - 1) * 3; for (int i = 0; i < (sh_K - 1) * 3; ++i) o[i] = 0.f;
+            }
+            else if (color_mode == 0) { float* o = v_colors + (int64_t)g * sh_K * 3; for (int i = 0; i < sh_K * 3; ++i) o[i] = 0.f; }
             else if (color_mode == 1) { v_colors[3 * g] = 0.f; v_colors[3 * g + 1] = 0.f; v_colors[3 * g + 2] = 0.f; }
         }
     }
@@ -502,26 +515,30 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
             float b[16], bx[16], by[16], bz[16];
             sh_basis(SH_DEG, dx, dy, dz, b);
             sh_basis_grad(SH_DEG, dx, dy, dz, bx, by, bz);
-            const float* c = colors_in + (int64_t)g * sh_K * 3;
             float acc[3] = {0.f, 0.f, 0.f};
             float cv[16][3];
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                cv[k][0] = c[3 * k]; cv[k][1] = c[3 * k + 1]; cv[k][2] = c[3 * k + 2];
+                const float* c = (sh_rest && k > 0) ? sh_rest + ((int64_t)g * (sh_K - 1) + (k - 1)) * 3
+                                                    : colors_in + ((int64_t)g * (sh_rest ? 1 : sh_K) + k) * 3;
+                cv[k][0] = c[0]; cv[k][1] = c[1]; cv[k][2] = c[2];
                 acc[0] += b[k] * cv[k][0]; acc[1] += b[k] * cv[k][1]; acc[2] += b[k] * cv[k][2];
             }
             float vres[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) vres[ch] = (acc[ch] + 0.5f >= 0.f) ? v_col[ch] : 0.f;
             float vdn[3] = {0.f, 0.f, 0.f};
-            float* o = v_colors ? v_colors + (int64_t)g * sh_K * 3 : nullptr;
+            float* o = v_colors ? v_colors + (int64_t)g * (sh_rest ? 1 : sh_K) * 3 : nullptr;
+            float* orst = (v_colors && sh_rest) ? v_sh_rest + (int64_t)g * (sh_K - 1) * 3 : nullptr;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const float wsum = cv[k][0] * vres[0] + cv[k][1] * vres[1] + cv[k][2] * vres[2];
                 vdn[0] += bx[k] * wsum; vdn[1] += by[k] * wsum; vdn[2] += bz[k] * wsum;
-                if (o) { o[3 * k] = b[k] * vres[0]; o[3 * k + 1] = b[k] * vres[1]; o[3 * k + 2] = b[k] * vres[2]; }
+                float* dst = (orst && k > 0) ? orst + 3 * (k - 1) : (o ? o + 3 * k : nullptr);
+                if (dst) { dst[0] = b[k] * vres[0]; dst[1] = b[k] * vres[1]; dst[2] = b[k] * vres[2]; }
             }
-            if (o) for (int i = NB * 3; i < sh_K * 3; ++i) o[i] = 0.f;
+            if (orst) { for (int i = (NB - 1) * 3; i < (sh_K - 1) * 3; ++i) orst[i] = 0.f; }
+            else if (o) { for (int i = NB * 3; i < sh_K * 3; ++i) o[i] = 0.f; }
             const float dd = vdn[0] * dx + vdn[1] * dy + vdn[2] * dz;
             const float vd[3] = {(vdn[0] - dd * dx) * inorm, (vdn[1] - dd * dy) * inorm, (vdn[2] - dd * dz) * inorm};
 #pragma unroll
@@ -601,8 +618,8 @@ __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, 
     }
 
 extern "C" int adk_project_fwd(int N, const float* means, const float* quats, const float* scales,
-                               const float* opacities, const float* colors_in, int sh_K, int sh_degree, int color_mode,
-                               const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                               const float* opacities, const float* colors_in, const float* sh_rest, int sh_K, int sh_degree,
+                               int color_mode, const float* viewmat, const float* Kmat, int width, int height, float eps2d,
                                float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
                                uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, hipStream_t stream)
 {
@@ -611,22 +628,24 @@ extern "C" int adk_project_fwd(int N, const float* means, const float* quats, co
     if (!means || !quats || !scales || !opacities || !viewmat || !Kmat || !rec || !radii || !depth_keys || !gauss_ids || !tiles_per_gauss) return ADK_EINVAL;
     if (color_mode < 0 || color_mode > 2 || (color_mode != 2 && !colors_in)) return ADK_EINVAL;
     if (color_mode == 0 && (sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1))) return ADK_EINVAL;
-    if (((uintptr_t)quats & 15) || ((uintptr_t)rec & 15) || (color_mode == 0 && ((uintptr_t)colors_in & 15))) return ADK_EINVAL;
+    if (((uintptr_t)quats & 15) || ((uintptr_t)rec & 15) || (color_mode == 0 && !sh_rest && ((uintptr_t)colors_in & 15))) return ADK_EINVAL;
+    if (sh_rest && (color_mode != 0 || sh_K < 2)) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
     const dim3 grid((unsigned)adk::ceil_div(N, 256)), block(256);
     const int deg = color_mode == 0 ? sh_degree : 0;
     ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_fwd_kernel<SH_DEG>), grid, block, 0, stream, N, means, quats,
-                                            scales, opacities, colors_in, sh_K, color_mode, viewmat, Kmat, width, height,
+                                            scales, opacities, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
                                             tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, inv_depth, rec, radii,
                                             depth_keys, gauss_ids, tiles_per_gauss));
     ADK_RETURN_LAST_ERROR();
 }
 
 extern "C" int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
-                               const float* colors_in, int sh_K, int sh_degree, int color_mode, const float* viewmat,
-                               const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane,
-                               int inv_depth, const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
-                               float* v_scales, float* v_opacities, float* v_colors, float* cam_grad /*[16], zeroed*/,
+                               const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
+                               const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                               float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                               const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                               float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad /*[16], zeroed*/,
                                float* v_viewmat /*[16] or NULL*/, hipStream_t stream)
 {
     if (N < 0 || width <= 0 || height <= 0) return ADK_EINVAL;
@@ -635,13 +654,14 @@ extern "C" int adk_project_bwd(int N, const float* means, const float* quats, co
     if (N > 0) {
         if (!means || !quats || !scales || !radii || !v_rec) return ADK_EINVAL;
         if (color_mode < 0 || color_mode > 2 || (color_mode == 0 && !colors_in)) return ADK_EINVAL;
+        if (sh_rest && (color_mode != 0 || sh_K < 2 || (v_colors && !v_sh_rest))) return ADK_EINVAL;
         if (((uintptr_t)quats & 15) || ((uintptr_t)v_rec & 15) || (v_quats && ((uintptr_t)v_quats & 15))) return ADK_EINVAL;
         const dim3 grid((unsigned)adk::ceil_div(N, 256)), block(256);
         const int deg = color_mode == 0 ? sh_degree : 0;
         ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_bwd_kernel<SH_DEG>), grid, block, 0, stream, N, means,
-                                                quats, scales, colors_in, sh_K, color_mode, viewmat, Kmat, width, height,
+                                                quats, scales, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
                                                 eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales,
-                                                v_opacities, v_colors, cam_grad));
+                                                v_opacities, v_colors, v_sh_rest, cam_grad));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

@@ -55,9 +55,9 @@ class GaussianRasterizer(torch.nn.Module):
         fx, fy = W / (2.0 * float(s.tanfovx)), H / (2.0 * float(s.tanfovy))
         K = torch.tensor([[fx, 0.0, W / 2.0], [0.0, fy, H / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
         viewmat = viewmatrix.transpose(0, 1).contiguous()
-        sh = torch.cat([dc.reshape(N, -1, 3), shs.reshape(N, -1, 3)], dim=1)
-        out = render_camera(means3D, rotations, scales * float(s.scale_modifier), opacities.reshape(N), sh, viewmat, K,
-                            W, H, sh_degree=int(s.sh_degree), eps2d=0.3, inv_depth=True, want_main_ids=True)
+        out = render_camera(means3D, rotations, scales * float(s.scale_modifier), opacities.reshape(N),
+                            dc.reshape(N, 1, 3), viewmat, K, W, H, sh_degree=int(s.sh_degree), eps2d=0.3,
+                            inv_depth=True, want_main_ids=True, sh_rest=shs.reshape(N, -1, 3))
         col4, alphas, radii2 = out[0], out[1], out[2]
         main_ids = out[9]
         bg = s.bg.to(dev).reshape(3)

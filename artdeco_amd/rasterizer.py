@@ -113,7 +113,7 @@ class RasterizeGaussians(torch.autograd.Function):
     render_colors [H,W,4], render_alphas [H,W,1], + non-differentiable aux tensors."""
 
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, viewmat, K, backgrounds, cfg: RasterConfig):
+    def forward(ctx, means, quats, scales, opacities, colors, sh_rest, viewmat, K, backgrounds, cfg: RasterConfig):
         lib = _lib.load()
         _lib.require_cuda(means, quats, scales, opacities, viewmat, K)
         dev = means.device
@@ -123,6 +123,7 @@ class RasterizeGaussians(torch.autograd.Function):
         means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
         opacities = _f32c(opacities, "opacities")
         colors_c = _f32c(colors, "colors") if colors is not None else None
+        rest_c = _f32c(sh_rest, "sh_rest") if sh_rest is not None else None
         viewmat, K = _f32c(viewmat, "viewmats"), _f32c(K, "Ks")
         bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
         with torch.cuda.device(dev):
@@ -135,7 +136,7 @@ class RasterizeGaussians(torch.autograd.Function):
             tiles_per_gauss = torch.empty(N, **i32)
             with _stage("project_fwd"):
               rc = lib.adk_project_fwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), opacities.data_ptr(),
-                                     _lib.ptr(colors_c), cfg.sh_K, cfg.sh_degree, cfg.color_mode, viewmat.data_ptr(),
+                                     _lib.ptr(colors_c), _lib.ptr(rest_c), cfg.sh_K, cfg.sh_degree, cfg.color_mode, viewmat.data_ptr(),
                                      K.data_ptr(), W, H, cfg.eps2d, cfg.near_plane, cfg.far_plane, cfg.radius_clip,
                                      int(cfg.inv_depth), rec.data_ptr(), radii.data_ptr(), depth_keys.data_ptr(), gauss_ids.data_ptr(),
                                      tiles_per_gauss.data_ptr(), stream)
@@ -185,8 +186,9 @@ class RasterizeGaussians(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.n_isects = n_isects
         ctx.has_bg = bg is not None
+        ctx.has_rest = rest_c is not None
         ctx.save_for_backward(means, quats, scales, colors_c if colors_c is not None else means.new_empty(0),
-                              viewmat, K, bg if bg is not None else means.new_empty(0), rec, radii, flatten_ids,
+                              rest_c if rest_c is not None else means.new_empty(0), viewmat, K, bg if bg is not None else means.new_empty(0), rec, radii, flatten_ids,
                               offsets, render_alphas, last_ids)
         aux = (radii, rec, tiles_per_gauss, flatten_ids, offsets, isect_ids, last_ids,
                main_ids if main_ids is not None else torch.empty(0, **i32))
@@ -197,7 +199,7 @@ class RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, v_colors, v_alphas, *unused):
         lib = _lib.load()
         cfg: RasterConfig = ctx.cfg
-        (means, quats, scales, colors, viewmat, K, bg, rec, radii, flatten_ids, offsets, render_alphas,
+        (means, quats, scales, colors, rest, viewmat, K, bg, rec, radii, flatten_ids, offsets, render_alphas,
          last_ids) = ctx.saved_tensors
         dev = means.device
         N = means.shape[0]
@@ -220,29 +222,39 @@ class RasterizeGaussians(torch.autograd.Function):
             v_scales = torch.empty_like(scales) if needs[2] else None
             v_opac = torch.empty(N, dtype=torch.float32, device=dev) if needs[3] else None
             has_colors = cfg.color_mode != _COLOR_DEPTH
-            v_cols = torch.empty_like(colors) if (needs[4] and has_colors) else None
+            want_col_grads = has_colors and (needs[4] or (ctx.has_rest and needs[5]))
+            v_cols = torch.empty_like(colors) if want_col_grads else None
+            v_rest = torch.empty_like(rest) if (want_col_grads and ctx.has_rest) else None
             v_viewmat = cam_grad = None
-            if needs[5]:
+            if needs[6]:
                 v_viewmat = torch.empty(4, 4, dtype=torch.float32, device=dev)
                 cam_grad = torch.zeros(16, dtype=torch.float32, device=dev)
             with _stage("project_bwd"):
               rc = lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
-                                     colors.data_ptr() if has_colors else None, cfg.sh_K, cfg.sh_degree,
+                                     colors.data_ptr() if has_colors else None, rest.data_ptr() if ctx.has_rest else None, cfg.sh_K, cfg.sh_degree,
                                      cfg.color_mode, viewmat.data_ptr(), K.data_ptr(), W, H, cfg.eps2d,
                                      cfg.near_plane, cfg.far_plane, int(cfg.inv_depth), radii.data_ptr(), v_rec.data_ptr(),
                                      _lib.ptr(v_means), _lib.ptr(v_quats), _lib.ptr(v_scales), _lib.ptr(v_opac),
-                                     _lib.ptr(v_cols), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), stream)
+                                     _lib.ptr(v_cols), _lib.ptr(v_rest), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), stream)
             _lib.check(rc, "adk_project_bwd")
-        return v_means, v_quats, v_scales, v_opac, v_cols, v_viewmat, None, None, None
+        return v_means, v_quats, v_scales, v_opac, v_cols, v_rest, v_viewmat, None, None, None
 
 
 def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,
                   eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, backgrounds=None,
-                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False):
+                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None):
     """One camera.  colors: SH coefficients [N,K,3] when sh_degree is not None, else RGB [N,3]
-    (ignored when depth_only).  backgrounds: [4] (RGB+D channel order) or None."""
+    (ignored when depth_only).  sh_rest: optional [N,K-1,3] -- then `colors` is band 0 only
+    ([N,1,3], ARTDECO's f_dc) and no concatenation is materialised.  backgrounds: [4] or None."""
     if depth_only:
         mode, K_sh, deg, cols = _COLOR_DEPTH, 0, 0, None
+        sh_rest = None
+    elif sh_degree is not None and sh_rest is not None:
+        if colors.dim() != 3 or colors.shape[1:] != (1, 3) or sh_rest.dim() != 3 or sh_rest.shape[-1] != 3:
+            raise ValueError("split SH colours must be f_dc [N,1,3] + f_rest [N,K-1,3]")
+        K_sh, deg, mode, cols = 1 + sh_rest.shape[1], int(sh_degree), _COLOR_SH, colors
+        if not 0 <= deg <= 3 or (deg + 1) ** 2 > K_sh:
+            raise ValueError(f"sh_degree {deg} not supported by {K_sh} coefficients")
     elif sh_degree is not None:
         if colors.dim() != 3 or colors.shape[-1] != 3:
             raise ValueError(f"SH colours must be [N,K,3], got {tuple(colors.shape)}")
@@ -257,4 +269,4 @@ def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, he
         mode, K_sh, deg, cols = _COLOR_RGB, 0, 0, colors
     cfg = RasterConfig(int(width), int(height), deg, K_sh, mode, float(eps2d), float(near_plane),
                        float(far_plane), float(radius_clip), bool(want_isect_ids), bool(inv_depth), bool(want_main_ids))
-    return RasterizeGaussians.apply(means, quats, scales, opacities, cols, viewmat, K, backgrounds, cfg)
+    return RasterizeGaussians.apply(means, quats, scales, opacities, cols, sh_rest, viewmat, K, backgrounds, cfg)

@@ -82,22 +82,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; used for barrier + metric all-reduce only
-
-    from artdeco_amd import _lib, mapper, rasterizer
+    from artdeco_amd import _lib, mapper, multigpu, rasterizer
+    multigpu.init("nccl", dev)  # RCCL over xGMI; used for the barrier + the metric all-reduce only
     _lib.load()
     torch.manual_seed(rank)
     scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=rank)
     nkf = len(scene.keyframes)
 
     def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        multigpu.barrier(dev)
 
     for i in range(args.warmup):
         scene.optimization_step(i % nkf)
@@ -118,13 +111,8 @@ def main():
     I, P = rasterizer.LAST_STATS["I"], args.width * args.height
     V = int(pkg["visibility_filter"].sum())
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(args.steps), float(I), float(V)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)  # the ~24 B metric all-reduce
-    elapsed_max = float(t_max.item())
-    total_steps = float(agg[0].item())
+    elapsed_max, sums = multigpu.aggregate(elapsed, {"steps": float(args.steps)}, dev)  # MAX time, SUM steps
+    total_steps = sums["steps"]
 
     if rank == 0:
         frames_per_s = total_steps / STEPS_PER_FRAME / elapsed_max
@@ -151,9 +139,7 @@ def main():
         if args.stage_detail:
             print(json.dumps(stages, indent=1), file=sys.stderr)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    multigpu.shutdown()
 
 
 def _traffic_from_profile(args):

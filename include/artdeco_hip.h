@@ -99,11 +99,13 @@ int adk_adam_update_basic(float* param, const float* grad, float* exp_avg, float
  * viewmat [4,4] world->camera and Kmat [3,3], row-major, DEVICE memory.
  * Out: rec, radii int32 [N,2], depth_keys u32 [N] (float bits of z, 0xFFFFFFFF if culled),
  * gauss_ids u32 [N] (0..N-1), tiles_per_gauss int32 [N].
+ * sh_rest != NULL (color_mode 0 only): band 0 is read from colors_in [N,1,3] and bands 1..sh_K-1 from
+ * sh_rest [N,sh_K-1,3] -- ARTDECO's separate f_dc / f_rest tensors, no concatenation needed.
  * inv_depth != 0 stores 1/z instead of z in the depth channel (the invdepth output of the
  * on-the-fly-nvs GaussianRasterizer, Reconstruct/webviewer/scene_models.py:596). */
 int adk_project_fwd(int N, const float* means, const float* quats, const float* scales,
-                    const float* opacities, const float* colors_in, int sh_K, int sh_degree, int color_mode,
-                    const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                    const float* opacities, const float* colors_in, const float* sh_rest, int sh_K, int sh_degree,
+                    int color_mode, const float* viewmat, const float* Kmat, int width, int height, float eps2d,
                     float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
                     uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, adk_stream_t stream);
 
@@ -111,10 +113,11 @@ int adk_project_fwd(int N, const float* means, const float* quats, const float* 
  * autograd edge of rasterization()).  Any v_* output may be NULL.  cam_grad: 16 zeroed floats of
  * scratch, required iff v_viewmat [4,4] is requested. */
 int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
-                    const float* colors_in, int sh_K, int sh_degree, int color_mode, const float* viewmat,
-                    const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane,
-                    int inv_depth, const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
-                    float* v_scales, float* v_opacities, float* v_colors, float* cam_grad,
+                    const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
+                    const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                    float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                    const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                    float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad,
                     float* v_viewmat, adk_stream_t stream);
 
 /* Replaces isect_tiles + radix sort + isect_offset_encode, in two calls around the single
@@ -196,6 +199,34 @@ int adk_knn_mean_dist3(const float* points, int P, float* mean_dists, void* work
 int adk_knn_indexQ(const float* points, int P, const int32_t* q_idx, int Q, const int32_t* n_idx, int N,
                    int K, float* dists, int32_t* indices, void* workspace, int64_t workspace_bytes,
                    adk_stream_t stream);
+
+/* ------------------------------------------------------ fused LoD / mlp_cov glue
+ * Replaces the torch ops of SceneModel.render between the parameter dictionary and the rasteriser
+ * (Reconstruct/scene/scene_models/h3dgsv3.py:626-662): LoD selection + fade, sigmoid/exp
+ * activations, the mlp_cov (Linear(32,32)-ReLU-Linear(32,7)) scale/rotation modulation.  All N
+ * Gaussians are processed; unselected ones get opacity 0 (culled by adk_project_fwd), so no
+ * compaction and no host sync.  local_dim = global_dim = 16, hidden_dim = 32 (run.sh) only.
+ * W1 [32,32], b1 [32], W2 [7,32], b2 [7] row-major as torch.nn.Linear stores them.
+ * Out: opac_eff [N], scale_eff [N,3], quat_eff [N,4] (un-normalised), selected [N] (0/1 bytes). */
+int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
+                       const float* rotation, const float* local_feat, const float* global_feat,
+                       const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
+                       const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                       float* opac_eff, float* scale_eff, float* quat_eff, uint8_t* selected, adk_stream_t stream);
+
+int64_t adk_lod_params_bwd_workspace_bytes(int N);
+
+/* Backward of the above.  v_xyz_add [N,3] is ACCUMULATED into (LoD fade term); v_global_feat
+ * [V,16] must be zero-filled by the caller (atomic scatter); v_mlp [1287] = dW1 | db1 | dW2 | db2
+ * (weight gradients contracted on the matrix cores, deterministic two-stage reduction). */
+int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
+                       const float* rotation, const float* local_feat, const float* global_feat,
+                       const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
+                       const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                       const float* v_opac_eff, const float* v_scale_eff, const float* v_quat_eff,
+                       float* v_xyz_add, float* v_opacity_raw, float* v_scaling_raw, float* v_rotation,
+                       float* v_local_feat, float* v_global_feat, float* v_mlp, void* workspace,
+                       int64_t workspace_bytes, adk_stream_t stream);
 
 #ifdef __cplusplus
 }
