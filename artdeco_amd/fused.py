@@ -139,6 +139,51 @@ def fused_render(self, width: int, height: int, view_matrix: torch.Tensor, bg: t
             "global_visibility_filter": global_visible_mask, "scale": scaling}
 
 
+class ExposureClamp(torch.autograd.Function):
+    """clamp(E[:3,:3] @ img.view(3,-1) + E[:3,3,None], 0, 1) without the [3,P]x[P,3] GEMMs (h3dgsv3.py:611-614)."""
+
+    @staticmethod
+    def forward(ctx, E, img):
+        lib = _lib.load()
+        _lib.require_cuda(E, img)
+        Ec, ic = E.detach().contiguous().float(), img.detach().contiguous().float()
+        P = ic.numel() // 3
+        with torch.cuda.device(ic.device):
+            out = torch.empty_like(ic)
+            with _stage("exposure_fwd"):
+                rc = lib.adk_exposure_fwd(Ec.data_ptr(), ic.data_ptr(), P, out.data_ptr(), _lib.stream_of(ic))
+        _lib.check(rc, "adk_exposure_fwd")
+        ctx.save_for_backward(Ec, ic)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        lib = _lib.load()
+        Ec, ic = ctx.saved_tensors
+        P = ic.numel() // 3
+        with torch.cuda.device(ic.device):
+            v_out = v_out.contiguous()
+            v_img = torch.empty_like(ic)
+            v_E = torch.zeros(3, 4, dtype=torch.float32, device=ic.device)
+            with _stage("exposure_bwd"):
+                rc = lib.adk_exposure_bwd(Ec.data_ptr(), ic.data_ptr(), v_out.data_ptr(), P, v_img.data_ptr(), v_E.data_ptr(),
+                                          _lib.stream_of(ic))
+        _lib.check(rc, "adk_exposure_bwd")
+        return v_E, v_img
+
+
+def fused_render_from_id(self, keyframe_id, pyr_lvl=0, bg=None):
+    """Drop-in body for SceneModel.render_from_id (h3dgsv3.py:595-615)."""
+    bg = torch.zeros(3, device=self.device) if bg is None else bg.to(self.device)
+    keyframe = self.keyframes[keyframe_id]
+    view_matrix = keyframe.get_Rt().to(self.device)
+    scale = 2 ** pyr_lvl
+    width, height = self.width // scale, self.height // scale
+    pkg = self.render(width, height, view_matrix, bg)
+    pkg["render"] = ExposureClamp.apply(keyframe.exposure, pkg["render"]).view(3, height, width)
+    return pkg
+
+
 def patch_scene_model(scene) -> bool:
     """Install fused_render on this scene-model instance (ARTDECO's SceneModel or artdeco_amd.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
@@ -146,4 +191,7 @@ def patch_scene_model(scene) -> bool:
         return False
     scene._unfused_render = scene.render
     scene.render = types.MethodType(fused_render, scene)
+    if hasattr(scene, "render_from_id"):
+        scene._unfused_render_from_id = scene.render_from_id
+        scene.render_from_id = types.MethodType(fused_render_from_id, scene)
     return True

@@ -228,6 +228,13 @@ int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_raw, const 
                        float* v_local_feat, float* v_global_feat, float* v_mlp, void* workspace,
                        int64_t workspace_bytes, adk_stream_t stream);
 
+/* Replaces the exposure correction of SceneModel.render_from_id (h3dgsv3.py:611-614):
+ * out[3,P] = clamp(E[:3,:3] @ img[3,P] + E[:3,3,None], 0, 1), E [3,4] row-major (device). */
+int adk_exposure_fwd(const float* E, const float* img, int64_t P, float* out, adk_stream_t stream);
+/* Backward: v_img [3,P]; v_E [12] is ACCUMULATED into (caller zero-fills). */
+int adk_exposure_bwd(const float* E, const float* img, const float* v_out, int64_t P, float* v_img,
+                     float* v_E, adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

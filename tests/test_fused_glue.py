@@ -82,6 +82,24 @@ def test_fused_optimization_step_tracks_unfused(dev):
         assert cos >= 0.97, (k, cos)
 
 
+@pytest.mark.gpu
+def test_exposure_clamp_matches_torch(dev):
+    from artdeco_amd.fused import ExposureClamp
+    g = torch.Generator().manual_seed(0)
+    E = (torch.eye(3, 4) + 0.2 * torch.randn(3, 4, generator=g)).to(dev).requires_grad_(True)
+    img = (torch.rand(3, 97, 131, generator=g) * 1.4 - 0.2).to(dev).requires_grad_(True)  # some values clamp
+    w = torch.randn(3, 97, 131, generator=g).to(dev)
+    ref = ((E[:3, :3] @ img.view(3, -1)) + E[:3, 3, None]).clamp(0, 1).view(3, 97, 131)
+    (ref * w).sum().backward()
+    gE, gi = E.grad.clone(), img.grad.clone()
+    E.grad = img.grad = None
+    out = ExposureClamp.apply(E, img)
+    (out * w).sum().backward()
+    assert torch.allclose(out, ref, atol=1e-6)
+    assert torch.allclose(img.grad, gi, atol=1e-5)
+    assert torch.allclose(E.grad, gE, rtol=1e-4, atol=1e-2)
+
+
 def test_patch_refuses_unsupported_shapes():
     from artdeco_amd import fused
 
