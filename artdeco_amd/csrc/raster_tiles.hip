@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
                 }
 // 64 -> 4 with DPP row reductions (VALU only), then ONE ds_add_f32 in which lane
                 // (row*16 + k) adds row `row`'s partial of value k: the 4 rows meet in the LDS atomic.
+#ifndef ADK_ABLATE_NO_REDUCE
 #pragma unroll
                 for (int k = 0; k < NACC; ++k) acc[k] = row16_allreduce_sum(acc[k]);
+#endif
+#ifndef ADK_ABLATE_NO_LDSADD
                 {
                     const int kk = lane & 15;
                     float v = acc[0];
@@ -260,6 +263,12 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
                     for (int k = 1; k < NACC; ++k) v = (kk == k) ? acc[k] : v;
                     if (kk < NACC && v != 0.f) unsafeAtomicAdd(&sacc[t][kk], v);
                 }
+#else
+                { float v = 0.f;
+#pragma unroll
+                  for (int k = 0; k < NACC; ++k) v += acc[k];
+                  if (v == 123.456f) sacc[t][0] = v; }
+#endif
             }
         }
         __syncthreads();
@@ -270,7 +279,12 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < NACC; ++k) {
                 const float v = sacc[threadIdx.x][k];
+#ifndef ADK_ABLATE_NO_FLUSH
                 if (v != 0.f) { unsafeAtomicAdd(dst + acc_to_rec(k), v); sacc[threadIdx.x][k] = 0.f; }
+#else
+                if (v == 123.456f) dst[acc_to_rec(k)] = v;
+                sacc[threadIdx.x][k] = 0.f;
+#endif
             }
         }
     }
