@@ -28,6 +28,7 @@ namespace adk {
 
 #define TILE 16
 #define BATCH 256
+#define BWD_BATCH 128 // smaller staging batch in the backward: 12 KB LDS per workgroup => 8 waves per SIMD resident
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
@@ -51,6 +52,39 @@ __device__ __forceinline__ TileCtx make_ctx(int tile_w, int n_tiles, int W, int 
     c.qy0 = (float)(c.ty * TILE + qy) + 0.5f; c.qy1 = c.qy0 + 7.0f;
     c.inside = (c.px < W) && (c.py < H);
     return c;
+}
+
+// Exact, conservative test "can this splat reach alpha >= 1/255 at any pixel centre of the rectangle
+// [x0,x1] x [y0,y1]?"  alpha = o*exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); sigma is a positive-
+// definite quadratic in d = mean - pixel, so its minimum over the rectangle is 0 if the mean is inside
+// and otherwise lies on one of the 4 edges (1-D quadratic, clamped vertex).  Evaluated by ONE LANE PER
+// SPLAT (64 splats per wave instruction), so its ~45 instructions cost < 1 instruction per splat.
+// The 1e-3 slack on sigma covers the approximate rcp/log/exp used here and in the pixel loop.
+__device__ __forceinline__ bool splat_reaches_rect(float mx, float my, float a, float b, float c, float opac,
+                                                   float x0, float x1, float y0, float y1)
+{
+    const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
+    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
+    const float tau = __logf(opac * 255.0f) + 1e-3f;
+    const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
+    float best;
+    {
+        const float dy = fminf(fmaxf(nb_c * dxl, dyl), dyh);
+        best = 0.5f * (a * dxl * dxl + c * dy * dy) + b * dxl * dy;
+    }
+    {
+        const float dy = fminf(fmaxf(nb_c * dxh, dyl), dyh);
+        best = fminf(best, 0.5f * (a * dxh * dxh + c * dy * dy) + b * dxh * dy);
+    }
+    {
+        const float dx = fminf(fmaxf(nb_a * dyl, dxl), dxh);
+        best = fminf(best, 0.5f * (a * dx * dx + c * dyl * dyl) + b * dx * dyl);
+    }
+    {
+        const float dx = fminf(fmaxf(nb_a * dyh, dxl), dxh);
+        best = fminf(best, 0.5f * (a * dx * dx + c * dyh * dyh) + b * dx * dyh);
+    }
+    return best <= tau;
 }
 
 // ---------------------------------------------------------------------------------- forward
@@ -97,13 +131,15 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
             bool hit = false;
             if (s < batch_size) {
                 const float4 a = srec[s][0];
-                const float ry = srec[s][1].w;
-                hit = (a.x + a.w >= c.qx0) && (a.x - a.w <= c.qx1) && (a.y + ry >= c.qy0) && (a.y - ry <= c.qy1);
+                const float4 cn = srec[s][1];
+                hit = (a.x + a.w >= c.qx0) && (a.x - a.w <= c.qx1) && (a.y + cn.w >= c.qy0) && (a.y - cn.w <= c.qy1) &&
+                      splat_reaches_rect(a.x, a.y, cn.x, cn.y, cn.z, a.z, c.qx0, c.qx1, c.qy0, c.qy1);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
                 const int t = sub + __builtin_ctzll(mask);
                 mask &= mask - 1;
+                bool newly_done = false;
                 if (!done) {
                     const float4 a = srec[t][0];
                     const float4 cn = srec[t][1];
@@ -114,6 +150,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
                         const float next_T = T * (1.0f - alpha);
                         if (next_T <= T_EPS) {
                             done = true;
+                            newly_done = true;
                         } else {
                             const float4 col = srec[t][2];
                             const float vis = alpha * T;
@@ -124,7 +161,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
                         }
                     }
                 }
-                if (__ballot(!done) == 0ull) { mask = 0; sub = batch_size; }
+                // the whole-quadrant-finished test is only re-evaluated when some pixel just finished
+                if (__ballot(newly_done) != 0ull && __ballot(!done) == 0ull) { mask = 0; sub = batch_size; }
             }
         }
     }
@@ -153,9 +191,9 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_rec)
 {
-    __shared__ float4 srec[BATCH][3];
-    __shared__ int sid[BATCH];
-    __shared__ float sacc[BATCH][NACC + 1]; // +1 pad: stride 11 dwords keeps the flush conflict-free
+    __shared__ float4 srec[BWD_BATCH][3];
+    __shared__ int sid[BWD_BATCH];
+    __shared__ float sacc[BWD_BATCH][NACC + 1]; // +1 pad: stride 11 dwords keeps the flush conflict-free
     const int n_tiles = tile_w * tile_h;
     const TileCtx c = make_ctx(tile_w, n_tiles, W, H);
     const int lane = threadIdx.x & 63;
@@ -163,7 +201,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
 
     const int range_start = offsets[c.tile];
     const int range_end = (c.tile == n_tiles - 1) ? n_isects : offsets[c.tile + 1];
-    const int num_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    const int num_batches = (range_end - range_start + BWD_BATCH - 1) / BWD_BATCH;
 
     const int64_t pix = (int64_t)c.py * W + c.px;
     float T_final = 1.f, vr0 = 0.f, vr1 = 0.f, vr2 = 0.f, vr3 = 0.f, v_render_a = 0.f;
@@ -176,21 +214,27 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
         bin_final = last_ids[pix];
     }
     float T = T_final;
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f; // colour accumulated BEHIND the current splat
+    // Only the projection of the "colour accumulated BEHIND the current splat" onto this pixel's output
+    // gradient is ever needed: bdot = sum_k buffer_k * v_render_k.  One register and one FMA per splat
+    // instead of four of each.
+    float bdot = 0.f;
     float bg_dot = 0.f;
     if (backgrounds) bg_dot = backgrounds[0] * vr0 + backgrounds[1] * vr1 + backgrounds[2] * vr2 + backgrounds[3] * vr3;
+    const float C0 = T_final * (v_render_a - bg_dot); // v_alpha = T*S1 + ra*(C0 - bdot)
     const int wave_bin_final = wave_max_i(bin_final);
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
 
+    if (threadIdx.x < BWD_BATCH) {
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) sacc[threadIdx.x][k] = 0.f;
+        for (int k = 0; k < NACC; ++k) sacc[threadIdx.x][k] = 0.f;
+    }
 
     for (int b = 0; b < num_batches; ++b) {
         __syncthreads();
-        const int batch_end = range_end - 1 - BATCH * b;
-        const int batch_size = min(BATCH, batch_end + 1 - range_start);
+        const int batch_end = range_end - 1 - BWD_BATCH * b;
+        const int batch_size = min(BWD_BATCH, batch_end + 1 - range_start);
         const int idx = batch_end - (int)threadIdx.x;
-        if (idx >= range_start) {
+        if ((int)threadIdx.x < BWD_BATCH && idx >= range_start) {
             const int g = flatten_ids[idx];
             sid[threadIdx.x] = g;
             srec[threadIdx.x][0] = rec4[3 * (int64_t)g];
@@ -204,58 +248,49 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
             bool hit = false;
             if (s < batch_size && (batch_end - s) <= wave_bin_final) {
                 const float4 a = srec[s][0];
-                const float ry = srec[s][1].w;
-                hit = (a.x + a.w >= c.qx0) && (a.x - a.w <= c.qx1) && (a.y + ry >= c.qy0) && (a.y - ry <= c.qy1);
+                const float4 cq = srec[s][1];
+                hit = (a.x + a.w >= c.qx0) && (a.x - a.w <= c.qx1) && (a.y + cq.w >= c.qy0) && (a.y - cq.w <= c.qy1) &&
+                      splat_reaches_rect(a.x, a.y, cq.x, cq.y, cq.z, a.z, c.qx0, c.qx1, c.qy0, c.qy1);
             }
             unsigned long long mask = __ballot(hit);
             while (mask) {
                 const int t = sub + __builtin_ctzll(mask);
                 mask &= mask - 1;
-                bool valid = c.inside && (batch_end - t <= bin_final);
-                float alpha = 0.f, opac = 0.f, vis = 0.f, dx = 0.f, dy = 0.f;
-                float4 cn = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) {
-                    const float4 a = srec[t][0];
-                    cn = srec[t][1];
-                    opac = a.z;
-                    dx = a.x - fx; dy = a.y - fy;
-                    const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
-                    vis = __expf(-sigma);
-                    alpha = fminf(MAX_ALPHA, opac * vis);
-                    if (sigma < 0.f || alpha < ALPHA_THR) valid = false;
-                }
+                // Branch-free body: an invalid lane gets vis = 0 => alpha = 0, ra = 1, fac = 0 and every
+                // gradient term vanishes on its own, so no exec-mask juggling and no zero-initialisation.
+                const float4 a = srec[t][0];
+                const float4 cn = srec[t][1];
+                const float opac = a.z;
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
+                float vis = __expf(-sigma);
+                const bool valid = c.inside && (batch_end - t <= bin_final) && !(sigma < 0.f) && !(opac * vis < ALPHA_THR);
                 if (__ballot(valid) == 0ull) continue;
+                vis = valid ? vis : 0.f;
+                const float ov = opac * vis;
+                const float alpha = fminf(MAX_ALPHA, ov);
+                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha); // 1 ulp v_rcp_f32; alpha <= 0.999
+                T *= ra;
+                const float fac = alpha * T;
+                const float4 col = srec[t][2];
+                const float S1 = col.x * vr0 + col.y * vr1 + col.z * vr2 + col.w * vr3;
+                const float v_alpha = T * S1 + ra * (C0 - bdot);
+                bdot += fac * S1;
+                const float gop = (ov <= MAX_ALPHA) ? vis * v_alpha : 0.f; // clamped alpha passes no gradient
+                const float v_sigma = -opac * gop;
+                const float t1 = v_sigma * dx, t2 = v_sigma * dy;
                 float acc[NACC];
-#pragma unroll
-                for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-                if (valid) {
-                    const float4 col = srec[t][2];
-                    const float ra = 1.0f / (1.0f - alpha);
-                    T *= ra;
-                    const float fac = alpha * T;
-                    acc[6] = fac * vr0; acc[7] = fac * vr1; acc[8] = fac * vr2; acc[9] = fac * vr3;
-                    float v_alpha = (col.x * T - b0 * ra) * vr0 + (col.y * T - b1 * ra) * vr1 +
-                                    (col.z * T - b2 * ra) * vr2 + (col.w * T - b3 * ra) * vr3;
-                    v_alpha += T_final * ra * v_render_a;
-                    if (backgrounds) v_alpha += -T_final * ra * bg_dot;
-                    if (opac * vis <= MAX_ALPHA) {
-                        const float v_sigma = -opac * vis * v_alpha;
-                        acc[3] = 0.5f * v_sigma * dx * dx;
-                        acc[4] = v_sigma * dx * dy;
-                        acc[5] = 0.5f * v_sigma * dy * dy;
-                        acc[0] = v_sigma * (cn.x * dx + cn.y * dy);
-                        acc[1] = v_sigma * (cn.y * dx + cn.z * dy);
-                        acc[2] = vis * v_alpha;
-                    }
-                    b0 += col.x * fac; b1 += col.y * fac; b2 += col.z * fac; b3 += col.w * fac;
-                }
-// 64 -> 4 with DPP row reductions (VALU only), then ONE ds_add_f32 in which lane
+                acc[0] = cn.x * t1 + cn.y * t2;   // v_mean2d.x
+                acc[1] = cn.y * t1 + cn.z * t2;   // v_mean2d.y
+                acc[2] = gop;                     // v_opacity
+                acc[3] = t1 * dx;                 // 2 * v_conic.a  (x0.5 applied at the flush)
+                acc[4] = t1 * dy;                 // v_conic.b
+                acc[5] = t2 * dy;                 // 2 * v_conic.c  (x0.5 applied at the flush)
+                acc[6] = fac * vr0; acc[7] = fac * vr1; acc[8] = fac * vr2; acc[9] = fac * vr3;
+                // 64 -> 4 with DPP row reductions (VALU only), then ONE ds_add_f32 in which lane
                 // (row*16 + k) adds row `row`'s partial of value k: the 4 rows meet in the LDS atomic.
-#ifndef ADK_ABLATE_NO_REDUCE
 #pragma unroll
                 for (int k = 0; k < NACC; ++k) acc[k] = row16_allreduce_sum(acc[k]);
-#endif
-#ifndef ADK_ABLATE_NO_LDSADD
                 {
                     const int kk = lane & 15;
                     float v = acc[0];
@@ -263,12 +298,6 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
                     for (int k = 1; k < NACC; ++k) v = (kk == k) ? acc[k] : v;
                     if (kk < NACC && v != 0.f) unsafeAtomicAdd(&sacc[t][kk], v);
                 }
-#else
-                { float v = 0.f;
-#pragma unroll
-                  for (int k = 0; k < NACC; ++k) v += acc[k];
-                  if (v == 123.456f) sacc[t][0] = v; }
-#endif
             }
         }
         __syncthreads();
@@ -278,13 +307,9 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
             float* dst = v_rec + 12 * g;
 #pragma unroll
             for (int k = 0; k < NACC; ++k) {
-                const float v = sacc[threadIdx.x][k];
-#ifndef ADK_ABLATE_NO_FLUSH
+                float v = sacc[threadIdx.x][k];
+                if (k == 3 || k == 5) v *= 0.5f;
                 if (v != 0.f) { unsafeAtomicAdd(dst + acc_to_rec(k), v); sacc[threadIdx.x][k] = 0.f; }
-#else
-                if (v == 123.456f) dst[acc_to_rec(k)] = v;
-                sacc[threadIdx.x][k] = 0.f;
-#endif
             }
         }
     }
