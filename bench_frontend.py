@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Frontend (BASELINE configs[0]/[1]): 2-frame MASt3R ViT-L 512x384 pair match = 2 encodes + decoder + 2 heads
++ iter_proj + refine_matches, on one MI355X (random-init weights: checkpoints are download-only), next to the
+PyTorch-CPU path of the same module on the host cores.  Prints one JSON line.
+
+    python bench_frontend.py [--iters 10] [--dtype bf16|fp32] [--cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import artdeco_amd  # noqa: E402
+
+artdeco_amd.install_dropins()
+from artdeco_amd.mast3r_model import vit_large  # noqa: E402
+
+# FLOPs of one asymmetric pair match at 512x384 (768 tokens): SURVEY.md 8 a8 (2 encodes 1.04 T + decoder 0.44 T + heads ~0.2 T)
+PAIR_TFLOP = 1.68
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def img_gradient(img):
+    """Central-difference stand-in for prep_for_iter_proj's gradient images (VSLAM/utils_matching.py:53-86)."""
+    gx = F.pad((img[..., 2:] - img[..., :-2]) * 0.5, (1, 1))
+    gy = F.pad((img[..., 2:, :] - img[..., :-2, :]) * 0.5, (0, 0, 1, 1))
+    return gx, gy
+
+
+def pair_match(net, img1, img2, autocast_dtype):
+    """mast3r_match_asymmetric (VSLAM/utils_mast3r.py:144-170) + match_iterative_proj (utils_matching.py:136-190)."""
+    import mast3r_slam_backends as msb
+    dev = img1.device
+    with torch.inference_mode():
+        with torch.autocast(dev.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+            r1, r2 = net({"img": img1}, {"img": img2})
+        X11, X21 = r1["pts3d"], r2["pts3d_in_other_view"]
+        D11, D21 = r1["desc"], r2["desc"]
+        b, h, w, _ = X11.shape
+        rays = F.normalize(X11, dim=-1).permute(0, 3, 1, 2)
+        gx, gy = img_gradient(rays)
+        rays_g = torch.cat((rays, gx, gy), dim=1).permute(0, 2, 3, 1).contiguous()
+        pts = F.normalize(X21.view(b, -1, 3), dim=-1).contiguous()
+        lin = torch.arange(h * w, device=dev)
+        p_init = torch.stack((lin % w, lin // w), -1)[None].float().contiguous()
+        p1, valid = msb.iter_proj(rays_g, pts, p_init, 10, 1e-8, 1e-6)
+        (p1,) = msb.refine_matches(D11.half().contiguous(), D21.reshape(b, h * w, -1).half().contiguous(), p1.long(), 4, 5)
+    return p1, valid
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = vit_large().to(dev).eval()
+    img1 = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
+    img2 = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
+    ac = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
+    for _ in range(3):
+        pair_match(net, img1, img2, ac)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        pair_match(net, img1, img2, ac)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    peak = MFMA_F32_PEAK_TFLOPS if ac is None else MFMA_BF16_PEAK_TFLOPS
+    out = {"metric": "MASt3R ViT-L 512x384 asymmetric pair matches per second (2 encodes + decoder + 2 heads + iter_proj + refine_matches)",
+           "value": 1.0 / dt, "unit": "pairs/s", "ms_per_pair": dt * 1e3, "dtype": args.dtype, "data": "synthetic, random-init weights",
+           "roofline": {"bound": "mfma", "achieved": PAIR_TFLOP / dt, "peak": peak, "unit": "TFLOP/s", "frac": PAIR_TFLOP / dt / peak}}
+    if args.cpu_baseline:
+        cnet = vit_large().eval()
+        c1, c2 = img1.cpu(), img2.cpu()
+        with torch.inference_mode():
+            cnet({"img": c1}, {"img": c2})
+            t0 = time.perf_counter()
+            cnet({"img": c1}, {"img": c2})
+            cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"one fp32 pair inference (model only, no matching kernels) on the host: {cdt:.2f} s"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
