@@ -12,6 +12,7 @@
 // traffic, 8 B of HBM traffic per element (read + write) -- a pure streaming kernel.
 #include "adk_common.hpp"
 #include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
 
 namespace adk {
 
@@ -31,6 +32,23 @@ template <> struct Vec4<__half> {
     __device__ __forceinline__ void store(__half* p) const {
         const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
         uint2 t; t.x = *reinterpret_cast<const unsigned*>(&a); t.y = *reinterpret_cast<const unsigned*>(&b);
+        *reinterpret_cast<uint2*>(p) = t;
+    }
+};
+
+template <> struct Vec4<__hip_bfloat16> {
+    float v[4];
+    __device__ __forceinline__ void load(const __hip_bfloat16* p) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p); // bf16 -> f32 is a 16-bit shift
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+    }
+    __device__ __forceinline__ void store(__hip_bfloat16* p) const {
+        auto rn = [](float f) { // round-to-nearest-even to bf16 bits
+            const unsigned u = __float_as_uint(f);
+            return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+        };
+        uint2 t; t.x = rn(v[0]) | (rn(v[1]) << 16); t.y = rn(v[2]) | (rn(v[3]) << 16);
         *reinterpret_cast<uint2*>(p) = t;
     }
 };
@@ -70,6 +88,8 @@ template <> __device__ __forceinline__ float to_f<__half>(__half x) { return __h
 template <typename T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ __half from_f<__half>(float x) { return __float2half(x); }
+template <> __device__ __forceinline__ float to_f<__hip_bfloat16>(__hip_bfloat16 x) { return __bfloat162float(x); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(float x) { return __float2bfloat16(x); }
 
 // Generic path (D % 4 == 0): one thread = (token, half, pair).
 template <typename T>
@@ -95,8 +115,8 @@ __global__ __launch_bounds__(256) void rope2d_scalar_kernel(T* __restrict__ toke
 template <typename T>
 static int launch_rope(T* tokens, const int64_t* pos, int64_t n_tokens, int N, int64_t stride_b, int64_t stride_n, int H, int D, float base, float fwd, hipStream_t stream)
 {
-    const int epv = 16 / (int)sizeof(float); // elements per 4-wide access
-    const bool vec = (D % 16 == 0) && (((uintptr_t)tokens & 15) == 0) && (stride_b % epv == 0) && (stride_n % epv == 0);
+    const int epv = 4; // elements per 4-wide access
+    const bool vec = (D % 16 == 0) && (((uintptr_t)tokens & (4 * sizeof(T) - 1)) == 0) && (stride_b % epv == 0) && (stride_n % epv == 0);
     if (vec) {
         const int64_t work = n_tokens * 2 * (D / 16);
         hipLaunchKernelGGL((rope2d_vec_kernel<T>), dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, tokens, pos, n_tokens, N, stride_b, stride_n, H, D, base, fwd);
@@ -109,7 +129,7 @@ static int launch_rope(T* tokens, const int64_t* pos, int64_t n_tokens, int N, i
 
 } // namespace adk
 
-// dtype: 0 = float16, 1 = float32.  tokens [B,N,H,D] with the last two dims dense (stride D, 1) and
+// dtype: 0 = float16, 1 = float32, 2 = bfloat16.  tokens [B,N,H,D] with the last two dims dense (stride D, 1) and
 // arbitrary element strides for batch / token (the reference passes a transposed qkv view),
 // positions [B,N,2] int64 (y, x) contiguous.
 extern "C" int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, int B, int N, int64_t stride_b,
@@ -121,5 +141,6 @@ extern "C" int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, in
     if (!tokens || !positions) return ADK_EINVAL;
     if (dtype == 1) return adk::launch_rope<float>((float*)tokens, positions, n_tokens, N, stride_b, stride_n, H, D, base, fwd, stream);
     if (dtype == 0) return adk::launch_rope<__half>((__half*)tokens, positions, n_tokens, N, stride_b, stride_n, H, D, base, fwd, stream);
+    if (dtype == 2) return adk::launch_rope<__hip_bfloat16>((__hip_bfloat16*)tokens, positions, n_tokens, N, stride_b, stride_n, H, D, base, fwd, stream);
     return ADK_EUNSUPPORTED;
 }

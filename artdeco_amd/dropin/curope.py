@@ -10,6 +10,9 @@ import torch
 from artdeco_amd import _lib
 
 
+_DTYPES = {torch.float16: 0, torch.float32: 1, torch.bfloat16: 2}
+
+
 def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
     """In place.  tokens [B,N,H,D] (float32/float16, D-contiguous, head stride D), positions [B,N,2] int64."""
     if tokens.dim() != 4:
@@ -34,10 +37,10 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
         raise RuntimeError("token dim must be multiple of 4")
     if positions.dtype != torch.int64:
         raise TypeError("positions must be int64")
-    if tokens.dtype not in (torch.float32, torch.float16):
-        raise TypeError("rope_2d supports float32 and float16 tokens")
+    if tokens.dtype not in _DTYPES:
+        raise TypeError("rope_2d supports float32, float16 and bfloat16 tokens")
     lib = _lib.load()
     with torch.cuda.device(tokens.device):
-        rc = lib.adk_rope_2d(tokens.data_ptr(), positions.data_ptr(), 0 if tokens.dtype == torch.float16 else 1,
+        rc = lib.adk_rope_2d(tokens.data_ptr(), positions.data_ptr(), _DTYPES[tokens.dtype],
                              B, N, tokens.stride(0), tokens.stride(1), H, D, float(base), float(fwd), _lib.stream_of(tokens))
     _lib.check(rc, "adk_rope_2d")

@@ -43,13 +43,23 @@ class RoPE2D(nn.Module):
 
     def forward(self, tokens, positions):
         """tokens [B,heads,N,D] (any strides with (N? ,D) dense per head as produced below), positions [B,N,2]."""
-        if tokens.is_cuda and tokens.dtype in (torch.float32, torch.float16):
+        if tokens.is_cuda and tokens.dtype in (torch.float32, torch.float16, torch.bfloat16):
             view = tokens.transpose(1, 2)  # [B,N,H,D]
             if view.stride(3) == 1 and view.stride(2) == view.shape[3]:
                 import curope  # drop-in HIP kernel (artdeco_amd/dropin/curope.py)
                 curope.rope_2d(view, positions.contiguous(), self.base, self.F0)
                 return tokens
         return self._torch(tokens, positions)
+
+    def rotate_qk_inplace(self, qkv5, positions) -> bool:
+        """qkv5 [B,N,3,H,D] contiguous: rotate the q and k slabs in place in one kernel launch (GPU only)."""
+        if not (qkv5.is_cuda and qkv5.is_contiguous() and qkv5.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+            return False
+        B, N, _, H, D = qkv5.shape
+        import curope
+        qk = qkv5.as_strided((B, N, 2 * H, D), (N * 3 * H * D, 3 * H * D, D, 1))
+        curope.rope_2d(qk, positions.contiguous(), self.base, self.F0)
+        return True
 
     def _torch(self, tokens, positions):
         B, Hh, N, D = tokens.shape
@@ -88,9 +98,14 @@ class Attention(nn.Module):
 
     def forward(self, x, xpos):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).transpose(1, 3)  # [B,H,3,N,D]
-        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        q, k = self.rope(q, xpos), self.rope(k, xpos)
+        qkv5 = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
+        # q and k are adjacent [H,D] slabs of every token: rotate both with ONE in-place rope launch over 2H "heads"
+        if not self.rope.rotate_qk_inplace(qkv5, xpos):
+            qkv = qkv5.transpose(1, 3)
+            q, k, v = self.rope(qkv[:, :, 0], xpos), self.rope(qkv[:, :, 1], xpos), qkv[:, :, 2]
+        else:
+            qkv = qkv5.transpose(1, 3)  # [B,H,3,N,D]
+            q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         x = F.scaled_dot_product_attention(q, k, v)  # softmax(q k^T / sqrt(D)) v
         return self.proj(x.transpose(1, 2).reshape(B, N, C))
 
@@ -358,9 +373,20 @@ class AsymmetricMASt3R(nn.Module):
         shp = img_shape[0] if torch.is_tensor(img_shape) and img_shape.dim() == 2 else img_shape
         return head(decout, shp)
 
+    def to_inference_dtype(self, dtype):
+        """Cast encoder + decoders ONCE to bf16/fp16 (autocast would re-cast every weight on every call);
+        the heads stay fp32 like the reference (dust3r/model.py:205)."""
+        for m in (self.patch_embed, self.enc_blocks, self.enc_norm, self.decoder_embed, self.dec_blocks, self.dec_blocks2, self.dec_norm):
+            m.to(dtype)
+        self._trunk_dtype = dtype
+        return self
+
     @torch.inference_mode()
     def forward(self, view1, view2):
         img1, img2 = view1["img"], view2["img"]
+        td = getattr(self, "_trunk_dtype", None)
+        if td is not None:
+            img1, img2 = img1.to(td), img2.to(td)
         shape1 = view1.get("true_shape", torch.tensor(img1.shape[-2:])[None])
         shape2 = view2.get("true_shape", torch.tensor(img2.shape[-2:])[None])
         feat1, pos1, _ = self._encode_image(img1, shape1)

@@ -169,7 +169,7 @@ int adk_refine_matches(const void* D11, const void* D21, const int64_t* p1, int 
 /* ----------------------------------------------------------------------- curope
  * Replaces rope_2d(tokens, positions, base, fwd) -- VSLAM/thirdparty/mast3r/dust3r/croco/models/
  * curope/curope.cpp:49-65 (CUDA kernel kernels.cu:17-108).  In place on tokens [B,N,H,D]
- * (dtype 0 = float16, 1 = float32; D % 4 == 0) whose last two dims are dense (strides D, 1, as
+ * (dtype 0 = float16, 1 = float32, 2 = bfloat16; D % 4 == 0) whose last two dims are dense (strides D, 1, as
  * kernels.cu:90 requires) with element strides stride_b / stride_n for batch / token -- the
  * reference hands over a transposed view of the qkv projection (blocks.py, curope2d.py:37);
  * positions [B,N,2] int64 (y, x); fwd = +F0 forward, -F0 backward (curope2d.py:20,27). */
