@@ -80,4 +80,47 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// Sum 10 per-lane values across the 64 lanes with as few cross-lane operations as possible.
+// DPP-modified VALU ops issue at ~1/3.3 of the plain rate on gfx950 (measured, scratch/dpp_bench.hip), so
+// instead of 10 independent 4-step row reductions (40 DPP ops) this is a TRANSPOSING butterfly inside each
+// 16-lane row: at every stage a lane keeps one half of its values and ships the other half to its partner
+// (row_mirror, row_half_mirror, quad mirror, quad xor-1), 5 + 3 + 2 + 1 = 11 DPP ops + ~20 selects.
+// Afterwards lane `owner lanes` {0,1,2,4,6} (+8 for values 5..9) of each row hold the row sums of values
+// {0,1,2,3,4} (+5); two ds_bpermute adds (xor 16, xor 32) finish the 4 rows.
+// Returns the total of value `slot` (valid in every row's owner lanes); is_owner is true for the 10 lanes
+// of row 0 that should publish it.
+struct Reduce10 { float value; int slot; bool is_owner; };
+__device__ __forceinline__ Reduce10 wave_reduce10(const float (&a)[10], int lane) {
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float r[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { // stage 1: row_mirror, class bit 3
+        const float keep = b3 ? a[j + 5] : a[j], send = b3 ? a[j] : a[j + 5];
+        r[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x140, 0xf, 0xf, false));
+    }
+    // stage 2: row_half_mirror, class bit 2: b2=0 keeps r0,r1,r2 ; b2=1 keeps r3,r4
+    const float k0 = b2 ? r[3] : r[0], k1 = b2 ? r[4] : r[1], s0 = b2 ? r[0] : r[3], s1 = b2 ? r[1] : r[4];
+    const float u0 = k0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x141, 0xf, 0xf, false));
+    const float u1 = k1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x141, 0xf, 0xf, false));
+    const float u2 = r[2] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r[2]), 0x141, 0xf, 0xf, false)); // b2=0 lanes only
+    // stage 3: quad mirror [3,2,1,0] (0x1B), class bit 1
+    const float k30 = b2 ? (b1 ? u1 : u0) : (b1 ? u2 : u0);
+    const float s30 = b2 ? (b1 ? u0 : u1) : (b1 ? u0 : u2);
+    const float w0 = k30 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s30), 0x1B, 0xf, 0xf, false));
+    const float w1 = u1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u1), 0x1B, 0xf, 0xf, false)); // (b2,b1)=(0,0) only
+    // stage 4: quad xor 1 [1,0,3,2] (0xB1), class bit 0
+    const bool two = !b2 && !b1;
+    const float k4 = (two && b0) ? w1 : w0;
+    const float s4 = two ? (b0 ? w0 : w1) : w0;
+    float f = k4 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s4), 0xB1, 0xf, 0xf, false));
+    // the 4 rows
+    f += __shfl_xor(f, 16, 64);
+    f += __shfl_xor(f, 32, 64);
+    Reduce10 o;
+    o.slot = (b3 ? 5 : 0) + (b2 ? (b1 ? 4 : 3) : (b1 ? 2 : (b0 ? 1 : 0)));
+    o.is_owner = (lane < 16) && (two || !b0);
+    o.value = f;
+    return o;
+}
+
 } // namespace adk

@@ -28,7 +28,6 @@ namespace adk {
 
 #define TILE 16
 #define BATCH 256
-#define BWD_BATCH 128 // smaller staging batch in the backward: 12 KB LDS per workgroup => 8 waves per SIMD resident
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
@@ -180,137 +179,148 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------- backward
-// Accumulator slots per staged splat: 0,1 v_mean2d | 2 v_opacity | 3,4,5 v_conic | 6..9 v_colour
+// Accumulator slots per splat: 0,1 v_mean2d | 2 v_opacity | 3,4,5 v_conic | 6..9 v_colour
 #define NACC 10
-__device__ __forceinline__ constexpr int acc_to_rec(int k) { return k < 3 ? k : (k < 6 ? k + 1 : k + 2); }
+__device__ __forceinline__ int acc_to_rec(int k) { return k < 3 ? k : (k < 6 ? k + 1 : k + 2); }
 
-__global__ __launch_bounds__(256) void raster_bwd_kernel(
+// Per-pixel backward state (one per quadrant the lane serves).
+struct PixBwd {
+    float fx, fy;        // pixel centre
+    float T, bdot, C0;   // running transmittance, <buffer, v_render>, T_final*(v_alpha_out - <bg, v_render>)
+    float vr0, vr1, vr2, vr3;
+    int bin_final;       // index of the last splat that contributed in the forward (-1: pixel outside the image)
+};
+
+// MEASURED on MI355X (scratch/dpp_bench.hip): a DPP-modified VALU instruction issues at ~8.6 cycles per
+// wave against 2.6 for a plain one (and a ds_bpermute shuffle+add pair at ~21).  Cross-lane reductions are
+// therefore the most expensive thing this kernel does, and the design goal is ONE reduction per (splat,
+// tile) instead of one per (splat, 8x8 quadrant):
+//   * one wavefront per 16x16 tile; lane l owns pixel l (8x8 raster order) of EACH of the 4 quadrants;
+//   * splat-parallel culling produces four 64-bit hit masks (one per quadrant) per group of 64 staged
+//     splats; the wave walks the union and, per splat, evaluates only the quadrants whose bit is set
+//     (wave-uniform branches), summing their contributions in the same 10 registers;
+//   * the 10 sums are reduced once (4 DPP row steps + 2 row_bcast steps) and lanes 63 issue the 10 global
+//     fp32 atomics directly -- no LDS accumulators, no cross-wave merge, no flush phase, no block barrier
+//     besides the (single-wave, free) staging barrier.
+__global__ __launch_bounds__(64) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_rec)
 {
-    __shared__ float4 srec[BWD_BATCH][3];
-    __shared__ int sid[BWD_BATCH];
-    __shared__ float sacc[BWD_BATCH][NACC + 1]; // +1 pad: stride 11 dwords keeps the flush conflict-free
+    __shared__ float4 srec[64][3];
+    __shared__ int sid[64];
     const int n_tiles = tile_w * tile_h;
-    const TileCtx c = make_ctx(tile_w, n_tiles, W, H);
-    const int lane = threadIdx.x & 63;
-    const float fx = (float)c.px + 0.5f, fy = (float)c.py + 0.5f;
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int lane = threadIdx.x;
 
-    const int range_start = offsets[c.tile];
-    const int range_end = (c.tile == n_tiles - 1) ? n_isects : offsets[c.tile + 1];
-    const int num_batches = (range_end - range_start + BWD_BATCH - 1) / BWD_BATCH;
+    const int range_start = offsets[tile];
+    const int range_end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    if (range_end <= range_start) return;
 
-    const int64_t pix = (int64_t)c.py * W + c.px;
-    float T_final = 1.f, vr0 = 0.f, vr1 = 0.f, vr2 = 0.f, vr3 = 0.f, v_render_a = 0.f;
-    int bin_final = -1;
-    if (c.inside) {
-        T_final = 1.0f - render_alphas[pix];
-        const float4 v = reinterpret_cast<const float4*>(v_render_colors)[pix];
-        vr0 = v.x; vr1 = v.y; vr2 = v.z; vr3 = v.w;
-        v_render_a = v_render_alphas[pix];
-        bin_final = last_ids[pix];
+    float bgc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (backgrounds) { bgc[0] = backgrounds[0]; bgc[1] = backgrounds[1]; bgc[2] = backgrounds[2]; bgc[3] = backgrounds[3]; }
+
+    PixBwd px[4];
+    float qx0[4], qy0[4]; // pixel-centre origin of each quadrant
+    int tile_bin_final = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ox = tx * TILE + (q & 1) * 8, oy = ty * TILE + (q >> 1) * 8;
+        qx0[q] = (float)ox + 0.5f; qy0[q] = (float)oy + 0.5f;
+        const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
+        PixBwd& P = px[q];
+        P.fx = (float)pxi + 0.5f; P.fy = (float)pyi + 0.5f;
+        P.vr0 = P.vr1 = P.vr2 = P.vr3 = 0.f; P.T = 1.f; P.bdot = 0.f; P.C0 = 0.f; P.bin_final = -1;
+        if (pxi < W && pyi < H) {
+            const int64_t pix = (int64_t)pyi * W + pxi;
+            const float T_final = 1.0f - render_alphas[pix];
+            const float4 v = reinterpret_cast<const float4*>(v_render_colors)[pix];
+            P.vr0 = v.x; P.vr1 = v.y; P.vr2 = v.z; P.vr3 = v.w;
+            const float bg_dot = bgc[0] * v.x + bgc[1] * v.y + bgc[2] * v.z + bgc[3] * v.w;
+            P.C0 = T_final * (v_render_alphas[pix] - bg_dot);
+            P.T = T_final;
+            P.bin_final = last_ids[pix];
+        }
+        tile_bin_final = max(tile_bin_final, P.bin_final);
     }
-    float T = T_final;
-    // Only the projection of the "colour accumulated BEHIND the current splat" onto this pixel's output
-    // gradient is ever needed: bdot = sum_k buffer_k * v_render_k.  One register and one FMA per splat
-    // instead of four of each.
-    float bdot = 0.f;
-    float bg_dot = 0.f;
-    if (backgrounds) bg_dot = backgrounds[0] * vr0 + backgrounds[1] * vr1 + backgrounds[2] * vr2 + backgrounds[3] * vr3;
-    const float C0 = T_final * (v_render_a - bg_dot); // v_alpha = T*S1 + ra*(C0 - bdot)
-    const int wave_bin_final = wave_max_i(bin_final);
+    tile_bin_final = wave_max_i(tile_bin_final);
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
 
-    if (threadIdx.x < BWD_BATCH) {
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) sacc[threadIdx.x][k] = 0.f;
-    }
-
-    for (int b = 0; b < num_batches; ++b) {
+    // walk the tile's list back to front in groups of 64; groups entirely behind every pixel's last
+    // contributor are skipped without being loaded
+    const int first_end = min(range_end - 1, tile_bin_final);
+    for (int batch_end = first_end; batch_end >= range_start; batch_end -= 64) {
+        const int batch_size = min(64, batch_end + 1 - range_start);
         __syncthreads();
-        const int batch_end = range_end - 1 - BWD_BATCH * b;
-        const int batch_size = min(BWD_BATCH, batch_end + 1 - range_start);
-        const int idx = batch_end - (int)threadIdx.x;
-        if ((int)threadIdx.x < BWD_BATCH && idx >= range_start) {
-            const int g = flatten_ids[idx];
-            sid[threadIdx.x] = g;
-            srec[threadIdx.x][0] = rec4[3 * (int64_t)g];
-            srec[threadIdx.x][1] = rec4[3 * (int64_t)g + 1];
-            srec[threadIdx.x][2] = rec4[3 * (int64_t)g + 2];
+        int g = 0;
+        bool have = lane < batch_size;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        if (have) {
+            g = flatten_ids[batch_end - lane];
+            r0 = rec4[3 * (int64_t)g]; r1 = rec4[3 * (int64_t)g + 1]; r2 = rec4[3 * (int64_t)g + 2];
+            sid[lane] = g; srec[lane][0] = r0; srec[lane][1] = r1; srec[lane][2] = r2;
         }
         __syncthreads();
-        // staged slot s holds global list index batch_end - s (s = 0 is the furthest back)
-        for (int sub = 0; sub < batch_size; sub += 64) {
-            const int s = sub + lane;
-            bool hit = false;
-            if (s < batch_size && (batch_end - s) <= wave_bin_final) {
-                const float4 a = srec[s][0];
-                const float4 cq = srec[s][1];
-                hit = (a.x + a.w >= c.qx0) && (a.x - a.w <= c.qx1) && (a.y + cq.w >= c.qy0) && (a.y - cq.w <= c.qy1) &&
-                      splat_reaches_rect(a.x, a.y, cq.x, cq.y, cq.z, a.z, c.qx0, c.qx1, c.qy0, c.qy1);
-            }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int t = sub + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                // Branch-free body: an invalid lane gets vis = 0 => alpha = 0, ra = 1, fac = 0 and every
-                // gradient term vanishes on its own, so no exec-mask juggling and no zero-initialisation.
-                const float4 a = srec[t][0];
-                const float4 cn = srec[t][1];
-                const float opac = a.z;
-                const float dx = a.x - fx, dy = a.y - fy;
-                const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
-                float vis = __expf(-sigma);
-                const bool valid = c.inside && (batch_end - t <= bin_final) && !(sigma < 0.f) && !(opac * vis < ALPHA_THR);
-                if (__ballot(valid) == 0ull) continue;
-                vis = valid ? vis : 0.f;
-                const float ov = opac * vis;
-                const float alpha = fminf(MAX_ALPHA, ov);
-                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha); // 1 ulp v_rcp_f32; alpha <= 0.999
-                T *= ra;
-                const float fac = alpha * T;
-                const float4 col = srec[t][2];
-                const float S1 = col.x * vr0 + col.y * vr1 + col.z * vr2 + col.w * vr3;
-                const float v_alpha = T * S1 + ra * (C0 - bdot);
-                bdot += fac * S1;
-                const float gop = (ov <= MAX_ALPHA) ? vis * v_alpha : 0.f; // clamped alpha passes no gradient
-                const float v_sigma = -opac * gop;
-                const float t1 = v_sigma * dx, t2 = v_sigma * dy;
-                float acc[NACC];
-                acc[0] = cn.x * t1 + cn.y * t2;   // v_mean2d.x
-                acc[1] = cn.y * t1 + cn.z * t2;   // v_mean2d.y
-                acc[2] = gop;                     // v_opacity
-                acc[3] = t1 * dx;                 // 2 * v_conic.a  (x0.5 applied at the flush)
-                acc[4] = t1 * dy;                 // v_conic.b
-                acc[5] = t2 * dy;                 // 2 * v_conic.c  (x0.5 applied at the flush)
-                acc[6] = fac * vr0; acc[7] = fac * vr1; acc[8] = fac * vr2; acc[9] = fac * vr3;
-                // 64 -> 4 with DPP row reductions (VALU only), then ONE ds_add_f32 in which lane
-                // (row*16 + k) adds row `row`'s partial of value k: the 4 rows meet in the LDS atomic.
+        // splat-parallel culling: this lane's splat against each quadrant
+        unsigned long long mq[4];
 #pragma unroll
-                for (int k = 0; k < NACC; ++k) acc[k] = row16_allreduce_sum(acc[k]);
-                {
-                    const int kk = lane & 15;
-                    float v = acc[0];
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = qx0[q], x1 = x0 + 7.0f, y0 = qy0[q], y1 = y0 + 7.0f;
+            const bool hit = have && (r0.x + r0.w >= x0) && (r0.x - r0.w <= x1) && (r0.y + r1.w >= y0) && (r0.y - r1.w <= y1) &&
+                             splat_reaches_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, x0, x1, y0, y1);
+            mq[q] = __ballot(hit);
+        }
+        unsigned long long any = (mq[0] | mq[1]) | (mq[2] | mq[3]);
+        while (any) {
+            const int t = __builtin_ctzll(any); // staged slot t holds list index batch_end - t (0 = furthest back)
+            const unsigned long long bit = 1ull << t;
+            any &= any - 1;
+            const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
+            const float opac = a.z;
+            const int idx = batch_end - t;
+            float acc[NACC];
 #pragma unroll
-                    for (int k = 1; k < NACC; ++k) v = (kk == k) ? acc[k] : v;
-                    if (kk < NACC && v != 0.f) unsafeAtomicAdd(&sacc[t][kk], v);
+            for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mq[q] & bit) { // wave-uniform
+                    PixBwd& P = px[q];
+                    // Branch-free body: an invalid lane gets vis = 0 => alpha = 0, ra = 1, fac = 0 and every
+                    // gradient term vanishes on its own.
+                    const float dx = a.x - P.fx, dy = a.y - P.fy;
+                    const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
+                    float vis = __expf(-sigma);
+                    const bool valid = (idx <= P.bin_final) && !(sigma < 0.f) && !(opac * vis < ALPHA_THR);
+                    vis = valid ? vis : 0.f;
+                    const float ov = opac * vis;
+                    const float alpha = fminf(MAX_ALPHA, ov);
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha); // 1 ulp v_rcp_f32; alpha <= 0.999
+                    P.T *= ra;
+                    const float fac = alpha * P.T;
+                    const float S1 = col.x * P.vr0 + col.y * P.vr1 + col.z * P.vr2 + col.w * P.vr3;
+                    const float v_alpha = P.T * S1 + ra * (P.C0 - P.bdot);
+                    P.bdot += fac * S1;
+                    const float gop = (ov <= MAX_ALPHA) ? vis * v_alpha : 0.f; // clamped alpha passes no gradient
+                    const float v_sigma = -opac * gop;
+                    const float t1 = v_sigma * dx, t2 = v_sigma * dy;
+                    acc[0] += cn.x * t1 + cn.y * t2;   // v_mean2d.x
+                    acc[1] += cn.y * t1 + cn.z * t2;   // v_mean2d.y
+                    acc[2] += gop;                     // v_opacity
+                    acc[3] += t1 * dx;                 // 2 * v_conic.a
+                    acc[4] += t1 * dy;                 // v_conic.b
+                    acc[5] += t2 * dy;                 // 2 * v_conic.c
+                    acc[6] += fac * P.vr0; acc[7] += fac * P.vr1; acc[8] += fac * P.vr2; acc[9] += fac * P.vr3;
                 }
             }
-        }
-        __syncthreads();
-        // flush: one thread per staged splat, hardware fp32 atomics into the packed gradient record
-        if ((int)threadIdx.x < batch_size) {
-            const int64_t g = sid[threadIdx.x];
-            float* dst = v_rec + 12 * g;
-#pragma unroll
-            for (int k = 0; k < NACC; ++k) {
-                float v = sacc[threadIdx.x][k];
-                if (k == 3 || k == 5) v *= 0.5f;
-                if (v != 0.f) { unsafeAtomicAdd(dst + acc_to_rec(k), v); sacc[threadIdx.x][k] = 0.f; }
-            }
+            // ONE 64-lane reduction per (splat, tile): transposing butterfly (11 DPP ops instead of 60), after
+            // which 10 lanes of row 0 each own one total and publish it with a single atomic instruction
+            acc[3] *= 0.5f; acc[5] *= 0.5f;
+            const Reduce10 red = wave_reduce10(acc, lane);
+            if (red.is_owner && red.value != 0.f)
+                unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[t] + acc_to_rec(red.slot), red.value);
         }
     }
 }
@@ -349,7 +359,7 @@ extern "C" int adk_raster_bwd(int width, int height, const float* rec, const int
     if (!rec || !flatten_ids || !offsets || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas || !v_rec) return ADK_EINVAL;
     if (((uintptr_t)rec & 15) || ((uintptr_t)v_render_colors & 15)) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
-    hipLaunchKernelGGL(adk::raster_bwd_kernel, dim3(tile_w * tile_h), dim3(256), 0, stream, tile_w, tile_h, width, height,
+    hipLaunchKernelGGL(adk::raster_bwd_kernel, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
                        rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_alphas, last_ids, v_render_colors,
                        v_render_alphas, v_rec);
     ADK_RETURN_LAST_ERROR();
