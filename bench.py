@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-detail", action="store_true", help="print per-stage timings to stderr")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the secondary measurements (other BASELINE configs, unfused glue) reported next to `value`")
     ap.add_argument("--unfused-glue", action="store_true",
                     help="time ARTDECO's render() glue as stock torch ops instead of artdeco_amd.fused (SURVEY 8 f-1)")
     return ap.parse_args()
@@ -140,12 +142,51 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profile(args),
                          "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms},
         }
+        if not args.no_extra_configs and world == 1:
+            out["other_configs"] = extra_configs(args, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         if args.stage_detail:
             print(json.dumps(stages, indent=1), file=sys.stderr)
         print(json.dumps(out))
     multigpu.shutdown()
+
+
+def _time_steps(scene, steps=10, warmup=3):
+    nkf = len(scene.keyframes)
+    for i in range(warmup):
+        scene.optimization_step(i % nkf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        scene.optimization_step(i % nkf)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_configs(args, dev):
+    """Secondary single-GPU measurements, OUTSIDE the timed region of `value` (10 steps each): the other
+    BASELINE.json configs that fit one GPU, and the headline config with ARTDECO's render() glue left as stock
+    torch ops (what an unchanged run_system.py gets without the one-line artdeco_amd.fused patch)."""
+    from artdeco_amd import fused, mapper
+    res = {}
+    cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True),
+             ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True),
+             ("configs[3] 4M Gaussians 2592x1944", 4_000_000, 2592, 1944, True),
+             (f"headline config, unfused torch glue ({args.gaussians} Gaussians {args.width}x{args.height})",
+              args.gaussians, args.width, args.height, False)]
+    for name, n, w, h, use_fused in cases:
+        try:
+            scene = mapper.build_synthetic_mapper(n, w, h, dev, seed=0)
+            if use_fused:
+                fused.patch_scene_model(scene)
+            dt = _time_steps(scene)
+            res[name] = {"ms_per_step": dt * 1e3, "frames_per_s": 1.0 / (dt * STEPS_PER_FRAME)}
+            del scene
+            torch.cuda.empty_cache()
+        except Exception as e:  # report, never hide
+            res[name] = {"error": repr(e)}
+    return res
 
 
 def _traffic_from_profile(args):
