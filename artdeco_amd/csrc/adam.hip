@@ -170,3 +170,127 @@ extern "C" int adk_adam_update_basic(float* param, const float* grad, float* exp
     using namespace adk;
     return launch_adam<LR_VALUE, false>(param, grad, exp_avg, exp_avg_sq, nullptr, nullptr, lr, b1, b2, eps, numel, 1, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Multi-tensor step ("host glue"): SparseGaussianAdam.step (optimizers.py:77-161) issues one
+// adamUpdate per parameter (8 Gaussian tensors + 4 mlp tensors) and, for per-element learning rates, three
+// more torch ops per tensor (`lr[vis] *= decay; lr.clamp_min_(...)`, :158-161, with a boolean-index host
+// sync).  One launch does all of it: descriptors travel by value in the kernel argument block, a thread finds
+// its tensor with a <= 16-entry scan, applies the same IEEE-unfused update, and decays the per-element lr of
+// visible rows in place.
+namespace adk {
+
+#define ADAM_MAX_TENSORS 16
+struct AdamMultiArgs {
+    float* p[ADAM_MAX_TENSORS];
+    const float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    const uint8_t* vis[ADAM_MAX_TENSORS]; // NULL => dense
+    float* lr_ptr[ADAM_MAX_TENSORS];      // device lr (numel 1, rows or rows*M), or NULL => lr_val
+    float lr_val[ADAM_MAX_TENSORS];
+    float lr_decay[ADAM_MAX_TENSORS];     // applied to per-element lr of visible rows after the update (1 => none)
+    float lr_min[ADAM_MAX_TENSORS];
+    int64_t total[ADAM_MAX_TENSORS];      // elements
+    int64_t lr_numel[ADAM_MAX_TENSORS];
+    int64_t item_end[ADAM_MAX_TENSORS];   // exclusive prefix of ceil(total/4) work items
+    int M[ADAM_MAX_TENSORS];
+    int n;
+    float b1, b2, eps;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
+{
+    const float omb1 = 1.0f - A.b1, omb2 = 1.0f - A.b2;
+    const int64_t n_items = A.item_end[A.n - 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += stride) {
+        int t = 0;
+        while (it >= A.item_end[t]) ++t;
+        const int64_t vi = it - (t ? A.item_end[t - 1] : 0);
+        const int64_t e0 = vi << 2, total = A.total[t];
+        const int M = A.M[t];
+        const int cnt = (int)((total - e0) < 4 ? (total - e0) : 4);
+        const uint8_t* vis = A.vis[t];
+        float* lrp = A.lr_ptr[t];
+        const int64_t lrn = A.lr_numel[t];
+        float* p = A.p[t] + e0; const float* g = A.g[t] + e0; float* m = A.m[t] + e0; float* v = A.v[t] + e0;
+        int64_t row = e0 / M;
+        int col = (int)(e0 - row * M);
+        bool on[4] = {false, false, false, false};
+        int64_t rows[4] = {0, 0, 0, 0};
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rows[j] = row;
+            on[j] = (j < cnt) && (!vis || vis[row] != 0);
+            any |= on[j];
+            if (++col == M) { col = 0; ++row; }
+        }
+        if (!any) continue;
+        const bool vec = (cnt == 4) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+        float pv[4], gv[4], mv[4], vv[4];
+        if (vec) {
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(g);
+            const float4 c = *reinterpret_cast<const float4*>(m), d = *reinterpret_cast<const float4*>(v);
+            pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < cnt) { pv[j] = p[j]; gv[j] = g[j]; mv[j] = m[j]; vv[j] = v[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!on[j]) continue;
+            float lr = A.lr_val[t];
+            if (lrp) lr = (lrn == 1) ? lrp[0] : (lrn == total ? lrp[e0 + j] : lrp[rows[j]]);
+            adam_elem(pv[j], gv[j], mv[j], vv[j], lr, A.b1, A.b2, omb1, omb2, A.eps);
+            if (lrp && lrn == total && A.lr_decay[t] != 1.0f) lrp[e0 + j] = fmaxf(lr * A.lr_decay[t], A.lr_min[t]);
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(p) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            *reinterpret_cast<float4*>(m) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(v) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (on[j]) { p[j] = pv[j]; m[j] = mv[j]; v[j] = vv[j]; }
+        }
+    }
+}
+
+} // namespace adk
+
+// Arrays of length n (HOST memory, read during the call): device pointers per tensor, rows x M shapes, lr as
+// a device pointer (lr_numel in {1, rows, rows*M}) or NULL + lr_val.  lr_decay/lr_min apply to per-element lr
+// tensors only: lr[e] = max(lr[e] * decay, lr_min) for elements of visible rows, after the update.
+extern "C" int adk_adam_update_multi(int n, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                     float* const* exp_avg_sqs, const uint8_t* const* visibles, float* const* lr_ptrs,
+                                     const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
+                                     const float* lr_mins, const int64_t* rows, const int64_t* Ms, float b1, float b2,
+                                     float eps, hipStream_t stream)
+{
+    if (n < 0 || n > ADAM_MAX_TENSORS) return ADK_EINVAL;
+    if (n == 0) return 0;
+    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !visibles || !lr_ptrs || !lr_numels || !lr_vals || !lr_decays || !lr_mins || !rows || !Ms) return ADK_EINVAL;
+    adk::AdamMultiArgs A;
+    int k = 0;
+    int64_t items = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t total = rows[i] * Ms[i];
+        if (rows[i] < 0 || Ms[i] < 0 || Ms[i] > 0x7fffffff) return ADK_EINVAL;
+        if (total == 0) continue;
+        if (!params[i] || !grads[i] || !exp_avgs[i] || !exp_avg_sqs[i]) return ADK_EINVAL;
+        if (lr_ptrs[i] && !(lr_numels[i] == 1 || lr_numels[i] == rows[i] || lr_numels[i] == total)) return ADK_EINVAL;
+        A.p[k] = params[i]; A.g[k] = grads[i]; A.m[k] = exp_avgs[i]; A.v[k] = exp_avg_sqs[i]; A.vis[k] = visibles[i];
+        A.lr_ptr[k] = lr_ptrs[i]; A.lr_numel[k] = lr_ptrs[i] ? lr_numels[i] : 0; A.lr_val[k] = lr_vals[i];
+        A.lr_decay[k] = lr_decays[i]; A.lr_min[k] = lr_mins[i]; A.total[k] = total; A.M[k] = (int)Ms[i];
+        items += (total + 3) / 4;
+        A.item_end[k] = items;
+        ++k;
+    }
+    if (k == 0) return 0;
+    for (int i = k; i < ADAM_MAX_TENSORS; ++i) { A.item_end[i] = items; A.total[i] = 0; A.M[i] = 1; A.p[i] = nullptr; A.g[i] = nullptr; A.m[i] = nullptr; A.v[i] = nullptr; A.vis[i] = nullptr; A.lr_ptr[i] = nullptr; A.lr_numel[i] = 0; A.lr_val[i] = 0.f; A.lr_decay[i] = 1.f; A.lr_min[i] = 0.f; }
+    A.n = k; A.b1 = b1; A.b2 = b2; A.eps = eps;
+    hipLaunchKernelGGL(adk::adam_multi_kernel, dim3(adk::stream_grid(items, 256)), dim3(256), 0, stream, A);
+    ADK_RETURN_LAST_ERROR();
+}

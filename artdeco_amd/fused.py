@@ -184,6 +184,67 @@ def fused_render_from_id(self, keyframe_id, pyr_lvl=0, bg=None):
     return pkg
 
 
+def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
+    """Drop-in body for SparseGaussianAdam.step (Reconstruct/scene/optimizers.py:77-161): the same updates, the
+    same learning-rate decay, one kernel launch (adk_adam_update_multi) and no boolean-index host sync."""
+    import ctypes
+    lib = _lib.load()
+    skip = ("id", "cls_id", "d_max")
+    b1, b2 = self.betas
+    ent = []  # (param, grad, m, v, vis, lr_tensor|None, lr_val, decay, lr_min, rows, M)
+    keep = []
+    for key, pd in self.params.items():
+        if key in skip:
+            continue
+        val = pd["val"]
+        if val.grad is None:
+            continue
+        grad = val.grad.contiguous()
+        keep.append(grad)
+        if key.startswith("mlp"):
+            ent.append((val, grad, pd["exp_avg"], pd["exp_avg_sq"], None, None, float(pd["lr"]), 1.0, 0.0, val.numel(), 1))
+            if key in self.lr_dict:  # host-side float schedule, optimizers.py:102-104
+                pd["lr"] = max(pd["lr"] * self.lr_dict[key]["lr_decay"], self.lr_dict[key]["lr_init"] * 0.1)
+            continue
+        vis, n = (global_visibility, N_global) if key == "global_feat" else (visibility, N)
+        lr = pd["lr"]
+        decay, lr_min = 1.0, 0.0
+        if key in self.lr_dict:
+            decay, lr_min = float(self.lr_dict[key]["lr_decay"]), float(self.lr_dict[key]["lr_init"] * 0.1)
+            if lr.numel() != val.numel():  # per-row lr cannot be decayed per element in place; keep reference path
+                decay = 1.0
+        ent.append((val, grad, pd["exp_avg"], pd["exp_avg_sq"], vis, lr, 0.0, decay, lr_min, int(n), val.numel() // int(n)))
+    if not ent:
+        return
+    n = len(ent)
+    if n > 16:
+        raise _lib.AdkError("fused optimizer step supports at most 16 tensors")
+    dev = ent[0][0].device
+    VP, I64, F32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_float * n
+    ptr = lambda t: None if t is None else t.data_ptr()
+    for e in ent:
+        for t in (e[0], e[2], e[3]):
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise _lib.AdkError("fused optimizer step needs contiguous float32 parameters and moments")
+    args = (n, VP(*[e[0].data_ptr() for e in ent]), VP(*[e[1].data_ptr() for e in ent]), VP(*[e[2].data_ptr() for e in ent]),
+            VP(*[e[3].data_ptr() for e in ent]), VP(*[ptr(e[4]) for e in ent]), VP(*[ptr(e[5]) for e in ent]),
+            I64(*[(e[5].numel() if e[5] is not None else 0) for e in ent]), F32(*[e[6] for e in ent]),
+            F32(*[e[7] for e in ent]), F32(*[e[8] for e in ent]), I64(*[e[9] for e in ent]), I64(*[e[10] for e in ent]),
+            float(b1), float(b2), float(self.eps))
+    with torch.no_grad(), torch.cuda.device(dev):
+        with _stage("adam_multi"):
+            rc = lib.adk_adam_update_multi(*args, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "adk_adam_update_multi")
+    # per-row lr tensors (finetune path, h3dgsv3.py:1240-1247) keep the reference's torch decay
+    for key, pd in self.params.items():
+        if key in skip or key.startswith("mlp") or key not in self.lr_dict or pd["val"].grad is None:
+            continue
+        if pd["lr"].numel() != pd["val"].numel():
+            vis = global_visibility if key == "global_feat" else visibility
+            pd["lr"][vis] *= self.lr_dict[key]["lr_decay"]
+            pd["lr"].clamp_min_(self.lr_dict[key]["lr_init"] * 0.1)
+
+
 def patch_scene_model(scene) -> bool:
     """Install fused_render on this scene-model instance (ARTDECO's SceneModel or artdeco_amd.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
@@ -194,4 +255,8 @@ def patch_scene_model(scene) -> bool:
     if hasattr(scene, "render_from_id"):
         scene._unfused_render_from_id = scene.render_from_id
         scene.render_from_id = types.MethodType(fused_render_from_id, scene)
+    opt = getattr(scene, "optimizer", None)
+    if opt is not None and hasattr(opt, "lr_dict") and hasattr(opt, "params"):
+        opt._unfused_step = opt.step
+        opt.step = types.MethodType(fused_optimizer_step, opt)
     return True

@@ -82,6 +82,17 @@ int adk_adam_update(float* param, const float* grad, float* exp_avg, float* exp_
 int adk_adam_update_basic(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                           float b1, float b2, float eps, int64_t numel, adk_stream_t stream);
 
+/* Multi-tensor form of the two above: everything SparseGaussianAdam.step
+ * (optimizers.py:77-161) does for n <= 16 tensors in ONE launch, including the per-element lr decay
+ * `lr[vis] *= decay; lr.clamp_min_(lr_min)` of :158-161.  All array arguments are HOST arrays of length n read
+ * during the call; their entries are device pointers / sizes per tensor.  visibles[i] == NULL => dense update;
+ * lr_ptrs[i] == NULL => python-float lr lr_vals[i].  Same IEEE-unfused arithmetic as adk_adam_update. */
+int adk_adam_update_multi(int n, float* const* params, const float* const* grads, float* const* exp_avgs,
+                          float* const* exp_avg_sqs, const uint8_t* const* visibles, float* const* lr_ptrs,
+                          const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
+                          const float* lr_mins, const int64_t* rows, const int64_t* Ms, float b1, float b2,
+                          float eps, adk_stream_t stream);
+
 /* ---------------------------------------------------------------------- gsplat
  * The five stages behind gsplat.rendering.rasterization(...) [UPSTREAM gsplat >= 1.5, not
  * vendored] as called at Reconstruct/scene/scene_models/h3dgsv3.py:664-680 (one camera per

@@ -100,6 +100,46 @@ def test_exposure_clamp_matches_torch(dev):
     assert torch.allclose(E.grad, gE, rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.gpu
+def test_fused_optimizer_step_is_bit_identical(dev):
+    """adk_adam_update_multi (one launch, in-kernel lr decay) == the per-tensor adamUpdate loop + torch lr ops."""
+    import copy
+    from artdeco_amd import fused
+    a = _scene(dev, N=6000, seed=5)
+    a.optimization_step(0)                       # populates .grad on every parameter and non-trivial moments
+    grads = {k: v["val"].grad.clone() for k, v in a.optimizer.params.items() if v["val"].grad is not None}
+    vis = torch.rand(6000, device=dev) < 0.6
+    gvis = torch.rand(a.global_feat.shape[0], device=dev) < 0.5
+
+    def snapshot(opt):
+        return {k: [v["val"].detach().clone(), v["exp_avg"].clone(), v["exp_avg_sq"].clone(),
+                    (v["lr"].clone() if torch.is_tensor(v["lr"]) else float(v["lr"]))] for k, v in opt.params.items()}
+
+    def restore(opt, snap):
+        with torch.no_grad():
+            for k, (p, m, s, lr) in snap.items():
+                opt.params[k]["val"].copy_(p); opt.params[k]["exp_avg"].copy_(m); opt.params[k]["exp_avg_sq"].copy_(s)
+                if torch.is_tensor(lr):
+                    opt.params[k]["lr"].copy_(lr)
+                else:
+                    opt.params[k]["lr"] = lr
+                opt.params[k]["val"].grad = grads[k].clone()
+
+    s0 = snapshot(a.optimizer)
+    a.optimizer.step(vis, 6000, gvis, gvis.shape[0])
+    ref = snapshot(a.optimizer)
+    restore(a.optimizer, s0)
+    fused.fused_optimizer_step(a.optimizer, vis, 6000, gvis, gvis.shape[0])
+    got = snapshot(a.optimizer)
+    for k in ref:
+        for i in range(3):
+            assert torch.equal(got[k][i], ref[k][i]), (k, i)
+        if torch.is_tensor(ref[k][3]):
+            assert torch.equal(got[k][3], ref[k][3]), (k, "lr")
+        else:
+            assert got[k][3] == ref[k][3]
+
+
 def test_patch_refuses_unsupported_shapes():
     from artdeco_amd import fused
 
