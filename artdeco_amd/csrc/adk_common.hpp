@@ -81,7 +81,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 }
 
 // Sum 10 per-lane values across the 64 lanes with as few cross-lane operations as possible.
-// DPP-modified VALU ops issue at ~1/3.3 of the plain rate on gfx950 (measured, scratch/dpp_bench.hip), so
+// DPP-modified VALU ops issue at ~1/3.3 of the plain rate on gfx950 (measured, tools/dpp_bench.hip), so
 // instead of 10 independent 4-step row reductions (40 DPP ops) this is a TRANSPOSING butterfly inside each
 // 16-lane row: at every stage a lane keeps one half of its values and ships the other half to its partner
 // (row_mirror, row_half_mirror, quad mirror, quad xor-1), 5 + 3 + 2 + 1 = 11 DPP ops + ~20 selects.

@@ -191,7 +191,7 @@ struct PixBwd {
     int bin_final;       // index of the last splat that contributed in the forward (-1: pixel outside the image)
 };
 
-// MEASURED on MI355X (scratch/dpp_bench.hip): a DPP-modified VALU instruction issues at ~8.6 cycles per
+// MEASURED on MI355X (tools/dpp_bench.hip): a DPP-modified VALU instruction issues at ~8.6 cycles per
 // wave against 2.6 for a plain one (and a ds_bpermute shuffle+add pair at ~21).  Cross-lane reductions are
 // therefore the most expensive thing this kernel does, and the design goal is ONE reduction per (splat,
 // tile) instead of one per (splat, 8x8 quadrant):
