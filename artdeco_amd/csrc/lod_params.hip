@@ -133,10 +133,30 @@ __global__ __launch_bounds__(256) void lod_params_fwd_kernel(
     reinterpret_cast<float4*>(quat_eff)[g] = make_float4(q.x * y[3], q.y * y[4], q.z * y[5], q.w * y[6]);
 }
 
-// LDS per wave: A (dz | dy padded) and B (x | h) tiles, [64 Gaussians][32 + 1 pad]
+// ---- backward -------------------------------------------------------------------------------------
+// One wavefront per workgroup walks 64-Gaussian chunks.  Every dense contraction of the chunk runs on
+// the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32):
+//     H  = relu(X W1^T + b1)      [64x32] . [32x32]      (recomputed, not stored by the forward)
+//     Y  = H W2^T + b2            [64x32] . [32x7]
+//     VH = VY W2 ; VZ = VH * (H>0)[64x7]  . [7x32]
+//     VX = VZ W1                  [64x32] . [32x32]      -> v_local_feat rows, v_global_feat atomics
+//     dW1 += VZ^T X ; dW2 += VY^T H                      (K = Gaussians; accumulators live across chunks)
+// The four weight operands are loaded ONCE per wavefront into VGPR fragments in the B-operand layout;
+// activations move between the "lane = Gaussian" elementwise stages and the MFMA operand layout through
+// wave-private LDS tiles with a 33-float row pitch (conflict-free for both access patterns).
+// MFMA 32x32x2 layout: a = A[i = lane&31][k = lane>>5], b = B[k = lane>>5][j = lane&31],
+//                      d[r] = D[i = (r&3) + 8 (r>>2) + 4 (lane>>5)][j = lane&31].
 #define LOD_LDW 33
+#define LOD_YW 9
 
-__global__ __launch_bounds__(256) void lod_params_bwd_kernel(
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS traffic has landed (tiles are wave-private)
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lod_params_bwd_kernel(
     int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
     const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
     const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
@@ -147,144 +167,215 @@ __global__ __launch_bounds__(256) void lod_params_bwd_kernel(
     float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation, float* __restrict__ v_local_feat,
     float* __restrict__ v_global_feat /* [V,G], zeroed, atomics */, float* __restrict__ partials /* [gridDim.x][LOD_NW] */)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* sA = smem + (size_t)wv * 2 * 64 * LOD_LDW; // [64][33]
-    float* sB = sA + 64 * LOD_LDW;
+    __shared__ float TX[64 * LOD_LDW], TH[64 * LOD_LDW], TZ[64 * LOD_LDW], TY[64 * LOD_YW];
+    __shared__ int TC[64];
+    const int lane = threadIdx.x, kk = lane >> 5, rc = lane & 31;
+
+    // weight fragments (B operands), resident for the whole kernel
+    float w1t[16], w1n[16], w2t[16], w2n[4];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        w1t[s] = W1[rc * LOD_IN + 2 * s + kk];                              // B[k][j] = W1[j][k]
+        w1n[s] = W1[(2 * s + kk) * LOD_IN + rc];                            // B[k][j] = W1[k][j]
+        w2t[s] = rc < LOD_OUT ? W2[rc * LOD_HID + 2 * s + kk] : 0.f;        // B[k][o] = W2[o][k]
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int o = 2 * s + kk;
+        w2n[s] = o < LOD_OUT ? W2[o * LOD_HID + rc] : 0.f;                  // B[o][i] = W2[o][i]
+    }
+    const float bias1 = b1[rc], bias2 = rc < LOD_OUT ? b2[rc] : 0.f;
 
     const CamCentre cc = cam_centre_of(viewmat);
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
     f32x16 acc1, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
-    float bsum = 0.f; // lane i < 32: sum_g vz[g][i] ; lane 32+o (o<7): sum_g vy[g][o]
+    float bs1 = 0.f, bs2 = 0.f;
 
-    // persistent-style: a workgroup walks chunks of 256 Gaussians, the MFMA accumulators live across chunks
-    const int n_chunks = (N + 255) / 256;
+    const int n_chunks = (N + 63) / 64;
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const int64_t g = (int64_t)chunk * 256 + threadIdx.x;
-
-    float x[LOD_IN], h[LOD_HID], y[LOD_OUT], vy[LOD_OUT], vz[LOD_HID];
-#pragma unroll
-    for (int i = 0; i < LOD_IN; ++i) x[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < LOD_HID; ++i) { h[i] = 0.f; vz[i] = 0.f; }
-#pragma unroll
-    for (int o = 0; o < LOD_OUT; ++o) vy[o] = 0.f;
-
-    bool active = false;
-    if (g < N) {
-        const float vo = v_opac_eff[g];
-        const float vs0 = v_scale_eff[3 * g], vs1 = v_scale_eff[3 * g + 1], vs2 = v_scale_eff[3 * g + 2];
-        const float4 vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
-        const LodGeom L = lod_geometry(xyz, d_max, g, cc);
-        active = L.selected && (vo != 0.f || vs0 != 0.f || vs1 != 0.f || vs2 != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
-        float go = 0.f, gs[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f};
-        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-        float vx[LOD_IN];
-#pragma unroll
-        for (int j = 0; j < LOD_IN; ++j) vx[j] = 0.f;
-        if (active) {
-            const int64_t cls = cls_id[g];
-            load_features(global_feat, local_feat, cls, g, x);
-            mlp_forward(W1, b1, W2, b2, x, h, y);
-            // opacity = sigmoid(o) * alpha_ratio
-            const float so = sigmoidf(opacity_raw[g]);
-            go = vo * L.alpha_ratio * so * (1.f - so);
-            if (L.fading) { // d(alpha_ratio)/d(xyz) = -dir / d_max
-                const float c = -vo * so * L.inv_dmax;
-                gx[0] = c * L.dir[0]; gx[1] = c * L.dir[1]; gx[2] = c * L.dir[2];
-            }
-            // scaling = exp(s) * sigmoid(y)
-            const float vs[3] = {vs0, vs1, vs2};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float e = __expf(scaling_raw[3 * g + k]), sy = sigmoidf(y[k]);
-                gs[k] = vs[k] * e * sy;
-                vy[k] = vs[k] * e * sy * (1.f - sy);
-            }
-            // quat = rotation * y[3:7]
-            const float4 q = reinterpret_cast<const float4*>(rotation)[g];
-            gq = make_float4(vq.x * y[3], vq.y * y[4], vq.z * y[5], vq.w * y[6]);
-            vy[3] = vq.x * q.x; vy[4] = vq.y * q.y; vy[5] = vq.z * q.z; vy[6] = vq.w * q.w;
-            // mlp backward: vh = W2^T vy ; vz = vh * (h > 0) ; vx = W1^T vz
-#pragma unroll
-            for (int i = 0; i < LOD_HID; ++i) {
-                float a = 0.f;
-#pragma unroll
-                for (int o = 0; o < LOD_OUT; ++o) a += W2[o * LOD_HID + i] * vy[o];
-                vz[i] = h[i] > 0.f ? a : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < LOD_HID; ++i) {
-#pragma unroll
-                for (int j = 0; j < LOD_IN; ++j) vx[j] += W1[i * LOD_IN + j] * vz[i];
-            }
-            float* vg = v_global_feat + cls * LOD_G;
-#pragma unroll
-            for (int j = 0; j < LOD_G; ++j) if (vx[j] != 0.f) unsafeAtomicAdd(vg + j, vx[j]);
+        const int64_t g = (int64_t)chunk * 64 + lane;
+        // ---- stage 0 (lane = Gaussian): incoming gradients, LoD geometry, feature gather
+        bool active = false;
+        float vo = 0.f, vs[3] = {0.f, 0.f, 0.f};
+        float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
+        LodGeom L;
+        L.alpha_ratio = 1.f; L.inv_dmax = 0.f; L.fading = false; L.selected = false; L.dist = 0.f;
+        L.dir[0] = L.dir[1] = L.dir[2] = 0.f;
+        if (g < N) {
+            vo = v_opac_eff[g];
+            vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
+            vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
+            L = lod_geometry(xyz, d_max, g, cc);
+            active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
         }
-        v_opacity_raw[g] = go;
+        if (__ballot(active) == 0ull) { // nothing visible in this chunk: zero gradients, no matrix work
+            if (g < N) {
+                v_opacity_raw[g] = 0.f;
+                v_scaling_raw[3 * g] = 0.f; v_scaling_raw[3 * g + 1] = 0.f; v_scaling_raw[3 * g + 2] = 0.f;
+                reinterpret_cast<float4*>(v_rotation)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4* vl = reinterpret_cast<float4*>(v_local_feat + g * LOD_L);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { v_scaling_raw[3 * g + k] = gs[k]; if (gx[k] != 0.f) v_xyz_add[3 * g + k] += gx[k]; }
-        reinterpret_cast<float4*>(v_rotation)[g] = gq;
-        float4* vl = reinterpret_cast<float4*>(v_local_feat + g * LOD_L);
+                for (int i = 0; i < LOD_L / 4; ++i) vl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
+        {
+            float x[LOD_IN];
 #pragma unroll
-        for (int i = 0; i < LOD_L / 4; ++i) vl[i] = make_float4(vx[LOD_G + 4 * i], vx[LOD_G + 4 * i + 1], vx[LOD_G + 4 * i + 2], vx[LOD_G + 4 * i + 3]);
-    }
+            for (int i = 0; i < LOD_IN; ++i) x[i] = 0.f;
+            int c32 = -1;
+            if (active) {
+                const int64_t cls = cls_id[g];
+                c32 = (int)cls;
+                load_features(global_feat, local_feat, cls, g, x);
+            }
+            TC[lane] = c32;
+#pragma unroll
+            for (int i = 0; i < LOD_IN; ++i) TX[lane * LOD_LDW + i] = x[i];
+        }
+        lds_fence();
 
-    // ---- weight gradients on the matrix cores: per wave D1 += vz^T x (32x32), D2 += vy^T h (7x32 in a 32x32 tile)
-    const bool wave_active = __ballot(active) != 0ull; // uniform
-    if (wave_active) {
-        // pass 1: A = vz, B = x
+        // ---- H = relu(X W1^T + b1): two 32-row blocks; keep only the sign mask in registers
+        unsigned hmask[2] = {0u, 0u};
 #pragma unroll
-        for (int i = 0; i < LOD_HID; ++i) { sA[lane * LOD_LDW + i] = vz[i]; sB[lane * LOD_LDW + i] = x[i]; }
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave are done (wave-private tiles)
-        __builtin_amdgcn_wave_barrier();
-        const int kk = lane >> 5, rc = lane & 31;
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TX[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w1t[s], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const float h = fmaxf(d[r] + bias1, 0.f);
+                TH[row * LOD_LDW + rc] = h;
+                hmask[rb] |= (h > 0.f ? 1u : 0u) << r;
+            }
+        }
+        lds_fence();
+        // ---- Y = H W2^T + b2 (columns 0..6 of the 32-wide tile)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TH[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w2t[s], d, 0, 0, 0);
+            if (rc < 8) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    TY[row * LOD_YW + rc] = d[r] + bias2;
+                }
+            }
+        }
+        lds_fence();
+        // ---- elementwise stage (lane = Gaussian): activation gradients, vy
+        {
+            float y[LOD_OUT], vy[LOD_OUT];
+#pragma unroll
+            for (int o = 0; o < LOD_OUT; ++o) { y[o] = TY[lane * LOD_YW + o]; vy[o] = 0.f; }
+            float go = 0.f, gs[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f};
+            float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) {
+                // opacity = sigmoid(o) * alpha_ratio
+                const float so = sigmoidf(opacity_raw[g]);
+                go = vo * L.alpha_ratio * so * (1.f - so);
+                if (L.fading) { // d(alpha_ratio)/d(xyz) = -dir / d_max
+                    const float c = -vo * so * L.inv_dmax;
+                    gx[0] = c * L.dir[0]; gx[1] = c * L.dir[1]; gx[2] = c * L.dir[2];
+                }
+                // scaling = exp(s) * sigmoid(y)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float e = __expf(scaling_raw[3 * g + k]), sy = sigmoidf(y[k]);
+                    gs[k] = vs[k] * e * sy;
+                    vy[k] = vs[k] * e * sy * (1.f - sy);
+                }
+                // quat = rotation * y[3:7]
+                const float4 q = reinterpret_cast<const float4*>(rotation)[g];
+                gq = make_float4(vq.x * y[3], vq.y * y[4], vq.z * y[5], vq.w * y[6]);
+                vy[3] = vq.x * q.x; vy[4] = vq.y * q.y; vy[5] = vq.z * q.z; vy[6] = vq.w * q.w;
+            }
+            if (g < N) {
+                v_opacity_raw[g] = go;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { v_scaling_raw[3 * g + k] = gs[k]; if (gx[k] != 0.f) v_xyz_add[3 * g + k] += gx[k]; }
+                reinterpret_cast<float4*>(v_rotation)[g] = gq;
+            }
+#pragma unroll
+            for (int o = 0; o < LOD_OUT; ++o) TY[lane * LOD_YW + o] = vy[o];
+            TY[lane * LOD_YW + 7] = 0.f;
+        }
+        lds_fence();
+        // ---- VZ = (VY W2) * (H > 0)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TY[(rb * 32 + rc) * LOD_YW + 2 * s + kk], w2n[s], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                TZ[row * LOD_LDW + rc] = ((hmask[rb] >> r) & 1u) ? d[r] : 0.f;
+            }
+        }
+        lds_fence();
+        // ---- VX = VZ W1: columns 16..31 are the local-feature gradients (plain stores, every row),
+        //      columns 0..15 scatter into the voxel's global feature (hardware fp32 atomics)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w1n[s], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int64_t gg = (int64_t)chunk * 64 + row;
+                if (rc >= LOD_G) {
+                    if (gg < N) v_local_feat[gg * LOD_L + (rc - LOD_G)] = d[r];
+                } else {
+                    const int c = TC[row];
+                    if (c >= 0 && d[r] != 0.f) unsafeAtomicAdd(v_global_feat + (int64_t)c * LOD_G + rc, d[r]);
+                }
+            }
+        }
+        // ---- weight gradients: dW1 += VZ^T X, dW2 += VY^T H (K = the 64 Gaussians of the chunk)
 #pragma unroll 8
         for (int s = 0; s < 32; ++s) {
-            const float a = sA[(2 * s + kk) * LOD_LDW + rc];
-            const float b = sB[(2 * s + kk) * LOD_LDW + rc];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
+            const float a = TZ[(2 * s + kk) * LOD_LDW + rc];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TX[(2 * s + kk) * LOD_LDW + rc], acc1, 0, 0, 0);
+            bs1 += a;
         }
-        if (lane < 32) { for (int r = 0; r < 64; ++r) bsum += sA[r * LOD_LDW + lane]; }
-        __builtin_amdgcn_wave_barrier();
-        // pass 2: A = vy (rows 0..6, rest 0), B = h
-#pragma unroll
-        for (int i = 0; i < LOD_HID; ++i) { sA[lane * LOD_LDW + i] = (i < LOD_OUT) ? vy[i] : 0.f; sB[lane * LOD_LDW + i] = h[i]; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll 8
         for (int s = 0; s < 32; ++s) {
-            const float a = sA[(2 * s + kk) * LOD_LDW + rc];
-            const float b = sB[(2 * s + kk) * LOD_LDW + rc];
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
+            const float a = rc < 8 ? TY[(2 * s + kk) * LOD_YW + rc] : 0.f;
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TH[(2 * s + kk) * LOD_LDW + rc], acc2, 0, 0, 0);
+            bs2 += a;
         }
-        if (lane >= 32 && lane < 32 + LOD_OUT) { for (int r = 0; r < 64; ++r) bsum += sA[r * LOD_LDW + (lane - 32)]; }
-        __builtin_amdgcn_wave_barrier(); // tiles are rewritten by the next chunk
+        lds_fence(); // tiles are rewritten by the next chunk
     }
-    } // chunk loop
-    // ---- combine the 4 waves in LDS (each wave re-uses its own A|B tile: 4224 floats >= LOD_NW),
-    //      write one partial row per workgroup
-    __builtin_amdgcn_wave_barrier();
-    float* my = sA;
-    {
-        const int col = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + rbase; // C/D layout of mfma 32x32
-            my[row * LOD_IN + col] = acc1[r];                                   // dW1[row][col]
-            if (row < LOD_OUT) my[LOD_HID * LOD_IN + LOD_HID + row * LOD_HID + col] = acc2[r]; // dW2[row][col]
-        }
-        if (lane < 32) my[LOD_HID * LOD_IN + lane] = bsum;                      // db1
-        else if (lane < 32 + LOD_OUT) my[LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + (lane - 32)] = bsum; // db2
-    }
-    __syncthreads();
+
+    // ---- one partial row per workgroup: dW1 | db1 | dW2 | db2
     float* out = partials + (size_t)blockIdx.x * LOD_NW;
-    constexpr int WT = 2 * 64 * LOD_LDW; // floats per wave tile
-    for (int i = threadIdx.x; i < LOD_NW; i += 256)
-        out[i] = (smem[i] + smem[WT + i]) + (smem[2 * WT + i] + smem[3 * WT + i]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        out[row * LOD_IN + rc] = acc1[r];
+        if (row < LOD_OUT) out[LOD_HID * LOD_IN + LOD_HID + row * LOD_HID + rc] = acc2[r];
+    }
+    const float o1 = __shfl(bs1, (lane + 32) & 63), o2 = __shfl(bs2, (lane + 32) & 63);
+    if (lane < 32) out[LOD_HID * LOD_IN + lane] = bs1 + o1;
+    if (lane < LOD_OUT) out[LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + lane] = bs2 + o2;
 }
 
 // v_w[i] = sum_b partials[b][i]; 8 row-slices per column summed in a fixed order => deterministic
@@ -308,8 +399,6 @@ __global__ __launch_bounds__(256) void lod_reduce_partials_kernel(const float* _
 
 } // namespace adk
 
-#define LOD_BWD_SMEM ((4 * 2 * 64 * LOD_LDW) * (int)sizeof(float)) // 67,584 B: two workgroups per CU
-
 extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
                                   const float* rotation, const float* local_feat, const float* global_feat,
                                   const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
@@ -327,7 +416,7 @@ extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_
     ADK_RETURN_LAST_ERROR();
 }
 
-#define LOD_BWD_MAX_BLOCKS 512 // 2 resident workgroups per CU x 256 CUs
+#define LOD_BWD_MAX_BLOCKS 1280 // 5 resident single-wave workgroups (27.9 KB LDS each) per CU x 256 CUs
 extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)
 {
     if (N < 0) return ADK_EINVAL;
@@ -353,11 +442,9 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     if (!v_opac_eff || !v_scale_eff || !v_quat_eff || !v_xyz_add || !v_opacity_raw || !v_scaling_raw || !v_rotation || !v_local_feat || !v_global_feat || !workspace) return ADK_EINVAL;
     if (workspace_bytes < adk_lod_params_bwd_workspace_bytes(N)) return ADK_EWORKSPACE;
     if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)v_quat_eff | (uintptr_t)v_rotation | (uintptr_t)v_local_feat) & 15) return ADK_EINVAL;
-    int nb = (int)adk::ceil_div(N, 256);
+    int nb = (int)adk::ceil_div(N, 64);
     if (nb > LOD_BWD_MAX_BLOCKS) nb = LOD_BWD_MAX_BLOCKS;
-    // > 64 KiB of dynamic LDS needs the per-function opt-in (idempotent host-side call, no device work)
-    (void)hipFuncSetAttribute((const void*)adk::lod_params_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LOD_BWD_SMEM);
-    hipLaunchKernelGGL(adk::lod_params_bwd_kernel, dim3(nb), dim3(256), LOD_BWD_SMEM, stream, N, xyz, opacity_raw, scaling_raw,
+    hipLaunchKernelGGL(adk::lod_params_bwd_kernel, dim3(nb), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw,
                        rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff,
                        v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat,
                        (float*)workspace);
