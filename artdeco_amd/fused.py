@@ -105,6 +105,55 @@ def supported(scene) -> bool:
         return False
 
 
+_K_CACHE: dict = {}
+
+
+def _intrinsics(self, width, height, dev):
+    """K of h3dgsv3.py:640-645, cached per (size, fov, device): building it from a python list is a
+    pageable host-to-device copy every step."""
+    key = (int(width), int(height), float(self.tanfovx), float(self.tanfovy), str(dev))
+    K = _K_CACHE.get(key)
+    if K is None:
+        fl_x, fl_y = width / (2 * self.tanfovx), height / (2 * self.tanfovy)
+        K = torch.tensor([[fl_x, 0, width / 2.0], [0, fl_y, height / 2.0], [0, 0, 1]], dtype=torch.float32, device=dev)
+        _K_CACHE[key] = K
+    return K
+
+
+def visibility_masks(radii: torch.Tensor, cls_id: torch.Tensor, n_vox: int):
+    """visible_mask / global_visible_mask of h3dgsv3.py:695-698 in one kernel (no index_put, no host sync)."""
+    lib = _lib.load()
+    dev, N = radii.device, radii.shape[0]
+    with torch.cuda.device(dev):
+        vis = torch.empty(N, dtype=torch.bool, device=dev)
+        gvis = torch.empty(n_vox, dtype=torch.bool, device=dev)
+        cls = cls_id.view(-1)
+        if cls.dtype != torch.int64 or not cls.is_contiguous():
+            cls = cls.long().contiguous()
+        rc = lib.adk_visibility_masks(N, radii.data_ptr(), cls.data_ptr(), n_vox, vis.data_ptr(), gvis.data_ptr(),
+                                      _lib.stream_of(radii))
+    _lib.check(rc, "adk_visibility_masks")
+    return vis, gvis
+
+
+def _render_raw(self, width: int, height: int, view_matrix: torch.Tensor):
+    """LoD/MLP kernel + rasteriser: the rasteriser's own [H,W,4] colours(+depth) and [H,W,1] alphas."""
+    dev = self.device
+    lin1, lin2 = self.mlp_cov[0], self.mlp_cov[2]
+    P = self.gaussian_params
+    opac, scaling, quat, sel = FusedLodParams.apply(
+        P["xyz"]["val"], P["opacity"]["val"], P["scaling"]["val"], P["rotation"]["val"], P["local_feat"]["val"],
+        P["global_feat"]["val"], lin1.weight, lin1.bias, lin2.weight, lin2.bias, P["cls_id"]["val"], P["d_max"]["val"],
+        view_matrix.detach())
+    K = _intrinsics(self, width, height, dev)
+    eps2d = self.args.low_pass_filter_eps if hasattr(self, "args") else self.eps2d
+    out = render_camera(P["xyz"]["val"], quat, scaling, opac, P["f_dc"]["val"], view_matrix.float(), K, width, height,
+                        sh_degree=self.active_sh_degree, eps2d=eps2d, sh_rest=P["f_rest"]["val"])
+    col4, alphas, radii = out[0], out[1], out[2]
+    vis, gvis = visibility_masks(radii, P["cls_id"]["val"], P["global_feat"]["val"].shape[0])
+    return col4, alphas, scaling, vis, gvis
+
+
 def fused_render(self, width: int, height: int, view_matrix: torch.Tensor, bg: torch.Tensor | None = None):
     """Drop-in body for SceneModel.render (h3dgsv3.py:617-700)."""
     dev = self.device
@@ -113,25 +162,10 @@ def fused_render(self, width: int, height: int, view_matrix: torch.Tensor, bg: t
     if lock is not None:
         lock.acquire()
     try:
-        lin1, lin2 = self.mlp_cov[0], self.mlp_cov[2]
-        P = self.gaussian_params
-        opac, scaling, quat, sel = FusedLodParams.apply(
-            P["xyz"]["val"], P["opacity"]["val"], P["scaling"]["val"], P["rotation"]["val"], P["local_feat"]["val"],
-            P["global_feat"]["val"], lin1.weight, lin1.bias, lin2.weight, lin2.bias, P["cls_id"]["val"], P["d_max"]["val"],
-            view_matrix.detach())
-        fl_x, fl_y = width / (2 * self.tanfovx), height / (2 * self.tanfovy)
-        K = torch.tensor([[fl_x, 0, width / 2.0], [0, fl_y, height / 2.0], [0, 0, 1]], dtype=torch.float32, device=dev)
-        eps2d = self.args.low_pass_filter_eps if hasattr(self, "args") else self.eps2d
-        out = render_camera(P["xyz"]["val"], quat, scaling, opac, P["f_dc"]["val"], view_matrix.float(), K, width, height,
-                            sh_degree=self.active_sh_degree, eps2d=eps2d, sh_rest=P["f_rest"]["val"])
-        col4, alphas, radii = out[0], out[1], out[2]
+        col4, alphas, scaling, visible_mask, global_visible_mask = _render_raw(self, width, height, view_matrix)
         rendered_alpha = alphas.permute(2, 0, 1)
         rendered_color = col4[..., 0:3].permute(2, 0, 1) + (1.0 - rendered_alpha) * bg[:, None, None]
         invdepth = 1.0 / col4[..., 3:4].permute(2, 0, 1)
-        visible_mask = (radii[:, 0] > 0) & (radii[:, 1] > 0)
-        cls = P["cls_id"]["val"].view(-1)
-        n_vox = P["global_feat"]["val"].shape[0]
-        global_visible_mask = torch.zeros(n_vox, dtype=torch.int32, device=dev).index_add_(0, cls, visible_mask.int()) > 0
     finally:
         if lock is not None:
             lock.release()
@@ -245,6 +279,185 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
             pd["lr"].clamp_min_(self.lr_dict[key]["lr_init"] * 0.1)
 
 
+class PoseRt(torch.autograd.Function):
+    """Keyframe.get_Rt (scene/keyframe.py:150-154): [sixD2mtx(rW2C) | tW2C ; 0 0 0 1] as one tiny kernel each way
+    instead of ~40 (norm, div, sum, cross, stack, eye, two slice-assigns and their autograd)."""
+
+    @staticmethod
+    def forward(ctx, r6, t):
+        lib = _lib.load()
+        _lib.require_cuda(r6, t)
+        r6c, tc = r6.detach().contiguous().float(), t.detach().contiguous().float()
+        with torch.cuda.device(r6c.device):
+            Rt = torch.empty(4, 4, dtype=torch.float32, device=r6c.device)
+            rc = lib.adk_pose6d_fwd(r6c.data_ptr(), tc.data_ptr(), Rt.data_ptr(), _lib.stream_of(r6c))
+        _lib.check(rc, "adk_pose6d_fwd")
+        ctx.save_for_backward(r6c)
+        return Rt
+
+    @staticmethod
+    def backward(ctx, v_Rt):
+        lib = _lib.load()
+        (r6c,) = ctx.saved_tensors
+        with torch.cuda.device(r6c.device):
+            v_Rt = v_Rt.contiguous().float()
+            v_r6, v_t = torch.empty_like(r6c), torch.empty(3, dtype=torch.float32, device=r6c.device)
+            rc = lib.adk_pose6d_bwd(r6c.data_ptr(), v_Rt.data_ptr(), v_r6.data_ptr(), v_t.data_ptr(), _lib.stream_of(r6c))
+        _lib.check(rc, "adk_pose6d_bwd")
+        return v_r6, v_t
+
+
+_SSIM_C1, _SSIM_C2 = 0.01 ** 2, 0.03 ** 2  # fused_ssim/__init__.py:36-37
+
+
+class FusedMapperLoss(torch.autograd.Function):
+    """(colors4 [H,W,4], alphas [H,W,1], exposure [>=3,4] | bg [3], gt [3,H,W], mono_idepth [1,H,W], rdk [H,W],
+    lambda_dssim, depth_weight, mask_outliers) -> loss (0-dim), image [3,H,W], invdepth [1,H,W], parts [4]
+    = the composite + exposure + clamp + (outlier mask) + L1 + fused-SSIM + inverse-depth L1 mix of
+    h3dgsv3.py:690-694, 611-614, 430-448; image / invdepth / parts are non-differentiable by-products."""
+
+    @staticmethod
+    def forward(ctx, colors4, alphas, exposure, bg, gt, mono, rdk, lambda_dssim, depth_weight, mask_outliers):
+        lib = _lib.load()
+        _lib.require_cuda(colors4, alphas, exposure, bg, gt, mono, rdk)
+        dev = colors4.device
+        H, W = colors4.shape[0], colors4.shape[1]
+        f = lambda t: t.detach().contiguous().float()
+        colors4, alphas, E, bg, gt, mono, rdk = f(colors4), f(alphas), f(exposure), f(bg), f(gt), f(mono), f(rdk)
+        if gt.numel() != 3 * H * W or mono.numel() != H * W or rdk.numel() != H * W or E.numel() < 12:
+            raise ValueError("FusedMapperLoss: gt [3,H,W], mono_idepth [1,H,W], rdk [H,W], exposure [3,4] expected")
+        mo = 1 if mask_outliers else 0
+        lam, wd = float(lambda_dssim), float(depth_weight)
+        with torch.cuda.device(dev):
+            st = _lib.stream_of(colors4)
+            image = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            gt_used = torch.empty(3, H, W, dtype=torch.float32, device=dev) if mo else gt
+            invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            ssim_map = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            dm = torch.empty(3, 3, H, W, dtype=torch.float32, device=dev)
+            parts = torch.empty(4, dtype=torch.float32, device=dev)
+            ws = torch.empty(int(lib.adk_photometric_workspace_bytes(W, H)), dtype=torch.uint8, device=dev)
+            with _stage("photometric_fwd"):
+                rc = lib.adk_photometric_fwd(W, H, colors4.data_ptr(), alphas.data_ptr(), bg.data_ptr(), E.data_ptr(),
+                                             gt.data_ptr(), mono.data_ptr(), rdk.data_ptr(), mo, image.data_ptr(),
+                                             gt_used.data_ptr() if mo else None, invdepth.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "adk_photometric_fwd")
+            with _stage("ssim_fwd"):
+                rc = lib.adk_fused_ssim_fwd(image.data_ptr(), gt_used.data_ptr(), 1, 3, H, W, _SSIM_C1, _SSIM_C2,
+                                            ssim_map.data_ptr(), dm[0].data_ptr(), dm[1].data_ptr(), dm[2].data_ptr(), st)
+            _lib.check(rc, "adk_fused_ssim_fwd")
+            with _stage("photometric_loss"):
+                rc = lib.adk_photometric_loss(W, H, ssim_map.data_ptr(), lam, wd, ws.data_ptr(), ws.numel(), parts.data_ptr(), st)
+            _lib.check(rc, "adk_photometric_loss")
+        ctx.save_for_backward(colors4, alphas, E, bg, gt, mono, rdk, image, gt_used, dm)
+        ctx.cfg = (H, W, lam, wd, mo, tuple(exposure.shape))
+        loss = parts[0].clone()
+        ctx.mark_non_differentiable(image, invdepth, parts)
+        return loss, image, invdepth, parts
+
+    @staticmethod
+    def backward(ctx, v_loss, *_unused):
+        lib = _lib.load()
+        colors4, alphas, E, bg, gt, mono, rdk, image, gt_used, dm = ctx.saved_tensors
+        H, W, lam, wd, mo, e_shape = ctx.cfg
+        dev = colors4.device
+        with torch.cuda.device(dev):
+            st = _lib.stream_of(colors4)
+            v_loss = v_loss.detach().reshape(1).float().contiguous()
+            v_img = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            with _stage("ssim_bwd"):
+                rc = lib.adk_fused_ssim_bwd(image.data_ptr(), gt_used.data_ptr(), None, -lam / float(3 * H * W), dm[0].data_ptr(),
+                                            dm[1].data_ptr(), dm[2].data_ptr(), 1, 3, H, W, v_img.data_ptr(), st)
+            _lib.check(rc, "adk_fused_ssim_bwd")
+            v_col = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
+            v_alpha = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
+            v_E12 = torch.empty(12, dtype=torch.float32, device=dev)
+            with _stage("photometric_bwd"):
+                rc = lib.adk_photometric_bwd(W, H, colors4.data_ptr(), alphas.data_ptr(), bg.data_ptr(), E.data_ptr(),
+                                             gt.data_ptr(), mono.data_ptr(), rdk.data_ptr(), mo, v_img.data_ptr(),
+                                             v_loss.data_ptr(), lam, wd, v_col.data_ptr(), v_alpha.data_ptr(), v_E12.data_ptr(), st)
+            _lib.check(rc, "adk_photometric_bwd")
+            if e_shape == (3, 4):
+                v_E = v_E12.view(3, 4)
+            else:
+                v_E = torch.zeros(e_shape, dtype=torch.float32, device=dev)
+                v_E.view(-1)[:12] = v_E12
+        return v_col, v_alpha, v_E, None, None, None, None, None, None, None
+
+
+def _rdk_cached(self, h, w):
+    """radial_decay_kernel(h, w, rad_decay) (utils.py:818-827), built once per resolution on the device."""
+    cache = self.__dict__.setdefault("_adk_rdk", {})
+    key = (int(h), int(w), float(self.rad_decay))
+    if key not in cache:
+        y = torch.linspace(-1, 1, steps=h)
+        x = torch.linspace(-1, 1, steps=w)
+        yy, xx = torch.meshgrid(y, x, indexing="ij")
+        cache[key] = torch.exp(-(xx ** 2 + yy ** 2) / (2 * self.rad_decay ** 2)).to(self.device).contiguous()
+    return cache[key]
+
+
+def fused_train_on_keyframe(self, keyframe_id, is_important=True):
+    """The body of SceneModel.optimization_step after the keyframe has been chosen (h3dgsv3.py:418-464): same
+    order of operations (zero_grad, render at the keyframe's level with a random background, loss, backward,
+    pose step, Gaussian step, latest_invdepth) with the image-space chain in FusedMapperLoss."""
+    keyframe = self.keyframes[keyframe_id]
+    lvl = keyframe.pyr_lvl
+    keyframe.zero_grad()
+    self.optimizer.zero_grad()
+    dev = self.device
+    bg = torch.rand(3, device=dev)
+    scale = 2 ** lvl
+    width, height = self.width // scale, self.height // scale
+    if keyframe.rW2C.is_cuda and keyframe.rW2C.dtype == torch.float32:
+        view_matrix = PoseRt.apply(keyframe.rW2C, keyframe.tW2C)
+    else:
+        view_matrix = keyframe.get_Rt().to(dev)
+    lock = getattr(self, "lock", None)
+    if lock is not None:
+        lock.acquire()
+    try:
+        col4, alphas, scaling, vis, gvis = _render_raw(self, width, height, view_matrix)
+    finally:
+        if lock is not None:
+            lock.release()
+    gt_image = keyframe.image_pyr[lvl]
+    mono_idepth = keyframe.get_mono_idepth(lvl)
+    rdk = _rdk_cached(self, height, width)
+    loss, _image, invdepth, _parts = FusedMapperLoss.apply(col4, alphas, keyframe.exposure, bg, gt_image, mono_idepth, rdk,
+                                                           self.lambda_dssim, keyframe.depth_loss_weight, not is_important)
+    if self.scaling_reg_factor != 0:
+        loss = loss + self.scaling_reg_factor * scaling.prod(dim=1).mean()
+    loss.backward()
+    with torch.no_grad():
+        keyframe.step()
+        if not keyframe.is_test:
+            self.optimizer.step(vis, vis.shape[0], gvis, gvis.shape[0])
+        keyframe.latest_invdepth = invdepth
+    return loss.detach()
+
+
+def fused_optimization_step_mirror(self, keyframe_id=-1, is_important=True):
+    """artdeco_amd.mapper.MapperScene.optimization_step with the fused chain."""
+    if len(self.xyz) == 0:
+        return None
+    return fused_train_on_keyframe(self, keyframe_id, is_important)
+
+
+def fused_optimization_step(self, is_important=True, finetuning=False):
+    """Drop-in body for SceneModel.optimization_step (h3dgsv3.py:401-469), keyframe choice included."""
+    import numpy as np
+    if len(self.xyz) == 0:
+        return
+    if np.random.rand() > self.use_last_frame_proba or self.last_trained_id == -1 or finetuning:
+        keyframe_id = self.get_training_id()
+    else:
+        keyframe_id = -1
+    fused_train_on_keyframe(self, keyframe_id, is_important)
+    self.valid_Rt_cache[keyframe_id] = False
+    self.last_trained_id = keyframe_id
+
+
 def patch_scene_model(scene) -> bool:
     """Install fused_render on this scene-model instance (ARTDECO's SceneModel or artdeco_amd.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
@@ -259,4 +472,8 @@ def patch_scene_model(scene) -> bool:
     if opt is not None and hasattr(opt, "lr_dict") and hasattr(opt, "params"):
         opt._unfused_step = opt.step
         opt.step = types.MethodType(fused_optimizer_step, opt)
+    if hasattr(scene, "optimization_step") and hasattr(scene, "lambda_dssim") and hasattr(scene, "rad_decay"):
+        scene._unfused_optimization_step = scene.optimization_step
+        body = fused_optimization_step if hasattr(scene, "get_training_id") else fused_optimization_step_mirror
+        scene.optimization_step = types.MethodType(body, scene)
     return True

@@ -246,6 +246,47 @@ int adk_exposure_fwd(const float* E, const float* img, int64_t P, float* out, ad
 int adk_exposure_bwd(const float* E, const float* img, const float* v_out, int64_t P, float* v_img,
                      float* v_E, adk_stream_t stream);
 
+/* ------------------------------------------------- training-loss image chain
+ * The image-space half of SceneModel.optimization_step between the rasteriser
+ * output and loss.backward(), Reconstruct/scene/scene_models/h3dgsv3.py:
+ *   :690-694 background composite + invdepth = 1 / depth,
+ *   :611-614 exposure correction + clamp,
+ *   :432-439 (is_important == False) outlier mask,
+ *   :440-448 radial-decay-weighted L1 on colour and inverse depth, loss mix.
+ * colors4 [H,W,4] / alphas [H,W] are the rasteriser's outputs as they are
+ * (adk_raster_fwd); gt_image [3,H,W], mono_idepth [H,W], rdk [H,W] (the radial
+ * decay kernel, utils.py:818-827); bg [3]; exposure [3,4] row-major, all device.
+ * Writes image [3,H,W] (what fused_ssim is then called on), invdepth [H,W]
+ * (unmasked, Keyframe.latest_invdepth) and, when mask_outliers != 0, gt_used
+ * [3,H,W] = gt * mask.  Partial sums stay in the workspace. */
+int64_t adk_photometric_workspace_bytes(int W, int H);
+int adk_photometric_fwd(int W, int H, const float* colors4, const float* alphas, const float* bg,
+                        const float* exposure, const float* gt_image, const float* mono_idepth,
+                        const float* rdk, int mask_outliers, float* image, float* gt_used,
+                        float* invdepth, void* workspace, int64_t workspace_bytes, adk_stream_t stream);
+/* loss_out [4] = { lambda (1 - ssim) + (1 - lambda) l1 + depth_weight depth, l1, ssim, depth };
+ * ssim_map [3,H,W] from adk_fused_ssim_fwd(image, gt).  Same workspace, same stream, after _fwd. */
+int adk_photometric_loss(int W, int H, const float* ssim_map, float lambda_dssim, float depth_weight,
+                         void* workspace, int64_t workspace_bytes, float* loss_out, adk_stream_t stream);
+/* Backward of the whole chain.  v_image_ssim [3,H,W]: adk_fused_ssim_bwd(...) with dL_dmap = NULL and
+ * dL_scalar = -lambda / (3 W H); v_loss: DEVICE scalar, autograd's gradient of the loss.  Writes
+ * v_colors4 [H,W,4], v_alphas [H,W] (the layouts adk_raster_bwd consumes) and v_exposure [12]. */
+int adk_photometric_bwd(int W, int H, const float* colors4, const float* alphas, const float* bg,
+                        const float* exposure, const float* gt_image, const float* mono_idepth,
+                        const float* rdk, int mask_outliers, const float* v_image_ssim, const float* v_loss,
+                        float lambda_dssim, float depth_weight, float* v_colors4, float* v_alphas,
+                        float* v_exposure, adk_stream_t stream);
+
+/* Keyframe.get_Rt (Reconstruct/scene/keyframe.py:150-154) = [sixD2mtx(rW2C) | tW2C ; 0 0 0 1]
+ * (utils.py:223-229): r6 [3,2] row-major, t [3] -> Rt [4,4]; and its backward. */
+int adk_pose6d_fwd(const float* r6, const float* t, float* Rt, adk_stream_t stream);
+int adk_pose6d_bwd(const float* r6, const float* v_Rt, float* v_r6, float* v_t, adk_stream_t stream);
+
+/* Visibility masks of SceneModel.render (h3dgsv3.py:695-698): vis[g] = radii[g] > 0 (both axes);
+ * gvis[cls_id[g]] = 1 for every visible g (gvis [V] bytes, cleared here; may be NULL). */
+int adk_visibility_masks(int N, const int* radii, const int64_t* cls_id, int64_t V, uint8_t* vis,
+                         uint8_t* gvis, adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,9 +69,9 @@ def test_fused_optimization_step_tracks_unfused(dev):
     la, lb = [], []
     for i in range(3):
         torch.manual_seed(i)
-        la.append(float(a.optimization_step(i % 2)))
+        la.append(float(a.optimization_step(i % 2, is_important=(i != 1))))
         torch.manual_seed(i)
-        lb.append(float(b.optimization_step(i % 2)))
+        lb.append(float(b.optimization_step(i % 2, is_important=(i != 1))))
     assert all(abs(x - y) <= 2e-5 * max(1.0, abs(x)) for x, y in zip(la, lb)), (la, lb)
     # Adam (eps = 1e-15, no bias correction) turns ANY gradient into a step of ~5 lr, so elements whose gradient
     # is rounding noise may step in opposite directions; compare the update DIRECTION over the whole tensor.
@@ -80,6 +80,96 @@ def test_fused_optimization_step_tracks_unfused(dev):
         ub = (b.gaussian_params[k]["val"] - p0[k]).flatten().double()
         cos = float((ua @ ub) / (ua.norm() * ub.norm() + 1e-30))
         assert cos >= 0.97, (k, cos)
+
+
+@pytest.mark.gpu
+def test_pose_rt_matches_sixd_autograd(dev):
+    """PoseRt (one kernel each way) vs Keyframe.get_Rt's torch chain (keyframe.py:150-154, utils.py:223-229)."""
+    from artdeco_amd.fused import PoseRt
+    from artdeco_amd.mapper import sixD2mtx
+    g = torch.Generator().manual_seed(1)
+    for trial in range(4):
+        r6 = (torch.eye(3)[:, :2] + 0.4 * torch.randn(3, 2, generator=g)).to(dev).requires_grad_(True)
+        t = torch.randn(3, generator=g).to(dev).requires_grad_(True)
+        w = torch.randn(4, 4, generator=g).to(dev)
+        Rt = torch.eye(4, device=dev)
+        Rt[:3, :3] = sixD2mtx(r6)
+        Rt[:3, 3] = t
+        (Rt * w).sum().backward()
+        gr, gt = r6.grad.clone(), t.grad.clone()
+        r6.grad = t.grad = None
+        out = PoseRt.apply(r6, t)
+        (out * w).sum().backward()
+        assert torch.allclose(out, Rt.detach(), atol=1e-6)
+        assert torch.allclose(r6.grad, gr, rtol=1e-4, atol=1e-5), (r6.grad, gr)
+        assert torch.allclose(t.grad, gt, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("important", [True, False])
+def test_fused_mapper_loss_matches_torch_chain(important, dev):
+    """FusedMapperLoss vs the reference's image-space chain written in torch (h3dgsv3.py:690-694, 611-614,
+    430-448) on the same rasteriser-shaped inputs: loss, by-products and all three gradients."""
+    from artdeco_amd.fused import FusedMapperLoss
+    from artdeco_amd.mapper import radial_decay_kernel
+    from fused_ssim import fused_ssim
+    H, W = 75, 133
+    g = torch.Generator().manual_seed(7)
+    col4 = torch.cat([torch.rand(H, W, 3, generator=g) * 1.3 - 0.15, 0.5 + 3 * torch.rand(H, W, 1, generator=g)], -1).to(dev).requires_grad_(True)
+    alphas = (0.6 + 0.4 * torch.rand(H, W, 1, generator=g)).to(dev).requires_grad_(True)
+    E = (torch.eye(3, 4) + 0.1 * torch.randn(3, 4, generator=g)).to(dev).requires_grad_(True)
+    bg = torch.rand(3, generator=g).to(dev)
+    gt = torch.rand(3, H, W, generator=g).to(dev)
+    mono = (0.2 + torch.rand(1, H, W, generator=g)).to(dev)
+    rdk = radial_decay_kernel(H, W, 5 ** 0.5).to(dev)
+    lam, wd = 0.2, 0.037
+
+    def torch_chain():
+        rendered_alpha = alphas.permute(2, 0, 1)
+        image = col4[..., 0:3].permute(2, 0, 1) + (1.0 - rendered_alpha) * bg[:, None, None]
+        invdepth = 1.0 / col4[..., 3:4].permute(2, 0, 1)
+        image = ((E[:3, :3] @ image.reshape(3, -1)) + E[:3, 3, None]).clamp(0, 1).view(3, H, W)
+        gt_i, mono_i, inv_i = gt, mono, invdepth
+        if not important:
+            error_map = rdk * (image - gt).abs()
+            m = ~((error_map[0] > 0.2) | (error_map[1] > 0.2) | (error_map[1] > 0.2))
+            image, gt_i, inv_i, mono_i = image * m, gt * m, invdepth * m, mono * m
+        l1 = (rdk * (image - gt_i).abs()).mean()
+        ss = fused_ssim(image[None], gt_i[None])
+        dl = (rdk * (inv_i - mono_i).abs()).mean()
+        return lam * (1 - ss) + (1 - lam) * l1 + wd * dl, image, invdepth, (l1, ss, dl)
+
+    ref, img_ref, inv_ref, (l1, ss, dl) = torch_chain()
+    (ref * 1.7).backward()
+    gref = [t.grad.clone() for t in (col4, alphas, E)]
+    for t in (col4, alphas, E):
+        t.grad = None
+    loss, image, invdepth, parts = FusedMapperLoss.apply(col4, alphas, E, bg, gt, mono, rdk, lam, wd, not important)
+    (loss * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    assert torch.allclose(parts[1:], torch.stack([l1, ss, dl]).detach(), rtol=2e-5, atol=1e-6)
+    assert torch.allclose(image, img_ref.detach(), atol=1e-6)
+    assert torch.allclose(invdepth, inv_ref.detach(), rtol=1e-6)
+    if not important:
+        assert float((image == 0).float().mean()) > 0.01  # the mask did cut something
+    for name, a, b in zip(("colors4", "alphas", "exposure"), (col4.grad, alphas.grad, E.grad), gref):
+        err = (a - b).abs().max() / (b.abs().max() + 1e-30)
+        assert float(err) <= 2e-4, (name, float(err))
+
+
+@pytest.mark.gpu
+def test_visibility_masks_match_torch(dev):
+    from artdeco_amd.fused import visibility_masks
+    g = torch.Generator().manual_seed(2)
+    N, V = 10007, 911
+    radii = (torch.randint(-1, 4, (N, 2), generator=g).clamp_min(0)).int().to(dev)
+    cls = torch.randint(0, V, (N, 1), generator=g).to(dev)
+    vis, gvis = visibility_masks(radii, cls, V)
+    ref = (radii[:, 0] > 0) & (radii[:, 1] > 0)
+    gref = torch.zeros(V, dtype=torch.bool, device=dev)
+    gref[cls[ref].squeeze(-1)] = True
+    assert vis.dtype == torch.bool and gvis.dtype == torch.bool
+    assert torch.equal(vis, ref) and torch.equal(gvis, gref)
 
 
 @pytest.mark.gpu
