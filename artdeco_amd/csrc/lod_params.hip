@@ -378,21 +378,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (lane < LOD_OUT) out[LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + lane] = bs2 + o2;
 }
 
-// v_w[i] = sum_b partials[b][i]; 8 row-slices per column summed in a fixed order => deterministic
-__global__ __launch_bounds__(256) void lod_reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
-                                                                  float* __restrict__ v_w)
+// v_w[i] = sum_b partials[b][i]; 32 row-slices per column summed in a fixed order => deterministic
+#define LOD_RED_PARTS 32
+__global__ __launch_bounds__(1024) void lod_reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
+                                                                   float* __restrict__ v_w)
 {
-    __shared__ float red[8][32];
+    __shared__ float red[LOD_RED_PARTS][32];
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
-    float s = 0.f;
-    if (col < LOD_NW)
-        for (int b = part; b < nblocks; b += 8) s += partials[(size_t)b * LOD_NW + col];
-    red[part][threadIdx.x & 31] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < LOD_NW) {
+        int b = part;
+        for (; b + LOD_RED_PARTS < nblocks; b += 2 * LOD_RED_PARTS) { // two independent chains
+            s0 += partials[(size_t)b * LOD_NW + col];
+            s1 += partials[(size_t)(b + LOD_RED_PARTS) * LOD_NW + col];
+        }
+        if (b < nblocks) s0 += partials[(size_t)b * LOD_NW + col];
+    }
+    red[part][threadIdx.x & 31] = s0 + s1;
     __syncthreads();
     if (threadIdx.x < 32 && col < LOD_NW) {
         float t = 0.f;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) t += red[p][threadIdx.x];
+        for (int p = 0; p < LOD_RED_PARTS; ++p) t += red[p][threadIdx.x];
         v_w[col] = t;
     }
 }
@@ -450,6 +457,6 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
                        (float*)workspace);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(256), 0, stream, (const float*)workspace, nb, v_mlp);
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, v_mlp);
     ADK_RETURN_LAST_ERROR();
 }

@@ -132,6 +132,25 @@ __global__ __launch_bounds__(256) void make_isect_ids_kernel(const uint32_t* __r
     isect_ids[i] = ((int64_t)tile_sorted[i] << 32) | (int64_t)depth_keys[flatten_ids[i]];
 }
 
+// Total number of (Gaussian, tile) intersections.  It only depends on the projection, so the host can
+// fetch it while the depth sort is still running instead of stalling the stream after it.
+__global__ __launch_bounds__(256) void count_isects_kernel(const int32_t* __restrict__ tiles_per_gauss, int N,
+                                                           unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long red[4];
+    unsigned long long s = 0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) s += (unsigned)tiles_per_gauss[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { // one same-address atomic per workgroup, <= 256 in total
+        const unsigned long long t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (t) atomicAdd(total, t);
+    }
+}
+
 } // namespace adk
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -173,6 +192,21 @@ extern "C" int adk_bin_depth_order(int N, const uint32_t* depth_keys, const uint
 }
 
 // ---- stage 2: emit in depth order, stable sort by tile, per-tile offsets -----------------------------
+// *n_isects (int64, device) = sum(tiles_per_gauss).  Same value adk_bin_depth_order reports, available
+// one sort earlier (integer sum: order-independent).
+extern "C" int adk_bin_count_isects(int N, const int32_t* tiles_per_gauss, int64_t* n_isects, hipStream_t stream)
+{
+    if (N < 0 || !n_isects) return ADK_EINVAL;
+    hipError_t e = hipMemsetAsync(n_isects, 0, sizeof(int64_t), stream);
+    if (e != hipSuccess) return (int)e;
+    if (N == 0) return 0;
+    if (!tiles_per_gauss) return ADK_EINVAL;
+    int nb = (int)adk::ceil_div(N, 2048);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(adk::count_isects_kernel, dim3(nb), dim3(256), 0, stream, tiles_per_gauss, N, (unsigned long long*)n_isects);
+    ADK_RETURN_LAST_ERROR();
+}
+
 extern "C" int64_t adk_bin_tiles_workspace_bytes(int64_t n_isects)
 {
     if (n_isects < 0) return ADK_EINVAL;

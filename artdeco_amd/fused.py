@@ -56,6 +56,7 @@ class FusedLodParams(torch.autograd.Function):
                                             W2.data_ptr(), b2.data_ptr(), viewmat.data_ptr(), opac.data_ptr(),
                                             scale.data_ptr(), quat.data_ptr(), sel.data_ptr(), _lib.stream_of(xyz))
         _lib.check(rc, "adk_lod_params_fwd")
+        ctx.set_materialize_grads(False)
         ctx.dims = (L, G, Hd)
         ctx.save_for_backward(xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, W1, b1, W2, b2, cls_id, d_max, viewmat)
         ctx.mark_non_differentiable(sel)
@@ -292,11 +293,14 @@ class PoseRt(torch.autograd.Function):
             Rt = torch.empty(4, 4, dtype=torch.float32, device=r6c.device)
             rc = lib.adk_pose6d_fwd(r6c.data_ptr(), tc.data_ptr(), Rt.data_ptr(), _lib.stream_of(r6c))
         _lib.check(rc, "adk_pose6d_fwd")
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(r6c)
         return Rt
 
     @staticmethod
     def backward(ctx, v_Rt):
+        if v_Rt is None:
+            return None, None
         lib = _lib.load()
         (r6c,) = ctx.saved_tensors
         with torch.cuda.device(r6c.device):
@@ -349,6 +353,7 @@ class FusedMapperLoss(torch.autograd.Function):
             with _stage("photometric_loss"):
                 rc = lib.adk_photometric_loss(W, H, ssim_map.data_ptr(), lam, wd, ws.data_ptr(), ws.numel(), parts.data_ptr(), st)
             _lib.check(rc, "adk_photometric_loss")
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors4, alphas, E, bg, gt, mono, rdk, image, gt_used, dm)
         ctx.cfg = (H, W, lam, wd, mo, tuple(exposure.shape))
         loss = parts[0].clone()
@@ -357,6 +362,8 @@ class FusedMapperLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_loss, *_unused):
+        if v_loss is None:
+            return (None,) * 10
         lib = _lib.load()
         colors4, alphas, E, bg, gt, mono, rdk, image, gt_used, dm = ctx.saved_tensors
         H, W, lam, wd, mo, e_shape = ctx.cfg

@@ -4,8 +4,9 @@ Mirrors what gsplat.rendering.rasterization does for ARTDECO's call
 (Reconstruct/scene/scene_models/h3dgsv3.py:664-680) but as ONE torch.autograd.Function per
 camera instead of upstream's chain (projection -> SH -> isect -> rasterize): the intermediate
 per-Gaussian tensors live in one packed 48 B record that both the tile kernels and the
-backward consume, and the only host synchronisation is the single read of n_isects that sizes
-the intersection list (upstream has the same one).
+backward consume, and the only host wait is for n_isects (it sizes the intersection list; upstream
+drains the stream for it) -- here it is counted right after the projection and fetched through
+pinned memory while the depth sort runs, so the stream stays busy.
 """
 from __future__ import annotations
 
@@ -25,11 +26,15 @@ class StageTimer:
     (torch's current stream).  bench.py installs one with set_stage_timer() for the timed region;
     when none is installed the stages run without any event overhead."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events: dict[str, list] = {}
+        self.only = None if only is None else frozenset(only)
 
     @contextlib.contextmanager
     def stage(self, name: str):
+        if self.only is not None and name not in self.only:
+            yield
+            return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         try:
@@ -100,6 +105,18 @@ class _Workspace:
 
 
 _WS = _Workspace()
+_TLS = threading.local()
+
+
+def _count_slot(device: torch.device):
+    """Per-thread, per-device pinned int64 + event for the asynchronous read of n_isects."""
+    slots = getattr(_TLS, "slots", None)
+    if slots is None:
+        slots = _TLS.slots = {}
+    slot = slots.get(device.index)
+    if slot is None:
+        slot = slots[device.index] = (torch.empty(1, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+    return slot
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -142,17 +159,27 @@ class RasterizeGaussians(torch.autograd.Function):
                                      tiles_per_gauss.data_ptr(), stream)
             _lib.check(rc, "adk_project_fwd")
 
+            # The list size only depends on the projection: count it now, start its copy to pinned host memory,
+            # and read it AFTER the depth sort has been enqueued -- the host waits for the count (an event), not
+            # for the sort, so the stream never drains (upstream syncs on n_isects after isect_tiles).
+            n_isects_dev = torch.empty(2, dtype=torch.int64, device=dev)
+            rc = lib.adk_bin_count_isects(N, tiles_per_gauss.data_ptr(), n_isects_dev.data_ptr(), stream)
+            _lib.check(rc, "adk_bin_count_isects")
+            host_count, count_ready = _count_slot(dev)
+            host_count.copy_(n_isects_dev[:1], non_blocking=True)
+            count_ready.record()
+
             sorted_ids = torch.empty(N, **i32)
             block_offs = torch.empty((N + 255) // 256 + 1, **i32)
-            n_isects_dev = torch.empty(1, dtype=torch.int64, device=dev)
             ws_bytes = lib.adk_bin_depth_workspace_bytes(N)
             ws = _WS.get(dev, ws_bytes)
             with _stage("bin_depth_order"):
               rc = lib.adk_bin_depth_order(N, depth_keys.data_ptr(), gauss_ids.data_ptr(), tiles_per_gauss.data_ptr(),
-                                         sorted_ids.data_ptr(), block_offs.data_ptr(), n_isects_dev.data_ptr(),
+                                         sorted_ids.data_ptr(), block_offs.data_ptr(), n_isects_dev[1:].data_ptr(),
                                          ws.data_ptr(), ws.numel(), stream)
             _lib.check(rc, "adk_bin_depth_order")
-            n_isects = int(n_isects_dev.item())  # the one host sync of the pipeline (sizes the list)
+            count_ready.synchronize()  # the one host wait of the pipeline (sizes the list)
+            n_isects = int(host_count[0])
             LAST_STATS.update(N=N, I=n_isects, width=W, height=H)
 
             flatten_ids = torch.empty(n_isects, **i32)
@@ -183,6 +210,7 @@ class RasterizeGaussians(torch.autograd.Function):
                                                 depth_keys.data_ptr(), isect_ids.data_ptr(), stream)
                 _lib.check(rc, "adk_bin_make_isect_ids")
 
+        ctx.set_materialize_grads(False)  # no zero tensors for the eight non-differentiable by-products
         ctx.cfg = cfg
         ctx.n_isects = n_isects
         ctx.has_bg = bg is not None

@@ -131,6 +131,11 @@ int adk_project_bwd(int N, const float* means, const float* quats, const float* 
                     float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad,
                     float* v_viewmat, adk_stream_t stream);
 
+/* *n_isects (int64, device) = sum(tiles_per_gauss): the size of the intersection list, known right after
+ * the projection.  Lets the host read it (pinned copy + event) while adk_bin_depth_order is still running,
+ * instead of the stream-draining read gsplat does after isect_tiles (rendering.py, `isect_tiles` -> n_isects). */
+int adk_bin_count_isects(int N, const int32_t* tiles_per_gauss, int64_t* n_isects, adk_stream_t stream);
+
 /* Replaces isect_tiles + radix sort + isect_offset_encode, in two calls around the single
  * point where the caller needs a size (n_isects).  Output order is bit-identical to a stable
  * sort of upstream's 64-bit (tile<<32 | depth bits) keys. */
