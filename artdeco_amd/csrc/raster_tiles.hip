@@ -7,11 +7,11 @@
 // T(1-alpha) <= 1e-4, last contributing index, back-to-front gradient recurrences).
 //
 // Wave64 design (not a port of the 32-lane warp tiling):
-//   * a workgroup = one 16x16 tile = 4 wavefronts; each wavefront owns an 8x8 pixel QUADRANT
-//     (lane -> (lane&7, lane>>3)), the squarest footprint 64 lanes can have, so a splat that
-//     misses a quadrant is skipped by that whole wave;
-//   * splats are staged 256 at a time in LDS as packed 48 B records (three ds_read_b128 per
-//     splat per wave, wave-uniform address => broadcast reads, no bank conflicts);
+//   * a workgroup = ONE wavefront = one 16x16 tile; lane l owns pixel l (8x8 raster order,
+//     lane -> (lane&7, lane>>3)) of each of the four 8x8 QUADRANTS, the squarest footprint 64
+//     lanes can have, so a splat that misses a quadrant costs that quadrant nothing;
+//   * splats are staged 64 at a time in LDS as packed 48 B records (three ds_read_b128 per
+//     splat, wave-uniform address => broadcast reads, no bank conflicts);
 //   * SPLAT-PARALLEL CULLING: before walking a group of 64 staged splats, each LANE tests ONE
 //     splat's screen-space box against the wave's quadrant; __ballot gives a 64-bit mask in
 //     SGPRs and the wave then walks only the set bits (s_ff1 / s_flbit), in order.  64 cull
@@ -31,27 +31,6 @@ namespace adk {
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
-
-struct TileCtx {
-    int tile, tx, ty;
-    int px, py;      // this lane's pixel
-    float qx0, qx1, qy0, qy1; // pixel-centre extent of this wave's quadrant
-    bool inside;
-};
-
-__device__ __forceinline__ TileCtx make_ctx(int tile_w, int n_tiles, int W, int H) {
-    TileCtx c;
-    c.tile = xcd_remap(blockIdx.x, n_tiles);
-    c.tx = c.tile % tile_w; c.ty = c.tile / tile_w;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qx = (wv & 1) * 8, qy = (wv >> 1) * 8;
-    c.px = c.tx * TILE + qx + (lane & 7);
-    c.py = c.ty * TILE + qy + (lane >> 3);
-    c.qx0 = (float)(c.tx * TILE + qx) + 0.5f; c.qx1 = c.qx0 + 7.0f;
-    c.qy0 = (float)(c.ty * TILE + qy) + 0.5f; c.qy1 = c.qy0 + 7.0f;
-    c.inside = (c.px < W) && (c.py < H);
-    return c;
-}
 
 // Exact, conservative test "can this splat reach alpha >= 1/255 at any pixel centre of the rectangle
 // [x0,x1] x [y0,y1]?"  alpha = o*exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o); sigma is a positive-
@@ -87,94 +66,129 @@ __device__ __forceinline__ bool splat_reaches_rect(float mx, float my, float a, 
 }
 
 // ---------------------------------------------------------------------------------- forward
+// One wavefront per 16x16 tile; lane l owns pixel l (8x8 raster order) of EACH of the four 8x8 quadrants,
+// exactly like the backward below.  Against the earlier 4-waves-per-tile version this removes every
+// workgroup barrier (single-wave __syncthreads is a free s_barrier), shares the scalar work of walking
+// the hit mask and the three LDS broadcast reads of a splat between the quadrants it touches, and lets a
+// finished quadrant drop out (its hit masks are no longer computed) while the rest of the tile goes on.
+// The next group of 64 records is fetched from global memory while the current one is composited.
+struct PixFwd {
+    float T, o0, o1, o2, o3;
+    int cur_idx;
+    float best_vis; int best_idx; // MAIN_ID only
+};
+
 template <bool MAIN_ID>
-__global__ __launch_bounds__(256) void raster_fwd_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void raster_fwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids,
     int32_t* __restrict__ main_ids)
 {
-    __shared__ float4 srec[BATCH][3];
+    __shared__ float4 srec[64][3];
     const int n_tiles = tile_w * tile_h;
-    const TileCtx c = make_ctx(tile_w, n_tiles, W, H);
-    const int lane = threadIdx.x & 63;
-    const float fx = (float)c.px + 0.5f, fy = (float)c.py + 0.5f;
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int tx = tile % tile_w, ty = tile / tile_w;
+    const int lane = threadIdx.x;
 
-    const int range_start = offsets[c.tile];
-    const int range_end = (c.tile == n_tiles - 1) ? n_isects : offsets[c.tile + 1];
-    const int num_batches = (range_end - range_start + BATCH - 1) / BATCH;
+    const int range_start = offsets[tile];
+    const int range_end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
 
-    bool done = !c.inside;
-    float T = 1.0f;
-    int cur_idx = 0;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    float best_vis = 0.f;   // MAIN_ID: largest alpha*T seen and the list index that produced it
-    int best_idx = -1;
+    PixFwd px[4];
+    float qx0[4], qy0[4];
+    bool inside[4];
+    unsigned live = 0u; // quadrants that still have an unfinished pixel (wave-uniform)
+    unsigned done = 0u; // per lane: bit q = this lane's pixel of quadrant q is finished
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ox = tx * TILE + (q & 1) * 8, oy = ty * TILE + (q >> 1) * 8;
+        qx0[q] = (float)ox + 0.5f; qy0[q] = (float)oy + 0.5f;
+        const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
+        PixFwd& P = px[q];
+        P.T = 1.f; P.o0 = P.o1 = P.o2 = P.o3 = 0.f; P.cur_idx = 0; P.best_vis = 0.f; P.best_idx = -1;
+        inside[q] = (pxi < W) && (pyi < H);
+        if (!inside[q]) done |= 1u << q;
+        if (__ballot(inside[q]) != 0ull) live |= 1u << q;
+    }
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
+    // pixel centre in quadrant 0; quadrant q adds (8 (q&1), 8 (q>>1)).  Register budget: 64 VGPRs, so that all
+    // tiles of a 1080p frame (8160) are resident at once (8 waves/SIMD x 1024 SIMDs) and there is no second,
+    // half-empty scheduling round.
+    const float fx0 = (float)(tx * TILE + (lane & 7)) + 0.5f, fy0 = (float)(ty * TILE + (lane >> 3)) + 0.5f;
 
-    for (int b = 0; b < num_batches; ++b) {
-        if (__syncthreads_and(done)) break;
-        const int batch_start = range_start + BATCH * b;
-        const int idx = batch_start + (int)threadIdx.x;
-        if (idx < range_end) {
-            const int64_t g = flatten_ids[idx];
-            srec[threadIdx.x][0] = rec4[3 * g];
-            srec[threadIdx.x][1] = rec4[3 * g + 1];
-            srec[threadIdx.x][2] = rec4[3 * g + 2];
+    for (int batch_start = range_start; batch_start < range_end && live; batch_start += 64) {
+        const int batch_size = min(64, range_end - batch_start);
+        const bool have = lane < batch_size;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        __syncthreads();
+        if (have) {
+            const int64_t g = flatten_ids[batch_start + lane];
+            r0 = rec4[3 * g]; r1 = rec4[3 * g + 1];
+            srec[lane][0] = r0; srec[lane][1] = r1; srec[lane][2] = rec4[3 * g + 2];
         }
         __syncthreads();
-        const int batch_size = min(BATCH, range_end - batch_start);
-        if (__ballot(!done) == 0ull) continue; // this wave's quadrant is finished; keep serving loads
-        for (int sub = 0; sub < batch_size; sub += 64) {
-            const int s = sub + lane;
-            bool hit = false;
-            if (s < batch_size) {
-                const float4 a = srec[s][0];
-                const float4 cn = srec[s][1];
-                hit = (a.x + a.w >= c.qx0) && (a.x - a.w <= c.qx1) && (a.y + cn.w >= c.qy0) && (a.y - cn.w <= c.qy1) &&
-                      splat_reaches_rect(a.x, a.y, cn.x, cn.y, cn.z, a.z, c.qx0, c.qx1, c.qy0, c.qy1);
+        // splat-parallel culling: this lane's splat against each live quadrant
+        unsigned long long mq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mq[q] = 0ull;
+            if ((live >> q) & 1u) {
+                const float x0 = qx0[q], x1 = x0 + 7.0f, y0 = qy0[q], y1 = y0 + 7.0f;
+                const bool hit = have && (r0.x + r0.w >= x0) && (r0.x - r0.w <= x1) && (r0.y + r1.w >= y0) && (r0.y - r1.w <= y1) &&
+                                 splat_reaches_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, x0, x1, y0, y1);
+                mq[q] = __ballot(hit);
             }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int t = sub + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                bool newly_done = false;
-                if (!done) {
-                    const float4 a = srec[t][0];
-                    const float4 cn = srec[t][1];
-                    const float dx = a.x - fx, dy = a.y - fy;
+        }
+        unsigned long long any = (mq[0] | mq[1]) | (mq[2] | mq[3]);
+        while (any) {
+            const int t = __builtin_ctzll(any);
+            const unsigned long long bit = 1ull << t;
+            any &= any - 1;
+            const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
+            const int idx = batch_start + t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mq[q] & bit) { // wave-uniform
+                    PixFwd& P = px[q];
+                    const float dx = a.x - (fx0 + (float)((q & 1) * 8)), dy = a.y - (fy0 + (float)((q >> 1) * 8));
                     const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
                     const float alpha = fminf(MAX_ALPHA, a.z * __expf(-sigma));
-                    if (!(sigma < 0.f || alpha < ALPHA_THR)) {
-                        const float next_T = T * (1.0f - alpha);
-                        if (next_T <= T_EPS) {
-                            done = true;
-                            newly_done = true;
-                        } else {
-                            const float4 col = srec[t][2];
-                            const float vis = alpha * T;
-                            o0 += col.x * vis; o1 += col.y * vis; o2 += col.z * vis; o3 += col.w * vis;
-                            cur_idx = batch_start + t;
-                            if (MAIN_ID && vis > best_vis) { best_vis = vis; best_idx = cur_idx; }
-                            T = next_T;
-                        }
+                    const bool valid = !((done >> q) & 1u) && !(sigma < 0.f || alpha < ALPHA_THR);
+                    const float next_T = P.T * (1.0f - alpha);
+                    const bool term = valid && (next_T <= T_EPS); // terminate BEFORE adding this splat
+                    const bool contrib = valid && !term;
+                    const float vis = contrib ? alpha * P.T : 0.f;
+                    P.o0 += col.x * vis; P.o1 += col.y * vis; P.o2 += col.z * vis; P.o3 += col.w * vis;
+                    P.cur_idx = contrib ? idx : P.cur_idx;
+                    if (MAIN_ID && vis > P.best_vis) { P.best_vis = vis; P.best_idx = idx; }
+                    P.T = contrib ? next_T : P.T;
+                    done |= term ? (1u << q) : 0u;
+                    // the quadrant-finished test is only evaluated when some pixel just finished
+                    if (__ballot(term) != 0ull && __ballot(!((done >> q) & 1u)) == 0ull) {
+                        live &= ~(1u << q);
+                        mq[q] = 0ull;
+                        any = ((mq[0] | mq[1]) | (mq[2] | mq[3])) & ~((bit << 1) - 1ull);
                     }
                 }
-                // the whole-quadrant-finished test is only re-evaluated when some pixel just finished
-                if (__ballot(newly_done) != 0ull && __ballot(!done) == 0ull) { mask = 0; sub = batch_size; }
             }
         }
     }
 
-    if (c.inside) {
-        const int64_t pix = (int64_t)c.py * W + c.px;
-        render_alphas[pix] = 1.0f - T;
-        if (backgrounds) {
-            o0 += T * backgrounds[0]; o1 += T * backgrounds[1]; o2 += T * backgrounds[2]; o3 += T * backgrounds[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (inside[q]) {
+            PixFwd& P = px[q];
+            const int pxi = tx * TILE + (q & 1) * 8 + (lane & 7), pyi = ty * TILE + (q >> 1) * 8 + (lane >> 3);
+            const int64_t pix = (int64_t)pyi * W + pxi;
+            render_alphas[pix] = 1.0f - P.T;
+            float o0 = P.o0, o1 = P.o1, o2 = P.o2, o3 = P.o3;
+            if (backgrounds) {
+                o0 += P.T * backgrounds[0]; o1 += P.T * backgrounds[1]; o2 += P.T * backgrounds[2]; o3 += P.T * backgrounds[3];
+            }
+            reinterpret_cast<float4*>(render_colors)[pix] = make_float4(o0, o1, o2, o3);
+            last_ids[pix] = P.cur_idx;
+            if (MAIN_ID) main_ids[pix] = P.best_idx >= 0 ? flatten_ids[P.best_idx] : -1;
         }
-        reinterpret_cast<float4*>(render_colors)[pix] = make_float4(o0, o1, o2, o3);
-        last_ids[pix] = cur_idx;
-        if (MAIN_ID) main_ids[pix] = best_idx >= 0 ? flatten_ids[best_idx] : -1;
     }
 }
 
@@ -340,10 +354,10 @@ extern "C" int adk_raster_fwd(int width, int height, const float* rec, const int
     if (((uintptr_t)rec & 15) || ((uintptr_t)render_colors & 15)) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
     if (main_ids)
-        hipLaunchKernelGGL(adk::raster_fwd_kernel<true>, dim3(tile_w * tile_h), dim3(256), 0, stream, tile_w, tile_h, width, height,
+        hipLaunchKernelGGL(adk::raster_fwd_kernel<true>, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
                            rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids, main_ids);
     else
-        hipLaunchKernelGGL(adk::raster_fwd_kernel<false>, dim3(tile_w * tile_h), dim3(256), 0, stream, tile_w, tile_h, width, height,
+        hipLaunchKernelGGL(adk::raster_fwd_kernel<false>, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
                            rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids, nullptr);
     ADK_RETURN_LAST_ERROR();
 }
