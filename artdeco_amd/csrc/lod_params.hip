@@ -167,8 +167,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation, float* __restrict__ v_local_feat,
     float* __restrict__ v_global_feat /* [V,G], zeroed, atomics */, float* __restrict__ partials /* [gridDim.x][LOD_NW] */)
 {
-    __shared__ float TX[64 * LOD_LDW], TH[64 * LOD_LDW], TZ[64 * LOD_LDW], TY[64 * LOD_YW];
+    // Two 64x33 tiles + a 64x9 one = 19.5 KB per wavefront => 8 single-wave workgroups per CU (2 per SIMD, which is
+    // also what the 256-VGPR budget allows).  TH holds H, later VZ: H is dead once dW2 has been accumulated, and
+    // the stage order below is chosen so that this alias is legal.
+    __shared__ float TX[64 * LOD_LDW], TH[64 * LOD_LDW], TY[64 * LOD_YW];
     __shared__ int TC[64];
+    float* const TZ = TH;
     const int lane = threadIdx.x, kk = lane >> 5, rc = lane & 31;
 
     // weight fragments (B operands), resident for the whole kernel
@@ -311,24 +315,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             TY[lane * LOD_YW + 7] = 0.f;
         }
         lds_fence();
-        // ---- VZ = (VY W2) * (H > 0)
+        // ---- dW2 += VY^T H (K = the 64 Gaussians of the chunk); last use of H
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const float a = rc < 8 ? TY[(2 * s + kk) * LOD_YW + rc] : 0.f;
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TH[(2 * s + kk) * LOD_LDW + rc], acc2, 0, 0, 0);
+            bs2 += a;
+        }
+        // ---- VZ = (VY W2) * (H > 0), written over H
+        f32x16 dz[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            f32x16 d;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            for (int r = 0; r < 16; ++r) dz[rb][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TY[(rb * 32 + rc) * LOD_YW + 2 * s + kk], w2n[s], d, 0, 0, 0);
+                dz[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(TY[(rb * 32 + rc) * LOD_YW + 2 * s + kk], w2n[s], dz[rb], 0, 0, 0);
+        }
+        lds_fence(); // every read of H (dW2) has completed
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                TZ[row * LOD_LDW + rc] = ((hmask[rb] >> r) & 1u) ? d[r] : 0.f;
+                TZ[row * LOD_LDW + rc] = ((hmask[rb] >> r) & 1u) ? dz[rb][r] : 0.f;
             }
         }
         lds_fence();
-        // ---- VX = VZ W1: columns 16..31 are the local-feature gradients (plain stores, every row),
-        //      columns 0..15 scatter into the voxel's global feature (hardware fp32 atomics)
+        // ---- dW1 += VZ^T X; last use of X
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const float a = TZ[(2 * s + kk) * LOD_LDW + rc];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TX[(2 * s + kk) * LOD_LDW + rc], acc1, 0, 0, 0);
+            bs1 += a;
+        }
+        // ---- VX = VZ W1, stored straight from the accumulator layout (lane = feature column, register = Gaussian
+        //      row): each store/atomic instruction then covers whole 64 B lines (16 consecutive floats of one
+        //      Gaussian per half-wave).  Measured: re-laying VX out one Gaussian per lane (16 B per lane, 64 lines
+        //      per instruction) is 3x slower.  Columns 16..31 = local-feature gradients (plain stores, every row),
+        //      columns 0..15 scatter into the voxel's global feature (hardware fp32 atomics).
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             f32x16 d;
@@ -337,30 +362,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int s = 0; s < 16; ++s)
                 d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w1n[s], d, 0, 0, 0);
+            if (rc >= LOD_G) {
+                // one base address per lane, compile-time row offsets (immediate-offset stores)
+                float* lbase = v_local_feat + ((int64_t)chunk * 64 + 4 * kk) * LOD_L + (rc - LOD_G);
+                if ((int64_t)chunk * 64 + 64 <= N) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                const int64_t gg = (int64_t)chunk * 64 + row;
-                if (rc >= LOD_G) {
-                    if (gg < N) v_local_feat[gg * LOD_L + (rc - LOD_G)] = d[r];
+                    for (int r = 0; r < 16; ++r) lbase[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LOD_L] = d[r];
                 } else {
-                    const int c = TC[row];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row0 = rb * 32 + (r & 3) + 8 * (r >> 2);
+                        if ((int64_t)chunk * 64 + row0 + 4 * kk < N) lbase[row0 * LOD_L] = d[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = TC[rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk];
                     if (c >= 0 && d[r] != 0.f) unsafeAtomicAdd(v_global_feat + (int64_t)c * LOD_G + rc, d[r]);
                 }
             }
-        }
-        // ---- weight gradients: dW1 += VZ^T X, dW2 += VY^T H (K = the 64 Gaussians of the chunk)
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const float a = TZ[(2 * s + kk) * LOD_LDW + rc];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TX[(2 * s + kk) * LOD_LDW + rc], acc1, 0, 0, 0);
-            bs1 += a;
-        }
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const float a = rc < 8 ? TY[(2 * s + kk) * LOD_YW + rc] : 0.f;
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TH[(2 * s + kk) * LOD_LDW + rc], acc2, 0, 0, 0);
-            bs2 += a;
         }
         lds_fence(); // tiles are rewritten by the next chunk
     }
@@ -423,7 +444,7 @@ extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_
     ADK_RETURN_LAST_ERROR();
 }
 
-#define LOD_BWD_MAX_BLOCKS 1280 // 5 resident single-wave workgroups (27.9 KB LDS each) per CU x 256 CUs
+#define LOD_BWD_MAX_BLOCKS 2048 // 8 resident single-wave workgroups (19.2 KB LDS each) per CU x 256 CUs
 extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)
 {
     if (N < 0) return ADK_EINVAL;
