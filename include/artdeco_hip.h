@@ -292,6 +292,37 @@ int adk_pose6d_bwd(const float* r6, const float* v_Rt, float* v_r6, float* v_t, 
 int adk_visibility_masks(int N, const int* radii, const int64_t* cls_id, int64_t V, uint8_t* vis,
                          uint8_t* gvis, adk_stream_t stream);
 
+/* ------------------------------------------------------------ torch_scatter
+ * Replaces torch_scatter.scatter_max / scatter_min (1-D) [UPSTREAM pytorch_scatter, not vendored]:
+ * module-level import at Reconstruct/scene/scene_models/h3dgsv3.py:35, call :289 (update_voxel).
+ * out[j] = max (min) of src[i] over index[i] == j, arg[j] = FIRST such i; empty groups: out = 0,
+ * arg = n.  dtype 0 = float32, 1 = int32, 2 = int64 (src and out); index int64; arg int64. */
+int adk_scatter_argmax(int64_t n, const void* src, int dtype, const int64_t* index, int64_t dim_size,
+                       int is_min, void* out, int64_t* arg, adk_stream_t stream);
+
+/* ------------------------------------------- mast3r_slam_backends: Gauss-Newton
+ * Replaces gauss_newton_points / gauss_newton_rays / gauss_newton_calib --
+ * VSLAM/backend/src/gn.cpp:3-82, gn_kernels.cu:455-811 / :813-1215 / :1218-1637; callers
+ * VSLAM/mast3r_slam/global_opt.py:158-173 and :208-228.
+ * kind 0 = points (sigma_a = sigma_point), 1 = rays (sigma_a = sigma_ray, sigma_b = sigma_dist),
+ * 2 = calib (sigma_a = sigma_pixel, sigma_b = sigma_depth, K [3,3] row-major, height, width,
+ * pixel_border, z_eps).  Twc [P,8] = (t3, q xyzw, s), updated IN PLACE; Xs [P,n,3]; Cs [P,n];
+ * ii / jj [E] int64 = position of each factor's keyframes in the pose arrays (the searchsorted indices
+ * of gn_kernels.cu:163-169); idx_ii2jj [E,n] int64; valid_match [E,n] bytes; Q [E,n].  The first
+ * num_fix (= 1, as in the reference) poses are held fixed.  dx_out [P-num_fix,7] receives the last
+ * step.  Hs_dbg [4,E,7,7] / gs_dbg [2,E,7] (both or neither) receive the reference's per-factor blocks
+ * of the last executed iteration.  The whole solve (assembly, fp64 Cholesky, retraction, termination
+ * test) runs on the device; all max_iter iterations are enqueued and turn into no-ops once
+ * |dx| < delta_thresh; the call never synchronises. */
+int64_t adk_gn_workspace_bytes(int num_poses, int num_edges, int num_points);
+int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_points, float* Twc, const float* Xs,
+                     const float* Cs, const float* K, const int64_t* ii, const int64_t* jj,
+                     const int64_t* idx_ii2jj, const uint8_t* valid_match, const float* Q, int height,
+                     int width, int pixel_border, float z_eps, float sigma_a, float sigma_b, float C_thresh,
+                     float Q_thresh, int max_iter, float delta_thresh, int num_fix, float* dx_out,
+                     float* Hs_dbg, float* gs_dbg, void* workspace, int64_t workspace_bytes,
+                     adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

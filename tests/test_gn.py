@@ -1,0 +1,193 @@
+"""Sim(3) Gauss-Newton global optimiser (mast3r_slam_backends.gauss_newton_points / rays / calib).
+
+CPU: the oracle's Jacobians against finite differences of its own residuals, and recovery of known poses.
+GPU: the HIP path (through the drop-in, i.e. through the C ABI) against the oracle -- per-factor blocks, full solves --
+plus size-independent properties at the reference's full factor size (196 608 points per factor)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gn_oracle as G
+
+PRM = dict(sigma_point=0.05, sigma_ray=0.003, sigma_dist=10.0, C_thresh=0.0, Q_thresh=1.5)  # config/base.yaml:36-51
+KINDS = ("points", "rays", "calib")
+
+
+def _calib_prm(c):
+    return dict(PRM, K=c["K"], width=c["width"], height=c["height"], pixel_border=-10, z_eps=1e-6, sigma_pixel=1.0, sigma_depth=10.0)
+
+
+def _perturb(T_gt, seed, mag):
+    rng = np.random.default_rng(seed)
+    T = T_gt.copy()
+    for k in range(1, len(T)):
+        T[k] = G.retr_sim3((mag * rng.standard_normal(7)).astype(np.float32), T[k])
+    return T
+
+
+def _graph(kind, **kw):
+    if kind == "calib":
+        c = G.synthetic_calib_graph(**kw)
+        return c, _calib_prm(c)
+    return G.synthetic_graph(**kw), dict(PRM)
+
+
+# ------------------------------------------------------------------------------------------ CPU: the oracle itself
+@pytest.mark.parametrize("kind", KINDS)
+def test_oracle_jacobians_match_finite_differences(kind):
+    c = G.synthetic_calib_graph(seed=2, height=12, width=16, fx=18.0)
+    prm = dict(_calib_prm(c), K=c["K"].astype(np.float64))
+    T = _perturb(c["T_gt"], 0, 0.05).astype(np.float64)
+    e = 1
+    ie, je, idx = np.array([c["ii"][e]]), np.array([c["jj"][e]]), c["idx"][e:e + 1]
+    ix, jx = int(ie[0]), int(je[0])
+    tij, qij, sij = G.rel_sim3(T[ix, 0:3], T[ix, 3:7], T[ix, 7], T[jx, 0:3], T[jx, 3:7], T[jx, 7])
+    P = G.act_so3(qij, c["Xs"][jx].astype(np.float64)) * sij + tij
+    Xi = c["Xs"][ix][idx[0]].astype(np.float64)
+    rows = G._rows(kind, P, Xi, idx[0], np.ones(len(P), bool), np.ones(len(P)), prm)
+    Jj = np.stack([G.apply_sim3_adj_inv(T[ix, 0:3], T[ix, 3:7], T[ix, 7], J0) for J0, _, _ in rows], 1).reshape(-1, 7)
+
+    def left_mul(xi, pose):  # exp(xi) * pose to first order in the translation part (enough for a central difference)
+        th = np.linalg.norm(xi[3:6])
+        dq = np.array([0, 0, 0, 1.0]) if th < 1e-14 else np.concatenate([np.sin(th / 2) * xi[3:6] / th, [np.cos(th / 2)]])
+        ds = np.exp(xi[6])
+        out = np.empty(8)
+        out[0:3] = G.act_so3(dq, pose[None, 0:3])[0] * ds + xi[0:3]
+        out[3:7] = G.quat_comp(dq, pose[3:7])
+        out[7] = ds * pose[7]
+        return out
+
+    h = 1e-6
+    for k, sign in ((jx, 1.0), (ix, -1.0)):  # J_i = -J_j (gn_kernels.cu:606)
+        Jn = np.zeros_like(Jj)
+        for d in range(7):
+            xi = np.zeros(7)
+            xi[d] = h
+            Tp, Tm = T.copy(), T.copy()
+            Tp[k], Tm[k] = left_mul(xi, T[k]), left_mul(-xi, T[k])
+            Jn[:, d] = (G.residual_vector(kind, Tp, c["Xs"], ie, je, idx, prm) - G.residual_vector(kind, Tm, c["Xs"], ie, je, idx, prm)) / (2 * h)
+        m = np.isfinite(Jn).all(1) & np.isfinite(Jj).all(1)
+        assert m.mean() > 0.9
+        assert np.abs(sign * Jj[m] - Jn[m]).max() <= 1e-5 * max(1.0, np.abs(Jn[m]).max())
+
+
+def test_oracle_exp_sim3_identities():
+    t, q, s = G.exp_sim3(np.zeros(7, dtype=np.float32))
+    assert np.array_equal(t, np.zeros(3)) and np.array_equal(q, [0, 0, 0, 1]) and s == 1
+    rng = np.random.default_rng(0)
+    for mag in (1e-4, 0.3):  # series branch and closed-form branch: exp(xi) exp(-xi) = identity
+        xi = (mag * rng.standard_normal(7)).astype(np.float32)
+        ident = np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float32)
+        back = G.retr_sim3(-xi, G.retr_sim3(xi, ident))
+        assert np.abs(back - ident).max() < 5e-6
+
+
+@pytest.mark.parametrize("kind", ("points", "rays"))
+def test_oracle_recovers_ground_truth(kind):
+    g = G.synthetic_graph(num_poses=4, n=300, seed=1)
+    T = _perturb(g["T_gt"], 5, 0.03)
+    G.gauss_newton(kind, T, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx"], g["valid"], g["Q"], PRM, 10, 1e-8)
+    assert np.abs(T - g["T_gt"]).max() < 2e-6
+
+
+# ------------------------------------------------------------------------------------------ GPU: HIP vs oracle
+def _run_hip(kind, T, g, prm, dev, max_iter=10, delta=1e-8, debug=False):
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    import mast3r_slam_backends as B
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Twc = t(T)
+    common = (t(g["Xs"]), t(g["Cs"]))
+    graph = (t(g["ii"]), t(g["jj"]), t(g["idx"]), t(g["valid"]), t(g["Q"]))
+    if debug:
+        k = KINDS.index(kind)
+        sa, sb = {"points": (prm["sigma_point"], 1.0), "rays": (prm["sigma_ray"], prm["sigma_dist"]),
+                  "calib": (prm.get("sigma_pixel"), prm.get("sigma_depth"))}[kind]
+        out = B._gauss_newton(k, Twc, *common, t(g["K"]) if kind == "calib" else None, *graph, g.get("height", 0), g.get("width", 0),
+                              prm.get("pixel_border", 0), prm.get("z_eps", 0.0), sa, sb, prm["C_thresh"], prm["Q_thresh"], max_iter,
+                              delta, debug_blocks=True)
+    elif kind == "points":
+        out = B.gauss_newton_points(Twc, *common, *graph, prm["sigma_point"], prm["C_thresh"], prm["Q_thresh"], max_iter, delta)
+    elif kind == "rays":
+        out = B.gauss_newton_rays(Twc, *common, *graph, prm["sigma_ray"], prm["sigma_dist"], prm["C_thresh"], prm["Q_thresh"], max_iter, delta)
+    else:
+        out = B.gauss_newton_calib(Twc, *common, t(g["K"]), *graph, g["height"], g["width"], prm["pixel_border"], prm["z_eps"],
+                                   prm["sigma_pixel"], prm["sigma_depth"], prm["C_thresh"], prm["Q_thresh"], max_iter, delta)
+    return Twc.cpu().numpy(), [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_factor_blocks_match_oracle(kind, dev):
+    """The reference's intermediate (Hs [4,E,7,7], gs [2,E,7], gn_kernels.cu:713-745) at the initial poses."""
+    g, prm = _graph(kind, seed=3)
+    T0 = _perturb(g["T_gt"], 1, 0.02)
+    _, (dx, Hs, gs) = _run_hip(kind, T0.copy(), g, prm, dev, max_iter=1, debug=True)
+    uniq = np.unique(np.concatenate([g["ii"], g["jj"]]))
+    Ho, go = G.factor_blocks(kind, T0, g["Xs"], g["Cs"], np.searchsorted(uniq, g["ii"]), np.searchsorted(uniq, g["jj"]),
+                             g["idx"], g["valid"], g["Q"], prm)
+    for e in range(len(g["ii"])):
+        for b in range(4):
+            assert np.abs(Hs[b, e] - Ho[b, e]).max() <= 2e-4 * np.abs(Ho[:, e]).max(), (kind, e, b)
+        for b in range(2):
+            assert np.abs(gs[b, e] - go[b, e]).max() <= 2e-4 * max(np.abs(go[:, e]).max(), 1e-3 * np.abs(Ho[:, e]).max()), (kind, e, b)
+    dxo = G.solve_step(Ho, go, np.searchsorted(uniq, g["ii"]), np.searchsorted(uniq, g["jj"]), len(T0))
+    assert np.abs(dx - dxo).max() <= 2e-4 * max(np.abs(dxo).max(), 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_full_solve_matches_oracle(kind, dev):
+    g, prm = _graph(kind, seed=4)
+    T0 = _perturb(g["T_gt"], 2, 0.02)
+    To = T0.copy()
+    dxo = G.gauss_newton(kind, To, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx"], g["valid"], g["Q"], prm, 10, 1e-8)
+    Th, (dxh,) = _run_hip(kind, T0.copy(), g, prm, dev)
+    assert np.array_equal(Th[0], T0[0])                      # the fixed keyframe is never touched
+    assert np.abs(Th - To).max() <= 2e-5, np.abs(Th - To).max()
+    assert np.abs(dxh - dxo).max() <= 1e-5
+    assert np.abs(Th - g["T_gt"]).max() < (2e-2 if kind == "calib" else 5e-6)
+
+
+@pytest.mark.gpu
+def test_keyframe_ids_need_not_be_contiguous(dev):
+    a = G.synthetic_graph(num_poses=4, n=400, seed=6)
+    b = G.synthetic_graph(num_poses=4, n=400, seed=6, kf_ids=[3, 10, 11, 42])
+    T0 = _perturb(a["T_gt"], 3, 0.02)
+    Ta, _ = _run_hip("rays", T0.copy(), a, PRM, dev)
+    Tb, _ = _run_hip("rays", T0.copy(), b, PRM, dev)
+    assert np.array_equal(Ta, Tb)
+
+
+@pytest.mark.gpu
+def test_singular_system_leaves_poses_untouched(dev):
+    """No usable match (all Q below the threshold): A = 0, the factorisation fails, dx = 0 (gn_kernels.cu:155-158)."""
+    g = G.synthetic_graph(num_poses=3, n=256, seed=7)
+    g["Q"][:] = 1.0
+    T0 = _perturb(g["T_gt"], 4, 0.02)
+    Th, (dx,) = _run_hip("points", T0.copy(), g, PRM, dev)
+    assert np.array_equal(Th, T0) and not dx.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("points", "rays"))
+def test_full_size_graph_recovers_ground_truth(kind, dev):
+    """Reference size: 196 608 points per factor (512x384), 6 keyframes, 16 factors; exact data => exact recovery, and
+    a second call from the solution does not move (idempotence)."""
+    g = G.synthetic_graph(num_poses=6, n=512 * 384, seed=8, extra_edges=3)
+    T0 = _perturb(g["T_gt"], 5, 0.03)
+    Th, (dx,) = _run_hip(kind, T0.copy(), g, PRM, dev)
+    assert np.abs(Th - g["T_gt"]).max() < 5e-6
+    Th2, _ = _run_hip(kind, Th.copy(), g, PRM, dev)
+    assert np.abs(Th2 - Th).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_outliers_are_downweighted_by_huber(dev):
+    g = G.synthetic_graph(num_poses=4, n=4096, seed=9, outlier_frac=0.15)
+    T0 = _perturb(g["T_gt"], 6, 0.02)
+    Th, _ = _run_hip("rays", T0.copy(), g, PRM, dev)
+    To = T0.copy()
+    G.gauss_newton("rays", To, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx"], g["valid"], g["Q"], PRM, 10, 1e-8)
+    assert np.abs(Th - To).max() <= 5e-5
+    assert np.abs(Th - g["T_gt"]).max() < 0.02 and np.abs(Th - g["T_gt"]).max() < np.abs(T0 - g["T_gt"]).max()
