@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void gn_accumulate_kernel(GnArgs a)
     const float* Ci_base = a.Cs + (int64_t)ix * n;
     const float* Cj_base = a.Cs + (int64_t)jx * n;
     const int k_end = min(n, (ch + 1) * a.chunk);
+#pragma unroll 4
     for (int k = ch * a.chunk + (int)threadIdx.x; k < k_end; k += 256) {
         const int64_t ek = (int64_t)e * n + k;
         const bool vm = a.valid[ek] != 0;
@@ -464,6 +465,9 @@ extern "C" int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_
     a.sigma_a = sigma_a; a.sigma_b = sigma_b; a.C_thresh = C_thresh; a.Q_thresh = Q_thresh;
     a.partials = partials; a.done = done;
     const size_t lds = (size_t)(D + 1) * sizeof(double);
+    // 16 waves even for a small system: the matrix lives in global memory (L2) and the trailing update is
+    // latency-bound -- measured at D = 105: 0.26 ms with 1024 threads, 1.2 ms with a single wavefront.
+    const int solve_threads = GN_SOLVE_THREADS;
     (void)hipFuncSetAttribute((const void*)adk::gn_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int it = 0; it < max_iter; ++it) {
         if (num_edges > 0) {
@@ -472,7 +476,7 @@ extern "C" int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_
             else if (kind == 1) hipLaunchKernelGGL(adk::gn_accumulate_kernel<1>, grid, dim3(256), 0, stream, a);
             else hipLaunchKernelGGL(adk::gn_accumulate_kernel<2>, grid, dim3(256), 0, stream, a);
         }
-        hipLaunchKernelGGL(adk::gn_solve_kernel, dim3(1), dim3(GN_SOLVE_THREADS), lds, stream, Twc, num_poses, num_fix, ii, jj,
+        hipLaunchKernelGGL(adk::gn_solve_kernel, dim3(1), dim3(solve_threads), lds, stream, Twc, num_poses, num_fix, ii, jj,
                            num_edges, chunks, (const float*)partials, A, dx_out, delta_thresh, done, Hs_dbg, gs_dbg);
     }
     ADK_RETURN_LAST_ERROR();

@@ -271,17 +271,22 @@ def _edges(rng, num_poses, extra_edges):
     return ii, jj
 
 
-def synthetic_graph(num_poses=5, n=768, seed=0, extra_edges=3, noise=0.0, outlier_frac=0.0, kf_ids=None):
+def synthetic_graph(num_poses=5, n=768, seed=0, extra_edges=3, noise=0.0, outlier_frac=0.0, kf_ids=None, coherent=False):
     """EXACTLY consistent graph for the points / rays factors: n world points, keyframe p stores T_p^-1 W in a private
     random slot order, a match pairs the two slots of the same world point.  With noise = 0 the ground-truth poses
     `T_gt` give zero residual on every valid match.  10 % of the matches get Q below the threshold and 10 % are
-    flagged invalid (with garbage indices) -- both must be ignored.  kf_ids: optional non-contiguous keyframe ids."""
+    flagged invalid (with garbage indices) -- both must be ignored.  kf_ids: optional non-contiguous keyframe ids.
+    coherent: slot orders are circular shifts instead of random permutations, so neighbouring points match neighbouring
+    points as dense pixel matches do (the random order is the worst case for the gathers)."""
     rng = np.random.default_rng(seed)
     T_gt = random_sim3(rng, num_poses, 0.3, 0.15, 0.08)
     T_gt[0] = np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float32)
     W = np.concatenate([rng.uniform(-1.5, 1.5, (n, 2)), rng.uniform(2.0, 5.0, (n, 1))], 1)
     Tg = T_gt.astype(np.float64)
-    perm = [rng.permutation(n) for _ in range(num_poses)]      # slot of world point m in keyframe p
+    if coherent:
+        perm = [np.roll(np.arange(n), int(rng.integers(0, n))) for _ in range(num_poses)]
+    else:
+        perm = [rng.permutation(n) for _ in range(num_poses)]  # slot of world point m in keyframe p
     Xs = np.zeros((num_poses, n, 3), dtype=np.float32)
     for p in range(num_poses):
         t, q, s = Tg[p, 0:3], Tg[p, 3:7], Tg[p, 7]
