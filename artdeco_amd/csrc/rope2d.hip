@@ -53,16 +53,20 @@ template <> struct Vec4<__hip_bfloat16> {
     }
 };
 
-// VEC path: D % 16 == 0.  One thread = (token, half X, group of 4 pair indices).
+// VEC path: D % 16 == 0.  One thread = (token, slice of heads, half X, group of 4 pair indices).  The heads are
+// split over `hsplit` threads so that small inputs (MASt3R: 768 tokens x 16 heads) still fill the chip: with one
+// thread per (token, group) the launch had 24 workgroups and took 14.8 us; split over the heads it is bandwidth-bound.
 template <typename T>
 __global__ __launch_bounds__(256) void rope2d_vec_kernel(T* __restrict__ tokens, const int64_t* __restrict__ pos,
-                                                         int64_t n_tokens, int N, int64_t stride_b, int64_t stride_n, int H, int D, float base, float fwd)
+                                                         int64_t n_tokens, int N, int64_t stride_b, int64_t stride_n, int H, int D, float base, float fwd,
+                                                         int hsplit)
 {
     const int Q = D >> 2, groups = Q >> 2, per_token = 2 * groups;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= n_tokens * per_token) return;
-    const int64_t tok = tid / per_token;
-    const int r = (int)(tid - tok * per_token);
+    if (tid >= n_tokens * per_token * hsplit) return;
+    const int64_t tok = tid / (per_token * hsplit);
+    const int rr = (int)(tid - tok * (per_token * hsplit));
+    const int hs = rr / per_token, r = rr - hs * per_token;
     const int X = r / groups, m0 = (r - X * groups) * 4;
     const float p = (float)pos[tok * 2 + X];
     float c[4], s[4];
@@ -72,8 +76,9 @@ __global__ __launch_bounds__(256) void rope2d_vec_kernel(T* __restrict__ tokens,
         const float f = p * inv_freq;
         c[j] = cosf(f); s[j] = sinf(f);
     }
-    T* tp = tokens + (tok / N) * stride_b + (tok % N) * stride_n + X * (D >> 1) + m0;
-    for (int h = 0; h < H; ++h, tp += D) {
+    const int hper = (H + hsplit - 1) / hsplit, h0 = hs * hper, h1 = min(H, h0 + hper);
+    T* tp = tokens + (tok / N) * stride_b + (tok % N) * stride_n + (int64_t)h0 * D + X * (D >> 1) + m0;
+    for (int h = h0; h < h1; ++h, tp += D) {
         Vec4<T> u, v, ou, ov;
         u.load(tp); v.load(tp + Q);
 #pragma unroll
@@ -118,8 +123,12 @@ static int launch_rope(T* tokens, const int64_t* pos, int64_t n_tokens, int N, i
     const int epv = 4; // elements per 4-wide access
     const bool vec = (D % 16 == 0) && (((uintptr_t)tokens & (4 * sizeof(T) - 1)) == 0) && (stride_b % epv == 0) && (stride_n % epv == 0);
     if (vec) {
-        const int64_t work = n_tokens * 2 * (D / 16);
-        hipLaunchKernelGGL((rope2d_vec_kernel<T>), dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, tokens, pos, n_tokens, N, stride_b, stride_n, H, D, base, fwd);
+        const int64_t base_work = n_tokens * 2 * (D / 16);
+        int hsplit = 1; // split the heads until there are >= ~4 waves per SIMD worth of threads
+        while (hsplit < H && base_work * hsplit < 256 * 1024) hsplit *= 2;
+        if (hsplit > H) hsplit = H;
+        const int64_t work = base_work * hsplit;
+        hipLaunchKernelGGL((rope2d_vec_kernel<T>), dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, tokens, pos, n_tokens, N, stride_b, stride_n, H, D, base, fwd, hsplit);
     } else {
         const int64_t work = n_tokens * 2 * (D / 4);
         hipLaunchKernelGGL((rope2d_scalar_kernel<T>), dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, stream, tokens, pos, n_tokens, N, stride_b, stride_n, H, D, base, fwd);
