@@ -180,11 +180,12 @@ extern "C" int adk_bin_depth_order(int N, const uint32_t* depth_keys, const uint
     uint32_t* k0 = (uint32_t*)w; uint32_t* v0 = (uint32_t*)(w + seg);
     uint32_t* k1 = (uint32_t*)(w + 2 * seg); uint32_t* v1 = (uint32_t*)(w + 3 * seg);
     uint32_t* scratch = (uint32_t*)(w + 4 * seg);
-    // depth bits of a positive float are < 0x7F800000 and the cull sentinel is 0xFFFFFFFF: 32 bits, 4 passes
-    const int res = adk::radix_sort_pairs(depth_keys, gauss_ids, k0, v0, k1, v1, N, 0, 32, scratch, stream);
-    const uint32_t* vres = res ? v1 : v0;
-    hipError_t e = hipMemcpyAsync(sorted_ids, vres, (size_t)N * 4, hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return (int)e;
+    // depth bits of a positive float are < 0x7F800000 and the cull sentinel is 0xFFFFFFFF: 32 bits, 4 passes.  An even
+    // number of passes ends in the second buffer pair, so sorted_ids itself is handed in as that pair's value
+    // buffer: the last scatter writes the result in place (no device-to-device copy).
+    (void)v1;
+    const int res = adk::radix_sort_pairs(depth_keys, gauss_ids, k0, v0, k1, sorted_ids, N, 0, 32, scratch, stream);
+    if (res != 1) return ADK_EUNSUPPORTED; // 4 passes by construction
     const int nb = (int)adk::ceil_div(N, 256);
     hipLaunchKernelGGL(adk::count_block_sums_kernel, dim3(nb), dim3(256), 0, stream, sorted_ids, tiles_per_gauss, N, block_offs);
     hipLaunchKernelGGL(adk::scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, block_offs, nb, n_isects);
@@ -241,15 +242,15 @@ extern "C" int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids
     int bits = 0;
     while ((1 << bits) < n_tiles) ++bits;
     const int bit_hi = ((bits + 7) / 8) * 8; // whole 8-bit digits covering the tile id
-    // source = (k0,v0); ping-pong between (k1,v1) and (k0,v0)
-    const int res = adk::radix_sort_pairs(k0, v0, k1, v1, k0, v0, n_isects, 0, bit_hi > 0 ? bit_hi : 8, scratch, stream);
-    // res==0 -> result in the "first" pair passed (k1,v1); res==1 -> (k0,v0)
-    const uint32_t* kres = res ? k0 : k1;
-    const uint32_t* vres = res ? v0 : v1;
-    hipError_t e = hipMemcpyAsync(tile_ids, kres, (size_t)n_isects * 4, hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(flatten_ids, vres, (size_t)n_isects * 4, hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return (int)e;
+    // source = (k0,v0), read by the first pass only.  The pass count decides which buffer pair receives the last
+    // scatter; the caller's (tile_ids, flatten_ids) are placed there so the sorted list is written in place.
+    const int hi = bit_hi > 0 ? bit_hi : 8, passes = hi / 8;
+    uint32_t* ko = tile_ids;
+    uint32_t* vo = reinterpret_cast<uint32_t*>(flatten_ids);
+    int res;
+    if (passes & 1) res = adk::radix_sort_pairs(k0, v0, ko, vo, k1, v1, n_isects, 0, hi, scratch, stream) == 0 ? 0 : -1;
+    else res = adk::radix_sort_pairs(k0, v0, k1, v1, ko, vo, n_isects, 0, hi, scratch, stream) == 1 ? 0 : -1;
+    if (res != 0) return ADK_EUNSUPPORTED;
     hipLaunchKernelGGL(adk::tile_offsets_kernel, dim3((unsigned)adk::ceil_div(n_isects, 256)), dim3(256), 0, stream, tile_ids, n_isects, n_tiles, offsets);
     ADK_RETURN_LAST_ERROR();
 }

@@ -33,14 +33,11 @@ def main():
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--random-matches", action="store_true", help="random slot order (worst case for the gathers) instead of spatially coherent matches")
     args = ap.parse_args()
-    from oracle import gn_oracle as G  # graph generator + (optional) CPU leg only
     import mast3r_slam_backends as B
+    from artdeco_amd import synthetic as S
     dev = torch.device("cuda:0")
-    g = G.synthetic_graph(num_poses=args.keyframes, n=512 * 384, seed=0, extra_edges=args.extra_edges, coherent=not args.random_matches)
-    rng = np.random.default_rng(1)
-    T0 = g["T_gt"].copy()
-    for k in range(1, len(T0)):
-        T0[k] = G.retr_sim3((0.03 * rng.standard_normal(7)).astype(np.float32), T0[k])
+    g = S.keyframe_graph(num_poses=args.keyframes, n=512 * 384, seed=0, extra_edges=args.extra_edges, coherent=not args.random_matches)
+    T0 = S.perturb_poses(g["T_gt"], np.random.default_rng(1), 0.03)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     Xs, Cs, ii, jj, idx, valid, Q = t(g["Xs"]), t(g["Cs"]), t(g["ii"]), t(g["jj"]), t(g["idx"]), t(g["valid"]), t(g["Q"])
     prm = dict(sigma_point=0.05, sigma_ray=0.003, sigma_dist=10.0, C=0.0, Q=1.5, max_iter=10, delta=1e-8)
@@ -70,13 +67,14 @@ def main():
     out = {"metric": f"global optimisation calls/s (gauss_newton_{args.kind}, {args.keyframes} keyframes, {E} factors x {n} points, 10 GN iterations)",
            "value": 1e3 / ms_call, "unit": "calls/s", "ms_per_call": ms_call, "n_gpus": 1, "higher_is_better": True, "dtype": "f32 (normal equations f64)",
            "data": "synthetic", "pose_error_after": err,
-           "config": {"workload": "exactly consistent synthetic keyframe graph (oracle.gn_oracle.synthetic_graph), " + ("random" if args.random_matches else "spatially coherent") + " matches", "keyframes": args.keyframes,
+           "config": {"workload": "exactly consistent synthetic keyframe graph (artdeco_amd.synthetic.keyframe_graph), " + ("random" if args.random_matches else "spatially coherent") + " matches", "keyframes": args.keyframes,
                       "factors": E, "points_per_factor": n, "unknowns": 7 * (args.keyframes - 1)},
            "roofline": {"bound": "hbm", "kernel": "gn_accumulate_kernel (x10) + gn_solve_kernel (x10), whole call", "achieved": alg_bytes / (ms_call * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (ms_call * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes": alg_bytes}}
     if args.cpu_baseline:
-        sub = G.synthetic_graph(num_poses=args.keyframes, n=512 * 384 // 16, seed=0, extra_edges=args.extra_edges)
+        from oracle import gn_oracle as G  # the CPU leg only
+        sub = S.keyframe_graph(num_poses=args.keyframes, n=512 * 384 // 16, seed=0, extra_edges=args.extra_edges)
         Tc = sub["T_gt"].copy()
         t0 = time.time()
         G.gauss_newton(args.kind, Tc, sub["Xs"], sub["Cs"], sub["ii"], sub["jj"], sub["idx"], sub["valid"], sub["Q"],

@@ -248,111 +248,3 @@ def residual_vector(kind, Twc, Xs, ii_edge, jj_edge, idx, prm):
             v = K[1, 1] * P[:, 1] / P[:, 2] + K[1, 2]
             out.append(np.stack([u - idx[e] % W, v - idx[e] // W, np.log(P[:, 2]) - np.log(Xi[:, 2])], 1).reshape(-1))
     return np.concatenate(out)
-
-
-# ---------------------------------------------------------------- synthetic factor graph
-def random_sim3(rng, n, t_scale=0.3, r_scale=0.2, s_scale=0.1):
-    T = np.zeros((n, 8), dtype=np.float32)
-    for k in range(n):
-        xi = np.concatenate([t_scale * rng.standard_normal(3), r_scale * rng.standard_normal(3), [s_scale * rng.standard_normal()]])
-        T[k] = retr_sim3(xi.astype(np.float32), np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float32))
-    return T
-
-
-def _edges(rng, num_poses, extra_edges):
-    edges = [(p, p + 1) for p in range(num_poses - 1)]
-    extra_edges = min(extra_edges, num_poses * (num_poses - 1) // 2 - (num_poses - 1))  # only so many pairs exist
-    while len(edges) < num_poses - 1 + extra_edges:
-        a, b = rng.integers(0, num_poses, 2)
-        if a != b and (a, b) not in edges and (b, a) not in edges:
-            edges.append((int(a), int(b)))
-    ii = np.array([a for a, b in edges] + [b for a, b in edges], dtype=np.int64)  # both directions, prep_two_way_edges
-    jj = np.array([b for a, b in edges] + [a for a, b in edges], dtype=np.int64)
-    return ii, jj
-
-
-def synthetic_graph(num_poses=5, n=768, seed=0, extra_edges=3, noise=0.0, outlier_frac=0.0, kf_ids=None, coherent=False):
-    """EXACTLY consistent graph for the points / rays factors: n world points, keyframe p stores T_p^-1 W in a private
-    random slot order, a match pairs the two slots of the same world point.  With noise = 0 the ground-truth poses
-    `T_gt` give zero residual on every valid match.  10 % of the matches get Q below the threshold and 10 % are
-    flagged invalid (with garbage indices) -- both must be ignored.  kf_ids: optional non-contiguous keyframe ids.
-    coherent: slot orders are circular shifts instead of random permutations, so neighbouring points match neighbouring
-    points as dense pixel matches do (the random order is the worst case for the gathers)."""
-    rng = np.random.default_rng(seed)
-    T_gt = random_sim3(rng, num_poses, 0.3, 0.15, 0.08)
-    T_gt[0] = np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float32)
-    W = np.concatenate([rng.uniform(-1.5, 1.5, (n, 2)), rng.uniform(2.0, 5.0, (n, 1))], 1)
-    Tg = T_gt.astype(np.float64)
-    if coherent:
-        perm = [np.roll(np.arange(n), int(rng.integers(0, n))) for _ in range(num_poses)]
-    else:
-        perm = [rng.permutation(n) for _ in range(num_poses)]  # slot of world point m in keyframe p
-    Xs = np.zeros((num_poses, n, 3), dtype=np.float32)
-    for p in range(num_poses):
-        t, q, s = Tg[p, 0:3], Tg[p, 3:7], Tg[p, 7]
-        q_inv = np.array([-q[0], -q[1], -q[2], q[3]])
-        Xs[p][perm[p]] = (act_so3(q_inv, W - t) / s).astype(np.float32)
-    if noise > 0:
-        Xs = (Xs + noise * rng.standard_normal(Xs.shape)).astype(np.float32)
-    Cs = (1.0 + rng.random((num_poses, n, 1))).astype(np.float32)
-    ii, jj = _edges(rng, num_poses, extra_edges)
-    E = len(ii)
-    idx = np.zeros((E, n), dtype=np.int64)
-    valid = np.ones((E, n, 1), dtype=bool)
-    Q = (1.6 + rng.random((E, n, 1))).astype(np.float32)
-    for e in range(E):
-        inv_j = np.empty(n, dtype=np.int64)
-        inv_j[perm[jj[e]]] = np.arange(n)
-        idx[e] = perm[ii[e]][inv_j]
-        Q[e, rng.random(n) < 0.1, 0] = 1.0
-        bad = rng.random(n) < 0.1
-        valid[e, bad, 0] = False
-        idx[e][bad] = rng.integers(0, n, bad.sum())
-        if outlier_frac > 0:
-            out = (rng.random(n) < outlier_frac) & ~bad
-            idx[e][out] = rng.integers(0, n, out.sum())
-    if kf_ids is not None:
-        kf_ids = np.asarray(kf_ids, dtype=np.int64)
-        ii, jj = kf_ids[ii], kf_ids[jj]
-    return dict(T_gt=T_gt, Xs=Xs, Cs=Cs, ii=ii, jj=jj, idx=idx, valid=valid, Q=Q)
-
-
-def synthetic_calib_graph(num_poses=4, height=48, width=64, seed=0, extra_edges=2, fx=70.0):
-    """Pixel-grid graph for the calibrated factor: keyframe p stores points on its own pixel rays (what
-    constrain_points_to_ray produces, mast3r_slam/geometry.py:38-43) of one smooth world surface; a match pairs a pixel
-    of j with the NEAREST pixel of its re-projection into i (so ground truth leaves a sub-pixel residual)."""
-    rng = np.random.default_rng(seed)
-    n = height * width
-    K = np.array([[fx, 0, width / 2.0], [0, fx, height / 2.0], [0, 0, 1]], dtype=np.float32)
-    T_gt = random_sim3(rng, num_poses, 0.25, 0.05, 0.03)
-    T_gt[0] = np.array([0, 0, 0, 0, 0, 0, 1, 1], dtype=np.float32)
-    Tg = T_gt.astype(np.float64)
-    uu, vv = np.meshgrid(np.arange(width), np.arange(height))
-    uv = np.stack([uu.reshape(-1), vv.reshape(-1)], 1).astype(np.float64)
-    surf = lambda x, y: 3.0 + 0.3 * np.sin(1.3 * x) + 0.25 * np.cos(1.1 * y)   # world surface z = surf(x, y)
-    Xs = np.zeros((num_poses, n, 3), dtype=np.float32)
-    for p in range(num_poses):
-        t, q, s = Tg[p, 0:3], Tg[p, 3:7], Tg[p, 7]
-        d = np.stack([(uv[:, 0] - K[0, 2]) / fx, (uv[:, 1] - K[1, 2]) / fx, np.ones(n)], 1)
-        z = np.full(n, 3.0)
-        for _ in range(30):                         # fixed point: camera depth whose world point lies on the surface
-            Wp = act_so3(q, d * z[:, None]) * s + t
-            z = z + (surf(Wp[:, 0], Wp[:, 1]) - Wp[:, 2]) / s
-        Xs[p] = (d * z[:, None]).astype(np.float32)
-    Cs = (1.0 + rng.random((num_poses, n, 1))).astype(np.float32)
-    ii, jj = _edges(rng, num_poses, extra_edges)
-    E = len(ii)
-    idx = np.zeros((E, n), dtype=np.int64)
-    valid = np.zeros((E, n, 1), dtype=bool)
-    Q = (1.6 + rng.random((E, n, 1))).astype(np.float32)
-    for e in range(E):
-        i, j = ii[e], jj[e]
-        tij, qij, sij = rel_sim3(Tg[i, 0:3], Tg[i, 3:7], Tg[i, 7], Tg[j, 0:3], Tg[j, 3:7], Tg[j, 7])
-        P = act_so3(qij, Xs[j].astype(np.float64)) * sij + tij
-        u = np.rint(fx * P[:, 0] / P[:, 2] + K[0, 2]).astype(np.int64)
-        v = np.rint(fx * P[:, 1] / P[:, 2] + K[1, 2]).astype(np.int64)
-        ok = (P[:, 2] > 0.1) & (u >= 0) & (u < width) & (v >= 0) & (v < height)
-        idx[e] = np.where(ok, v * width + u, 0)
-        valid[e, :, 0] = ok
-        Q[e, rng.random(n) < 0.1, 0] = 1.0
-    return dict(T_gt=T_gt, Xs=Xs, Cs=Cs, K=K, ii=ii, jj=jj, idx=idx, valid=valid, Q=Q, height=height, width=width)
