@@ -350,21 +350,45 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     r4[2] = make_float4(col[0], col[1], col[2], col[3]);
 }
 
+// Optional in-kernel optimiser for the SH coefficients (see adk_project_bwd_adam): the gradient of coefficient
+// (k, ch) is the product b_k * v_rgb[ch] of two numbers this thread already holds, and the coefficient itself was
+// just read for the forward value -- so the sparse-Adam update of f_dc / f_rest is applied right here instead of
+// writing 48 gradients per Gaussian for a second kernel to read back together with the parameters.
+struct ColorAdam {
+    float* m_dc; float* v_dc; float* m_rest; float* v_rest; // exp_avg / exp_avg_sq of colors [N,1,3] and sh_rest [N,K-1,3]
+    const float* lr_dc; const float* lr_rest;               // 0-dim device tensors (optimizers.py:70-73)
+    float b1, b2, eps;
+};
+
+// identical expression order to adam.hip:adam_elem (bit-identical updates; this file is built -ffp-contract=off too)
+__device__ __forceinline__ void color_adam_elem(float* __restrict__ p_ptr, float p, float g, float* __restrict__ m_ptr,
+                                                float* __restrict__ v_ptr, float lr, float b1, float b2, float eps)
+{
+    const float m = b1 * *m_ptr + (1.0f - b1) * g;
+    const float v = b2 * *v_ptr + (1.0f - b2) * g * g;
+    const float step = -lr * m / (sqrtf(v) + eps);
+    *m_ptr = m; *v_ptr = v; *p_ptr = p + step;
+}
+
 // ---------------------------------------------------------------------------------- backward
 // v_rec layout mirrors rec: [0] v_mx [1] v_my [2] v_opacity | [4] v_ca [5] v_cb [6] v_cc | [8..11] v_colour channels.
 // cam_grad[16]: v_R (9, row-major) | v_t (3) | v_campos (3) | pad, accumulated with atomics.
-template <int SH_DEG>
+template <int SH_DEG, bool FUSE_ADAM>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
-    const float* __restrict__ colors_in, const float* __restrict__ sh_rest, int sh_K, int color_mode,
+    const float* colors_in, const float* sh_rest, int sh_K, int color_mode,
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height,
     float eps2d, float near_plane, float far_plane, int inv_depth,
     const int32_t* __restrict__ radii, const float* __restrict__ v_rec,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
     float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ v_sh_rest,
-    float* __restrict__ cam_grad)
+    float* __restrict__ cam_grad, ColorAdam opt)
 {
     __shared__ float red[4][16];
+    // FUSE_ADAM: per-Gaussian (b_k, v_rgb, live) for the coalesced optimiser phase (17 B-conflict-free row pitch)
+    __shared__ float adam_b[FUSE_ADAM ? 256 : 1][17];
+    __shared__ float adam_v[FUSE_ADAM ? 256 : 1][3];
+    __shared__ uint8_t adam_live[FUSE_ADAM ? 256 : 1];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const Cam cam = load_cam(viewmat, Kmat);
     float cg[15];
@@ -372,6 +396,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     for (int i = 0; i < 15; ++i) cg[i] = 0.f;
 
     const bool live = (g < N) && (radii[2 * g] > 0) && (radii[2 * g + 1] > 0);
+    if (FUSE_ADAM) adam_live[threadIdx.x] = live ? 1 : 0;
     if (g < N && !live) {
         if (v_means) { v_means[3 * g] = 0.f; v_means[3 * g + 1] = 0.f; v_means[3 * g + 2] = 0.f; }
         if (v_quats) reinterpret_cast<float4*>(v_quats)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -534,10 +559,18 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
             for (int k = 0; k < NB; ++k) {
                 const float wsum = cv[k][0] * vres[0] + cv[k][1] * vres[1] + cv[k][2] * vres[2];
                 vdn[0] += bx[k] * wsum; vdn[1] += by[k] * wsum; vdn[2] += bz[k] * wsum;
-                float* dst = (orst && k > 0) ? orst + 3 * (k - 1) : (o ? o + 3 * k : nullptr);
-                if (dst) { dst[0] = b[k] * vres[0]; dst[1] = b[k] * vres[1]; dst[2] = b[k] * vres[2]; }
+                if (FUSE_ADAM) { // applied by the coalesced phase at the end of the kernel
+                } else {
+                    float* dst = (orst && k > 0) ? orst + 3 * (k - 1) : (o ? o + 3 * k : nullptr);
+                    if (dst) { dst[0] = b[k] * vres[0]; dst[1] = b[k] * vres[1]; dst[2] = b[k] * vres[2]; }
+                }
             }
-            if (orst) { for (int i = (NB - 1) * 3; i < (sh_K - 1) * 3; ++i) orst[i] = 0.f; }
+            if (FUSE_ADAM) { // hand (b_k, v_rgb) to the coalesced optimiser phase at the end of the kernel
+#pragma unroll
+                for (int k = 0; k < 16; ++k) adam_b[threadIdx.x][k] = k < NB ? b[k] : 0.f; // bands above the active degree: zero gradient
+                adam_v[threadIdx.x][0] = vres[0]; adam_v[threadIdx.x][1] = vres[1]; adam_v[threadIdx.x][2] = vres[2];
+            }
+            else if (orst) { for (int i = (NB - 1) * 3; i < (sh_K - 1) * 3; ++i) orst[i] = 0.f; }
             else if (o) { for (int i = NB * 3; i < sh_K * 3; ++i) o[i] = 0.f; }
             const float dd = vdn[0] * dx + vdn[1] * dy + vdn[2] * dz;
             const float vd[3] = {(vdn[0] - dd * dx) * inorm, (vdn[1] - dd * dy) * inorm, (vdn[2] - dd * dz) * inorm};
@@ -560,6 +593,54 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         }
     }
 
+    if (FUSE_ADAM) {
+        // Sparse-Adam step of the block's SH coefficients, walked as the flat, 16 B-aligned slab they are in memory
+        // (every access a full-width float4 per lane, like adam.hip).  A thread that walked its own Gaussian's row
+        // (12 B accesses 180 B apart: 64 cache lines per wave instruction) made this 4x slower than the two separate
+        // kernels; this way it is faster than them.  Gradient of element (row, k, ch) = b_k[row] * v_rgb[row][ch].
+        __syncthreads();
+        const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+        const int rows = (int)min((int64_t)blockDim.x, (int64_t)N - g0);
+        const int RW = (sh_K - 1) * 3;
+        const float lr_dc = opt.lr_dc[0], lr_rest = opt.lr_rest[0];
+        const float omb1 = 1.0f - opt.b1, omb2 = 1.0f - opt.b2;
+        auto step = [&](float& p, float& m, float& v, float gr, float lr) { // expression order of adam.hip:adam_elem
+            m = opt.b1 * m + omb1 * gr;
+            v = opt.b2 * v + omb2 * gr * gr;
+            p += -lr * m / (sqrtf(v) + opt.eps);
+        };
+        {
+            float* P = const_cast<float*>(sh_rest) + g0 * RW;
+            float* M = opt.m_rest + g0 * RW;
+            float* V = opt.v_rest + g0 * RW;
+            const int total = rows * RW, n4 = total >> 2;
+            for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+                const int e0 = 4 * i, r0 = e0 / RW, r1 = (e0 + 3) / RW;
+                if (!adam_live[r0] && !adam_live[r1]) continue; // culled rows are not touched (not even read)
+                float4 p4 = reinterpret_cast<float4*>(P)[i], m4 = reinterpret_cast<float4*>(M)[i], v4 = reinterpret_cast<float4*>(V)[i];
+                float* pe = &p4.x; float* me = &m4.x; float* ve = &v4.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j, row = e / RW, col = e - row * RW, k = col / 3 + 1, ch = col - (col / 3) * 3;
+                    if (adam_live[row]) step(pe[j], me[j], ve[j], adam_b[row][k] * adam_v[row][ch], lr_rest);
+                }
+                reinterpret_cast<float4*>(P)[i] = p4; reinterpret_cast<float4*>(M)[i] = m4; reinterpret_cast<float4*>(V)[i] = v4;
+            }
+            for (int e = (n4 << 2) + threadIdx.x; e < total; e += blockDim.x) {
+                const int row = e / RW, col = e - row * RW, k = col / 3 + 1, ch = col - (col / 3) * 3;
+                if (adam_live[row]) step(P[e], M[e], V[e], adam_b[row][k] * adam_v[row][ch], lr_rest);
+            }
+        }
+        {
+            float* P = const_cast<float*>(colors_in) + g0 * 3;
+            float* M = opt.m_dc + g0 * 3;
+            float* V = opt.v_dc + g0 * 3;
+            for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
+                const int row = e / 3, ch = e - row * 3;
+                if (adam_live[row]) step(P[e], M[e], V[e], adam_b[row][0] * adam_v[row][ch], lr_dc);
+            }
+        }
+    }
     if (cam_grad) { // uniform branch
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -640,13 +721,13 @@ extern "C" int adk_project_fwd(int N, const float* means, const float* quats, co
     ADK_RETURN_LAST_ERROR();
 }
 
-extern "C" int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
-                               const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
-                               const float* viewmat, const float* Kmat, int width, int height, float eps2d,
-                               float near_plane, float far_plane, int inv_depth, const int32_t* radii,
-                               const float* v_rec, float* v_means, float* v_quats, float* v_scales,
-                               float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad /*[16], zeroed*/,
-                               float* v_viewmat /*[16] or NULL*/, hipStream_t stream)
+static int project_bwd_launch(int N, const float* means, const float* quats, const float* scales,
+                              const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
+                              const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                              float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                              const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                              float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad,
+                              float* v_viewmat, const adk::ColorAdam* opt, hipStream_t stream)
 {
     if (N < 0 || width <= 0 || height <= 0) return ADK_EINVAL;
     if (!viewmat || !Kmat) return ADK_EINVAL;
@@ -658,13 +739,59 @@ extern "C" int adk_project_bwd(int N, const float* means, const float* quats, co
         if (((uintptr_t)quats & 15) || ((uintptr_t)v_rec & 15) || (v_quats && ((uintptr_t)v_quats & 15))) return ADK_EINVAL;
         const dim3 grid((unsigned)adk::ceil_div(N, 256)), block(256);
         const int deg = color_mode == 0 ? sh_degree : 0;
-        ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_bwd_kernel<SH_DEG>), grid, block, 0, stream, N, means,
-                                                quats, scales, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
-                                                eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales,
-                                                v_opacities, v_colors, v_sh_rest, cam_grad));
+        if (opt) {
+            ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_bwd_kernel<SH_DEG, true>), grid, block, 0, stream, N, means,
+                                                    quats, scales, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
+                                                    eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales,
+                                                    v_opacities, nullptr, nullptr, cam_grad, *opt));
+        } else {
+            const adk::ColorAdam none = {};
+            ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_bwd_kernel<SH_DEG, false>), grid, block, 0, stream, N, means,
+                                                    quats, scales, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
+                                                    eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales,
+                                                    v_opacities, v_colors, v_sh_rest, cam_grad, none));
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
     if (v_viewmat) hipLaunchKernelGGL(adk::viewmat_grad_finalize_kernel, dim3(1), dim3(64), 0, stream, viewmat, cam_grad, v_viewmat);
     ADK_RETURN_LAST_ERROR();
+}
+
+extern "C" int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
+                               const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
+                               const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                               float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                               const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                               float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad /*[16], zeroed*/,
+                               float* v_viewmat /*[16] or NULL*/, hipStream_t stream)
+{
+    return project_bwd_launch(N, means, quats, scales, colors_in, sh_rest, sh_K, sh_degree, color_mode, viewmat, Kmat, width, height,
+                              eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities,
+                              v_colors, v_sh_rest, cam_grad, v_viewmat, nullptr, stream);
+}
+
+// adk_project_bwd with the sparse-Adam step of the SH coefficients applied in the same pass: no v_colors / v_sh_rest
+// are produced; f_dc [N,1,3] and f_rest [N,K-1,3] and their moments are updated IN PLACE for every Gaussian with
+// radii > 0 -- exactly the rows adamUpdate(..., visible = radii > 0, ...) touches (optimizers.py:116-128), with the
+// same arithmetic (bit-identical to adk_project_bwd followed by adk_adam_update).  lr_*: device scalars.
+extern "C" int adk_project_bwd_adam(int N, const float* means, const float* quats, const float* scales,
+                                    float* f_dc, float* f_rest, int sh_K, int sh_degree,
+                                    const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                                    float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                                    const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                                    float* v_opacities, float* cam_grad, float* v_viewmat,
+                                    float* m_dc, float* v_dc, float* m_rest, float* v_rest, const float* lr_dc,
+                                    const float* lr_rest, float b1, float b2, float eps, hipStream_t stream)
+{
+    if (!f_dc || !f_rest || sh_K < 2 || !m_dc || !v_dc || !m_rest || !v_rest || !lr_dc || !lr_rest) return ADK_EINVAL;
+    if (sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1)) return ADK_EINVAL;
+    if (sh_K > 16) return ADK_EUNSUPPORTED;
+    if (((uintptr_t)f_rest | (uintptr_t)m_rest | (uintptr_t)v_rest) & 15) return ADK_EINVAL; // walked as float4
+    adk::ColorAdam opt;
+    opt.m_dc = m_dc; opt.v_dc = v_dc; opt.m_rest = m_rest; opt.v_rest = v_rest; opt.lr_dc = lr_dc; opt.lr_rest = lr_rest;
+    opt.b1 = b1; opt.b2 = b2; opt.eps = eps;
+    return project_bwd_launch(N, means, quats, scales, f_dc, f_rest, sh_K, sh_degree, 0, viewmat, Kmat, width, height, eps2d,
+                              near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities,
+                              nullptr, nullptr, cam_grad, v_viewmat, &opt, stream);
 }

@@ -21,6 +21,7 @@ import types
 import torch
 
 from . import _lib
+from . import rasterizer
 from .rasterizer import _WS, _stage, render_camera
 
 _NW = 32 * 32 + 32 + 7 * 32 + 7
@@ -404,6 +405,24 @@ def _rdk_cached(self, h, w):
     return cache[key]
 
 
+def _color_adam_state(opt):
+    """State for rasterizer.color_adam from a SparseGaussianAdam (optimizers.py:59-75), or None when its layout is
+    not the plain one (0-dim device learning rates, no per-element schedule on the colours)."""
+    try:
+        dc, rest = opt.params["f_dc"], opt.params["f_rest"]
+        if "f_dc" in opt.lr_dict or "f_rest" in opt.lr_dict:
+            return None
+        for pd in (dc, rest):
+            if not (torch.is_tensor(pd["lr"]) and pd["lr"].numel() == 1 and pd["lr"].is_cuda and pd["val"].is_contiguous()
+                    and pd["val"].dtype == torch.float32):
+                return None
+        return {"f_dc": dc["val"], "f_rest": rest["val"], "m_dc": dc["exp_avg"], "v_dc": dc["exp_avg_sq"],
+                "m_rest": rest["exp_avg"], "v_rest": rest["exp_avg_sq"], "lr_dc": dc["lr"], "lr_rest": rest["lr"],
+                "betas": opt.betas, "eps": opt.eps}
+    except (KeyError, AttributeError):
+        return None
+
+
 def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     """The body of SceneModel.optimization_step after the keyframe has been chosen (h3dgsv3.py:418-464): same
     order of operations (zero_grad, render at the keyframe's level with a random background, loss, backward,
@@ -435,7 +454,10 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
                                                            self.lambda_dssim, keyframe.depth_loss_weight, not is_important)
     if self.scaling_reg_factor != 0:
         loss = loss + self.scaling_reg_factor * scaling.prod(dim=1).mean()
-    loss.backward()
+    # the SH colours (48 of the 75 floats of a Gaussian) take their Adam step inside the projection backward, on
+    # exactly the rows optimizer.step would touch (radii > 0); their .grad stays None and the step below skips them
+    with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
+        loss.backward()
     with torch.no_grad():
         keyframe.step()
         if not keyframe.is_test:

@@ -108,6 +108,39 @@ _WS = _Workspace()
 _TLS = threading.local()
 
 
+@contextlib.contextmanager
+def color_adam(state: dict | None):
+    """While active, RasterizeGaussians.backward applies the sparse-Adam step of the split SH colours
+    (f_dc / f_rest) inside the projection backward (adk_project_bwd_adam) instead of returning their gradients.
+    state: {"f_dc", "f_rest": the parameter tensors; "m_dc", "v_dc", "m_rest", "v_rest": their moments;
+    "lr_dc", "lr_rest": 0-dim device tensors; "betas": (b1, b2); "eps": float}.  Only takes effect when the tensors
+    rendered are exactly those parameters; otherwise the gradients are returned as usual.  Process-wide, not
+    thread-local: autograd runs backward nodes on its own device thread."""
+    global _COLOR_ADAM
+    prev = _COLOR_ADAM
+    _COLOR_ADAM = state
+    try:
+        yield
+    finally:
+        _COLOR_ADAM = prev
+
+
+_COLOR_ADAM: dict | None = None
+
+
+def _color_adam_for(colors: torch.Tensor, rest: torch.Tensor):
+    st = _COLOR_ADAM
+    if st is None:
+        return None
+    ok = (colors.data_ptr() == st["f_dc"].data_ptr() and rest.data_ptr() == st["f_rest"].data_ptr()
+          and all(st[k].is_contiguous() and st[k].dtype == torch.float32 and st[k].device == colors.device
+                  for k in ("m_dc", "v_dc", "m_rest", "v_rest"))
+          and st["m_dc"].numel() == colors.numel() and st["v_dc"].numel() == colors.numel()
+          and st["m_rest"].numel() == rest.numel() and st["v_rest"].numel() == rest.numel()
+          and st["lr_dc"].numel() == 1 and st["lr_rest"].numel() == 1 and st["lr_dc"].is_cuda and st["lr_rest"].is_cuda)
+    return st if ok else None
+
+
 def _count_slot(device: torch.device):
     """Per-thread, per-device pinned int64 + event for the asynchronous read of n_isects."""
     slots = getattr(_TLS, "slots", None)
@@ -251,12 +284,26 @@ class RasterizeGaussians(torch.autograd.Function):
             v_opac = torch.empty(N, dtype=torch.float32, device=dev) if needs[3] else None
             has_colors = cfg.color_mode != _COLOR_DEPTH
             want_col_grads = has_colors and (needs[4] or (ctx.has_rest and needs[5]))
-            v_cols = torch.empty_like(colors) if want_col_grads else None
-            v_rest = torch.empty_like(rest) if (want_col_grads and ctx.has_rest) else None
+            fuse_cols = want_col_grads and ctx.has_rest and cfg.color_mode == _COLOR_SH and _color_adam_for(colors, rest) is not None
+            v_cols = torch.empty_like(colors) if (want_col_grads and not fuse_cols) else None
+            v_rest = torch.empty_like(rest) if (want_col_grads and ctx.has_rest and not fuse_cols) else None
             v_viewmat = cam_grad = None
             if needs[6]:
                 v_viewmat = torch.empty(4, 4, dtype=torch.float32, device=dev)
                 cam_grad = torch.zeros(16, dtype=torch.float32, device=dev)
+            opt = _color_adam_for(colors, rest) if (want_col_grads and ctx.has_rest and cfg.color_mode == _COLOR_SH) else None
+            if opt is not None:
+                with _stage("project_bwd"):
+                    rc = lib.adk_project_bwd_adam(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), colors.data_ptr(),
+                                                  rest.data_ptr(), cfg.sh_K, cfg.sh_degree, viewmat.data_ptr(), K.data_ptr(), W, H,
+                                                  cfg.eps2d, cfg.near_plane, cfg.far_plane, int(cfg.inv_depth), radii.data_ptr(),
+                                                  v_rec.data_ptr(), _lib.ptr(v_means), _lib.ptr(v_quats), _lib.ptr(v_scales),
+                                                  _lib.ptr(v_opac), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), opt["m_dc"].data_ptr(),
+                                                  opt["v_dc"].data_ptr(), opt["m_rest"].data_ptr(), opt["v_rest"].data_ptr(),
+                                                  opt["lr_dc"].data_ptr(), opt["lr_rest"].data_ptr(), float(opt["betas"][0]),
+                                                  float(opt["betas"][1]), float(opt["eps"]), stream)
+                _lib.check(rc, "adk_project_bwd_adam")
+                return v_means, v_quats, v_scales, v_opac, None, None, v_viewmat, None, None, None
             with _stage("project_bwd"):
               rc = lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
                                      colors.data_ptr() if has_colors else None, rest.data_ptr() if ctx.has_rest else None, cfg.sh_K, cfg.sh_degree,

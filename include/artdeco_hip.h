@@ -131,6 +131,20 @@ int adk_project_bwd(int N, const float* means, const float* quats, const float* 
                     float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad,
                     float* v_viewmat, adk_stream_t stream);
 
+/* adk_project_bwd with the sparse-Adam step of the SH coefficients (ARTDECO's f_dc [N,1,3] / f_rest [N,K-1,3],
+ * Reconstruct/scene/optimizers.py:106-128) applied in the same pass: the coefficient gradients are never written;
+ * f_dc, f_rest and their moments (m_*, v_* = exp_avg, exp_avg_sq) are updated IN PLACE for every Gaussian with
+ * radii > 0 -- the rows adamUpdate(..., visible = radii > 0, ...) touches -- bit-identically to adk_project_bwd
+ * followed by adk_adam_update.  lr_dc / lr_rest: 0-dim DEVICE tensors (optimizers.py:70-73). */
+int adk_project_bwd_adam(int N, const float* means, const float* quats, const float* scales,
+                         float* f_dc, float* f_rest, int sh_K, int sh_degree,
+                         const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                         float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                         const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                         float* v_opacities, float* cam_grad, float* v_viewmat,
+                         float* m_dc, float* v_dc, float* m_rest, float* v_rest, const float* lr_dc,
+                         const float* lr_rest, float b1, float b2, float eps, adk_stream_t stream);
+
 /* *n_isects (int64, device) = sum(tiles_per_gauss): the size of the intersection list, known right after
  * the projection.  Lets the host read it (pinned copy + event) while adk_bin_depth_order is still running,
  * instead of the stream-draining read gsplat does after isect_tiles (rendering.py, `isect_tiles` -> n_isects). */

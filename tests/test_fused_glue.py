@@ -230,6 +230,91 @@ def test_fused_optimizer_step_is_bit_identical(dev):
             assert got[k][3] == ref[k][3]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,deg", [(5000, 3), (777, 3), (1300, 2)])
+def test_colour_adam_inside_backward_is_bit_identical(N, deg, dev):
+    """adk_project_bwd_adam (sparse-Adam step of f_dc / f_rest inside the projection backward) leaves the same
+    parameters and moments, bit for bit, as adk_project_bwd + adamUpdate on the rows with radii > 0, and the same
+    other gradients.  (Compared on one fixed v_rec: the raster backward's float atomics are not order-deterministic,
+    so two full steps never agree to the bit.)"""
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    from diff_gaussian_rasterization import adamUpdate
+    from artdeco_amd import _lib, mapper
+    lib = _lib.load()
+    W, H, K = 160, 112, 16
+    c = mapper.synthetic_cloud(N, W, H, seed=4)
+    g = torch.Generator().manual_seed(9)
+    t = lambda x: x.to(dev).contiguous()
+    means, quats, scales, opac = t(c["means"]), t(c["quats"]), t(c["scales"]), t(c["opacities"])
+    opac[::7] = 0.001  # culled rows: must stay untouched
+    f_dc, f_rest = t(c["sh"][:, :1, :]), t(c["sh"][:, 1:, :])
+    viewmat = torch.eye(4, device=dev)
+    Km = torch.tensor([[c["fx"], 0, W / 2], [0, c["fx"], H / 2], [0, 0, 1]], device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    rec, radii = torch.empty(N, 12, device=dev), torch.empty(N, 2, **i32)
+    keys, ids, tpg = torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N, **i32)
+    st = _lib.stream_of(means)
+    _lib.check(lib.adk_project_fwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), opac.data_ptr(), f_dc.data_ptr(),
+                                   f_rest.data_ptr(), K, deg, 0, viewmat.data_ptr(), Km.data_ptr(), W, H, 0.01, 0.01, 1e10, 0.0, 0,
+                                   rec.data_ptr(), radii.data_ptr(), keys.data_ptr(), ids.data_ptr(), tpg.data_ptr(), st), "fwd")
+    vis = (radii[:, 0] > 0) & (radii[:, 1] > 0)
+    assert 0.3 < float(vis.float().mean()) < 0.95
+    v_rec = t(torch.randn(N, 12, generator=g))
+    m_dc, v_dc = t(0.01 * torch.randn(N, 1, 3, generator=g)), t(1e-4 * torch.rand(N, 1, 3, generator=g))
+    m_rest, v_rest = t(0.01 * torch.randn(N, K - 1, 3, generator=g)), t(1e-4 * torch.rand(N, K - 1, 3, generator=g))
+    lr_dc, lr_rest = torch.tensor(5e-3, device=dev), torch.tensor(2.5e-4, device=dev)
+    b1, b2, eps = 0.5, 0.99, 1e-15
+
+    def grads():
+        return [torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, device=dev),
+                torch.zeros(16, device=dev), torch.empty(4, 4, device=dev)]
+
+    # reference path: gradients, then the optimiser
+    A = [x.clone() for x in (f_dc, f_rest, m_dc, v_dc, m_rest, v_rest)]
+    ga = grads()
+    v_cols, v_rst = torch.empty_like(f_dc), torch.empty_like(f_rest)
+    _lib.check(lib.adk_project_bwd(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), A[0].data_ptr(), A[1].data_ptr(), K, deg, 0,
+                                   viewmat.data_ptr(), Km.data_ptr(), W, H, 0.01, 0.01, 1e10, 0, radii.data_ptr(), v_rec.data_ptr(),
+                                   ga[0].data_ptr(), ga[1].data_ptr(), ga[2].data_ptr(), ga[3].data_ptr(), v_cols.data_ptr(),
+                                   v_rst.data_ptr(), ga[4].data_ptr(), ga[5].data_ptr(), st), "bwd")
+    adamUpdate(A[0], v_cols, A[2], A[3], vis, lr_dc, b1, b2, eps, N, 3)
+    adamUpdate(A[1], v_rst, A[4], A[5], vis, lr_rest, b1, b2, eps, N, (K - 1) * 3)
+    # fused path
+    B = [x.clone() for x in (f_dc, f_rest, m_dc, v_dc, m_rest, v_rest)]
+    gb = grads()
+    _lib.check(lib.adk_project_bwd_adam(N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), B[0].data_ptr(), B[1].data_ptr(), K, deg,
+                                        viewmat.data_ptr(), Km.data_ptr(), W, H, 0.01, 0.01, 1e10, 0, radii.data_ptr(), v_rec.data_ptr(),
+                                        gb[0].data_ptr(), gb[1].data_ptr(), gb[2].data_ptr(), gb[3].data_ptr(), gb[4].data_ptr(),
+                                        gb[5].data_ptr(), B[2].data_ptr(), B[3].data_ptr(), B[4].data_ptr(), B[5].data_ptr(),
+                                        lr_dc.data_ptr(), lr_rest.data_ptr(), b1, b2, eps, st), "bwd_adam")
+    names = ("f_dc", "f_rest", "m_dc", "v_dc", "m_rest", "v_rest")
+    for n, x, y in zip(names, A, B):
+        assert torch.equal(x, y), (n, float((x - y).abs().max()))
+    for x, y in zip(ga[:4], gb[:4]):
+        assert torch.equal(x, y)
+    assert torch.allclose(ga[5], gb[5], rtol=1e-4, atol=1e-3)  # camera gradient: block sums meet in fp32 atomics (order varies)
+    assert torch.equal(A[1][~vis], f_rest[~vis]) and not torch.equal(A[1][vis], f_rest[vis])  # culled rows untouched, others stepped
+
+
+@pytest.mark.gpu
+def test_fused_step_applies_colour_adam_in_backward(dev):
+    """In the fused training step the SH colours never materialise a .grad, yet they move like the unfused step moves them."""
+    from artdeco_amd import fused
+    a, b = _scene(dev, N=7000, seed=11), _scene(dev, N=7000, seed=11)
+    assert fused.patch_scene_model(a)
+    assert fused._color_adam_state(a.optimizer) is not None
+    p0 = a.gaussian_params["f_rest"]["val"].detach().clone()
+    torch.manual_seed(0)
+    a.optimization_step(0)
+    torch.manual_seed(0)
+    b.optimization_step(0)
+    assert a.gaussian_params["f_rest"]["val"].grad is None and a.gaussian_params["f_dc"]["val"].grad is None
+    ua = (a.gaussian_params["f_rest"]["val"] - p0).flatten().double()
+    ub = (b.gaussian_params["f_rest"]["val"] - p0).flatten().double()
+    assert float(ua.norm()) > 0 and float((ua @ ub) / (ua.norm() * ub.norm())) > 0.97
+
+
 def test_patch_refuses_unsupported_shapes():
     from artdeco_amd import fused
 
