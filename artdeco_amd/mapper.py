@@ -334,8 +334,13 @@ def synthetic_cloud(N, width, height, seed=0, sh_k=16, z_range=(2.0, 6.0), sigma
     return dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, fx=fx)
 
 
-def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4):
-    """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height)."""
+def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random"):
+    """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height).
+    targets: "random" = uniform-noise keyframe images (every parameter gets a large gradient: what the parity tests
+    want); "render" = each keyframe observes the cloud itself (its own render and inverse depth), i.e. a converged map,
+    so the cloud keeps the SURVEY 8(d) statistics while it is optimised.  With noise targets the optimiser dissolves
+    the cloud within ~30 steps (opacities and radii shrink, intersections 3.7 M -> 2.3 M at 1 M Gaussians / 1080p,
+    raster backward 1.0 -> 0.5 ms): a benchmark on them times a workload that gets lighter every step."""
     c = synthetic_cloud(N, width, height, seed)
     torch.manual_seed(seed)  # nn.Linear's default init draws from the global generator
     scene = MapperScene(width, height, c["fx"], device)
@@ -355,4 +360,12 @@ def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4):
         img = torch.rand(3, height, width, generator=g).to(device)
         idepth = (0.15 + 0.35 * torch.rand(1, height, width, generator=g)).to(device)
         scene.add_keyframe(Keyframe(img, idepth, Rt.to(device), torch.device(device)))
+    if targets == "render":
+        with torch.no_grad():
+            for i, kf in enumerate(scene.keyframes):
+                pkg = scene.render_from_id(i, bg=torch.full((3,), 0.5, device=scene.device))
+                kf.image_pyr[0] = pkg["render"].clamp(0, 1).contiguous()
+                kf.idepth_pyr[0] = pkg["invdepth"].contiguous()
+    elif targets != "random":
+        raise ValueError("targets must be 'random' or 'render'")
     return scene
