@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 
     PixBwd px[4];
     float qx0[4], qy0[4]; // pixel-centre origin of each quadrant
-    int tile_bin_final = -1;
+    int quad_bin_final[4], tile_bin_final = -1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ox = tx * TILE + (q & 1) * 8, oy = ty * TILE + (q >> 1) * 8;
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             P.T = T_final;
             P.bin_final = last_ids[pix];
         }
-        tile_bin_final = max(tile_bin_final, P.bin_final);
+        quad_bin_final[q] = wave_max_i(P.bin_final); // wave-uniform: nothing behind it can matter to this quadrant
+        tile_bin_final = max(tile_bin_final, quad_bin_final[q]);
     }
-    tile_bin_final = wave_max_i(tile_bin_final);
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
 
     // walk the tile's list back to front in groups of 64; groups entirely behind every pixel's last
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float x0 = qx0[q], x1 = x0 + 7.0f, y0 = qy0[q], y1 = y0 + 7.0f;
-            const bool hit = have && (r0.x + r0.w >= x0) && (r0.x - r0.w <= x1) && (r0.y + r1.w >= y0) && (r0.y - r1.w <= y1) &&
+            const bool hit = have && (batch_end - lane <= quad_bin_final[q]) &&
+                             (r0.x + r0.w >= x0) && (r0.x - r0.w <= x1) && (r0.y + r1.w >= y0) && (r0.y - r1.w <= y1) &&
                              splat_reaches_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, x0, x1, y0, y1);
             mq[q] = __ballot(hit);
         }
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             float acc[NACC];
 #pragma unroll
             for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+            bool touched = false; // wave-uniform
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (mq[q] & bit) { // wave-uniform
@@ -308,6 +310,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
                     float vis = __expf(-sigma);
                     const bool valid = (idx <= P.bin_final) && !(sigma < 0.f) && !(opac * vis < ALPHA_THR);
+                    if (__ballot(valid) == 0ull) continue; // nobody in this quadrant blended it (all finished earlier / below 1/255)
+                    touched = true;
                     vis = valid ? vis : 0.f;
                     const float ov = opac * vis;
                     const float alpha = fminf(MAX_ALPHA, ov);
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             }
             // ONE 64-lane reduction per (splat, tile): transposing butterfly (11 DPP ops instead of 60), after
             // which 10 lanes of row 0 each own one total and publish it with a single atomic instruction
+            if (!touched) continue; // every sum is zero: no reduction, no atomics
             acc[3] *= 0.5f; acc[5] *= 0.5f;
             const Reduce10 red = wave_reduce10(acc, lane);
             if (red.is_owner && red.value != 0.f)
