@@ -371,7 +371,9 @@ __device__ __forceinline__ void color_adam_elem(float* __restrict__ p_ptr, float
 }
 
 // ---------------------------------------------------------------------------------- backward
-// v_rec layout mirrors rec: [0] v_mx [1] v_my [2] v_opacity | [4] v_ca [5] v_cb [6] v_cc | [8..11] v_colour channels.
+// v_rec layout mirrors rec: [0] s_x [1] s_y [2] v_opacity | [4] v_ca [5] v_cb [6] v_cc | [8..11] v_colour channels,
+// where (s_x, s_y) = sum over pixels of v_sigma * (mean2d - pixel): the raster backward leaves the multiplication by the
+// conic, v_mean2d = conic (s_x, s_y)^T, to this kernel (once per Gaussian instead of once per (splat, pixel)).
 // cam_grad[16]: v_R (9, row-major) | v_t (3) | v_campos (3) | pad, accumulated with atomics.
 template <int SH_DEG, bool FUSE_ADAM>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 
         const float4* vr = reinterpret_cast<const float4*>(v_rec) + 3 * (int64_t)g;
         const float4 g0 = vr[0], g1 = vr[1], g2 = vr[2];
-        const float v_mx = g0.x, v_my = g0.y, v_op = g0.z;
+        const float v_mx = P.ca * g0.x + P.cb * g0.y, v_my = P.cb * g0.x + P.cc * g0.y, v_op = g0.z;
         const float v_ca = g1.x, v_cb = g1.y, v_cc = g1.z;
         float v_col[3] = {g2.x, g2.y, g2.z};
         float v_depth = g2.w;

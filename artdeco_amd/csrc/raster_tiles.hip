@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // ---------------------------------------------------------------------------------- backward
-// Accumulator slots per splat: 0,1 v_mean2d | 2 v_opacity | 3,4,5 v_conic | 6..9 v_colour
+// Accumulator slots per splat: 0,1 sum v_sigma*(mean2d - pixel) (-> v_mean2d in project_bwd) | 2 v_opacity | 3,4,5 v_conic | 6..9 v_colour
 #define NACC 10
 __device__ __forceinline__ int acc_to_rec(int k) { return k < 3 ? k : (k < 6 ? k + 1 : k + 2); }
 
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     const float gop = (ov <= MAX_ALPHA) ? vis * v_alpha : 0.f; // clamped alpha passes no gradient
                     const float v_sigma = -opac * gop;
                     const float t1 = v_sigma * dx, t2 = v_sigma * dy;
-                    acc[0] += cn.x * t1 + cn.y * t2;   // v_mean2d.x
-                    acc[1] += cn.y * t1 + cn.z * t2;   // v_mean2d.y
+                    acc[0] += t1;                      // v_mean2d = conic (acc[0], acc[1])^T is formed by project_bwd,
+                    acc[1] += t2;                      //   once per Gaussian instead of once per (splat, pixel)
                     acc[2] += gop;                     // v_opacity
                     acc[3] += t1 * dx;                 // 2 * v_conic.a
                     acc[4] += t1 * dy;                 // v_conic.b

@@ -102,7 +102,9 @@ int adk_adam_update_multi(int n, float* const* params, const float* const* grads
  * Packed per-Gaussian "splat record" rec[N][12] (three float4, 16 B aligned):
  *   [0] mean2d.x [1] mean2d.y [2] opacity [3] radius_x | [4..6] conic a,b,c [7] radius_y |
  *   [8..11] colour channels (color_mode 0/1: r,g,b,depth; 2: depth,0,0,0)
- * Gradient record v_rec[N][12] mirrors it ([2] = v_opacity, [3],[7] unused).
+ * Gradient record v_rec[N][12] mirrors it ([2] = v_opacity, [3],[7] unused), except that slots
+ * [0],[1] carry s = sum over pixels of v_sigma * (mean2d - pixel); adk_project_bwd forms
+ * v_mean2d = conic * s itself (once per Gaussian instead of once per (splat, pixel)).
  */
 
 /* Replaces fully_fused_projection fwd + spherical_harmonics fwd + the counting half of
