@@ -322,8 +322,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     const float v_alpha = P.T * S1 + ra * (P.C0 - P.bdot);
                     P.bdot += fac * S1;
                     const float gop = (ov <= MAX_ALPHA) ? vis * v_alpha : 0.f; // clamped alpha passes no gradient
-                    const float v_sigma = -opac * gop;
-                    const float t1 = v_sigma * dx, t2 = v_sigma * dy;
+                    const float t1 = gop * dx, t2 = gop * dy; // v_sigma = -opac * gop: the factor -opac is applied after the reduction
                     acc[0] += t1;                      // v_mean2d = conic (acc[0], acc[1])^T is formed by project_bwd,
                     acc[1] += t2;                      //   once per Gaussian instead of once per (splat, pixel)
                     acc[2] += gop;                     // v_opacity
@@ -336,10 +335,13 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             // ONE 64-lane reduction per (splat, tile): transposing butterfly (11 DPP ops instead of 60), after
             // which 10 lanes of row 0 each own one total and publish it with a single atomic instruction
             if (!touched) continue; // every sum is zero: no reduction, no atomics
-            acc[3] *= 0.5f; acc[5] *= 0.5f;
             const Reduce10 red = wave_reduce10(acc, lane);
-            if (red.is_owner && red.value != 0.f)
-                unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[t] + acc_to_rec(red.slot), red.value);
+            // per-splat factors of the sums, applied once by the owner lane: -opac on the v_sigma-weighted slots
+            // (0,1,3,4,5), and the 1/2 of the symmetric conic entries (3,5)
+            const float scale = (red.slot == 2 || red.slot >= 6) ? 1.0f : ((red.slot == 3 || red.slot == 5) ? -0.5f * opac : -opac);
+            const float total = red.value * scale;
+            if (red.is_owner && total != 0.f)
+                unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[t] + acc_to_rec(red.slot), total);
         }
     }
 }
