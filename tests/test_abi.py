@@ -49,3 +49,27 @@ def test_cpu_tensor_is_rejected_loudly():
     from fused_ssim import fused_ssim
     with pytest.raises(_lib.AdkError):
         fused_ssim(torch.rand(1, 3, 16, 16), torch.rand(1, 3, 16, 16))
+
+
+def test_argument_validation_returns_error_codes_without_touching_the_gpu(lib):
+    """Every entry point rejects bad arguments (negative sizes, NULL where data is required, unsupported shapes)
+    with a negative adk error code BEFORE any HIP call, so these calls are safe on a machine without a GPU."""
+    EINVAL, EUNSUPPORTED = -1, -3
+    N = None  # NULL
+    assert lib.adk_scatter_argmax(-1, N, 2, N, 4, 0, N, N, N) == EINVAL
+    assert lib.adk_scatter_argmax(4, N, 2, N, 4, 0, N, N, N) == EINVAL            # out / arg missing
+    assert lib.adk_gauss_newton(7, 2, 1, 8, N, N, N, N, N, N, N, N, N, 0, 0, 0, 0.0, 1.0, 1.0, 0.0, 0.0, 10, 1e-8, 1,
+                                N, N, N, N, 0, N) == EINVAL                        # unknown factor kind
+    assert lib.adk_gauss_newton(1, 1, 0, 8, N, N, N, N, N, N, N, N, N, 0, 0, 0, 0.0, 1.0, 1.0, 0.0, 0.0, 10, 1e-8, 1,
+                                N, N, N, N, 0, N) == 0                             # nothing to optimise: one pose, fixed
+    assert lib.adk_gn_workspace_bytes(-1, 0, 0) == EINVAL and lib.adk_gn_workspace_bytes(16, 54, 196608) > 0
+    assert lib.adk_photometric_workspace_bytes(-1, 4) == EINVAL and lib.adk_photometric_workspace_bytes(1920, 1080) > 0
+    assert lib.adk_photometric_fwd(-1, 4, N, N, N, N, N, N, N, 0, N, N, N, N, 0, N) == EINVAL
+    assert lib.adk_pose6d_fwd(N, N, N, N) == EINVAL and lib.adk_pose6d_bwd(N, N, N, N, N) == EINVAL
+    assert lib.adk_visibility_masks(-1, N, N, 0, N, N, N) == EINVAL
+    assert lib.adk_bin_count_isects(-1, N, N, N) == EINVAL
+    assert lib.adk_lod_params_bwd_workspace_bytes(-1) == EINVAL
+    assert lib.adk_lod_params_fwd(8, N, N, N, N, N, N, N, N, 8, 8, 32, N, N, N, N, N, N, N, N, N, N) == EUNSUPPORTED  # only 16+16 features
+    assert lib.adk_project_bwd_adam(8, N, N, N, N, N, 16, 3, N, N, 64, 64, 0.01, 0.01, 1e10, 0, N, N, N, N, N, N, N, N,
+                                    N, N, N, N, N, N, 0.5, 0.99, 1e-15, N) == EINVAL
+    assert lib.adk_rope_2d(N, N, 1, 1, 4, 0, 0, 2, 6, 100.0, 1.0, N) == EINVAL     # D must be a multiple of 4
