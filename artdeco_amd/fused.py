@@ -487,6 +487,87 @@ def fused_optimization_step(self, is_important=True, finetuning=False):
     self.last_trained_id = keyframe_id
 
 
+def fused_add_and_prune(self, extension_tensors, valid_mask):
+    """Drop-in body for SparseGaussianAdam.add_and_prune (Reconstruct/scene/optimizers.py:163-219): every
+    `torch.cat([x[valid_mask], extension])` of the parameters, both moments and the per-element learning rates in ONE
+    kernel launch after one scan of the mask (the reference evaluates the boolean index ~40 times, each a host sync).
+    `global_feat` (extended, never pruned) keeps the reference's own two-line path."""
+    import ctypes
+    import struct
+    lib = _lib.load()
+    keys = [k for k in self.params if k in extension_tensors and k != "global_feat"]
+    if "global_feat" in extension_tensors and "global_feat" in self.params:
+        param, ext = self.params["global_feat"], extension_tensors["global_feat"]
+        empty = ext.numel() == 0 or ext.dim() == 0
+        param["val"] = param["val"].detach().contiguous() if empty else torch.cat([param["val"].detach(), ext], dim=0).contiguous()
+        param["val"].requires_grad = True
+        param["exp_avg"] = torch.cat([param["exp_avg"], torch.zeros_like(ext)], dim=0).contiguous()
+        param["exp_avg_sq"] = torch.cat([param["exp_avg_sq"], torch.zeros_like(ext)], dim=0).contiguous()
+        if "global_feat" in self.lr_dict:
+            param["lr"] = torch.cat([param["lr"], torch.ones_like(ext) * self.lr_dict["global_feat"]["lr_init"]], dim=0).contiguous()
+    if not keys:
+        return
+    dev = self.params[keys[0]]["val"].device
+    N = self.params[keys[0]]["val"].shape[0]
+    mask = valid_mask.to(dev).contiguous()
+    if mask.dtype != torch.bool or mask.numel() != N:
+        raise ValueError("valid_mask must be a bool tensor with one entry per Gaussian")
+    E = None
+    jobs = []  # (dict to store into, key in that dict, src tensor, ext tensor or None, fill bits, requires_grad)
+    for key in keys:
+        param, ext = self.params[key], extension_tensors[key]
+        has_ext = not (ext.numel() == 0 or ext.dim() == 0)
+        if has_ext:
+            if E is None:
+                E = ext.shape[0]
+            elif ext.shape[0] != E:
+                raise ValueError("extension tensors must all add the same number of rows")
+        meta_only = key in ("id", "cls_id", "d_max")
+        jobs.append((param, "val", param["val"].detach(), ext if has_ext else None, 0, not meta_only))
+        if meta_only:
+            continue
+        jobs.append((param, "exp_avg", param["exp_avg"], None, 0, False))
+        jobs.append((param, "exp_avg_sq", param["exp_avg_sq"], None, 0, False))
+        if key in self.lr_dict:
+            bits = struct.unpack("<I", struct.pack("<f", float(self.lr_dict[key]["lr_init"])))[0]
+            jobs.append((param, "lr", param["lr"], None, bits, False))
+    E = E or 0
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ws = torch.empty(int(lib.adk_compact_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+        n_keep_dev = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.adk_compact_plan(N, mask.data_ptr(), n_keep_dev.data_ptr(), ws.data_ptr(), ws.numel(), st), "adk_compact_plan")
+        K = int(n_keep_dev.item())  # the one host read: sizes every output
+        srcs, exts, dsts, fills, words, outs = [], [], [], [], [], []
+        for store, name, src, ext, bits, _rg in jobs:
+            src = src.contiguous()
+            if src.shape[0] != N or src.element_size() not in (4, 8):
+                raise ValueError(f"add_and_prune: unexpected tensor for {name}: shape {tuple(src.shape)}, dtype {src.dtype}")
+            row_words = (src.numel() // max(N, 1)) * (src.element_size() // 4) if N > 0 else int(torch.tensor(src.shape[1:]).prod()) * (src.element_size() // 4)
+            e = None
+            if ext is not None:
+                e = ext.to(device=dev, dtype=src.dtype).contiguous()
+                if e.shape[1:] != src.shape[1:]:
+                    raise ValueError("extension tensor does not match the parameter's row shape")
+            # appended rows of a tensor without an extension (moments, lr) exist only when some parameter is extended
+            n_app = E if (e is not None or name != "val") else 0
+            out = torch.empty((K + n_app,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
+            srcs.append(src); exts.append(e); dsts.append(out); fills.append(bits); words.append(max(row_words, 1)); outs.append((store, name, out, _rg, n_app))
+        # tensors that append nothing take part with E = 0 in a second call; the common case is a single call
+        for group_E in sorted({o[4] for o in outs}, reverse=True):
+            idx = [i for i, o in enumerate(outs) if o[4] == group_E]
+            n = len(idx)
+            VP, U32, I32 = ctypes.c_void_p * n, ctypes.c_uint32 * n, ctypes.c_int * n
+            rc = lib.adk_compact_apply(n, VP(*[srcs[i].data_ptr() for i in idx]), VP(*[(exts[i].data_ptr() if exts[i] is not None else None) for i in idx]),
+                                       VP(*[dsts[i].data_ptr() for i in idx]), U32(*[fills[i] for i in idx]), I32(*[words[i] for i in idx]),
+                                       N, group_E, mask.data_ptr(), n_keep_dev.data_ptr(), ws.data_ptr(), st)
+            _lib.check(rc, "adk_compact_apply")
+        for store, name, out, rg, _ in outs:
+            store[name] = out
+            if rg:
+                out.requires_grad = True
+
+
 def patch_scene_model(scene) -> bool:
     """Install fused_render on this scene-model instance (ARTDECO's SceneModel or artdeco_amd.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
@@ -501,6 +582,9 @@ def patch_scene_model(scene) -> bool:
     if opt is not None and hasattr(opt, "lr_dict") and hasattr(opt, "params"):
         opt._unfused_step = opt.step
         opt.step = types.MethodType(fused_optimizer_step, opt)
+        if hasattr(opt, "add_and_prune"):
+            opt._unfused_add_and_prune = opt.add_and_prune
+            opt.add_and_prune = types.MethodType(fused_add_and_prune, opt)
     if hasattr(scene, "optimization_step") and hasattr(scene, "lambda_dssim") and hasattr(scene, "rad_decay"):
         scene._unfused_optimization_step = scene.optimization_step
         body = fused_optimization_step if hasattr(scene, "get_training_id") else fused_optimization_step_mirror

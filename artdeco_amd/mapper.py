@@ -61,6 +61,33 @@ class BaseAdam:
 _NO_OPT = ("id", "cls_id", "d_max")
 
 
+def _add_and_prune(self, extension_tensors, valid_mask):
+    """scene/optimizers.py:163-219 restated: prune rows by `valid_mask`, append the extension rows, for every parameter,
+    its two moments and (keys in lr_dict) its per-element learning rate; `global_feat` is extended but never pruned."""
+    for key, param in self.params.items():
+        if key not in extension_tensors:
+            continue
+        ext = extension_tensors[key]
+        empty = ext.numel() == 0 or ext.dim() == 0
+        if key == "global_feat":
+            param["val"] = param["val"].detach().contiguous() if empty else torch.cat([param["val"].detach(), ext], dim=0).contiguous()
+            param["val"].requires_grad = True
+            param["exp_avg"] = torch.cat([param["exp_avg"], torch.zeros_like(ext)], dim=0).contiguous()
+            param["exp_avg_sq"] = torch.cat([param["exp_avg_sq"], torch.zeros_like(ext)], dim=0).contiguous()
+            if key in self.lr_dict:
+                param["lr"] = torch.cat([param["lr"], torch.ones_like(ext) * self.lr_dict[key]["lr_init"]], dim=0).contiguous()
+            continue
+        kept = param["val"].detach()[valid_mask]
+        param["val"] = kept.contiguous() if empty else torch.cat([kept, ext], dim=0).contiguous()
+        if key in ("id", "cls_id", "d_max"):
+            continue
+        param["val"].requires_grad = True
+        param["exp_avg"] = torch.cat([param["exp_avg"][valid_mask], torch.zeros_like(ext)], dim=0).contiguous()
+        param["exp_avg_sq"] = torch.cat([param["exp_avg_sq"][valid_mask], torch.zeros_like(ext)], dim=0).contiguous()
+        if key in self.lr_dict:
+            param["lr"] = torch.cat([param["lr"][valid_mask], torch.ones_like(ext) * self.lr_dict[key]["lr_init"]], dim=0).contiguous()
+
+
 class SparseGaussianAdam(BaseAdam):
     """scene/optimizers.py:59-161: visibility-gated Adam; lr is a 0-dim device tensor, or a
     per-element tensor for keys in lr_dict (xyz), python floats for the mlp_* entries."""
@@ -76,6 +103,8 @@ class SparseGaussianAdam(BaseAdam):
                 p["lr"] = torch.tensor(p["lr"], dtype=torch.float, device=device)
             else:
                 p["lr"] = torch.ones_like(p["val"]) * self.lr_dict[key]["lr_init"]
+
+    add_and_prune = torch.no_grad()(_add_and_prune)
 
     @torch.no_grad()
     def step(self, visibility, N, global_visibility, N_global):

@@ -339,6 +339,21 @@ int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_points, flo
                      float* Hs_dbg, float* gs_dbg, void* workspace, int64_t workspace_bytes,
                      adk_stream_t stream);
 
+/* ------------------------------------------------------- prune-and-append
+ * Replaces the body of SparseGaussianAdam.add_and_prune (Reconstruct/scene/optimizers.py:163-219; called on
+ * every important frame, h3dgsv3.py:938 and :953): `torch.cat([x[valid_mask], extension])` for every
+ * parameter, both Adam moments and the per-element learning rate -- ~40 boolean-index host syncs and ~100
+ * launches there; one mask scan, one host read (the kept count, to size the outputs) and ONE launch here.
+ * adk_compact_plan: keep [N] bytes (torch.bool) -> *n_keep (int64, device) and a plan in the workspace.
+ * adk_compact_apply: dst[t] [K+E, words[t]] = concat(src[t][keep] (order preserved), ext[t] or E rows of
+ * fill_bits[t]) for t < n_tensors <= 48; words[t] = 4-byte words per row (2 per int64 element); host arrays. */
+int64_t adk_compact_workspace_bytes(int64_t N);
+int adk_compact_plan(int64_t N, const uint8_t* keep, int64_t* n_keep, void* workspace, int64_t workspace_bytes,
+                     adk_stream_t stream);
+int adk_compact_apply(int n_tensors, const void* const* src, const void* const* ext, void* const* dst,
+                      const uint32_t* fill_bits, const int* words, int64_t N, int64_t E, const uint8_t* keep,
+                      const int64_t* n_keep, const void* workspace, adk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
