@@ -425,6 +425,50 @@ __global__ __launch_bounds__(1024) void lod_reduce_partials_kernel(const float* 
     }
 }
 
+// ---- weed_out_gaussians (h3dgsv3.py:942-953): in how many keyframes is each Gaussian inside its LoD range? -------
+// The reference loops over every keyframe of the map in Python: a 4x4 torch.inverse, a [N,3] subtraction, a norm, a
+// compare and an integer add per keyframe -- five full passes over the Gaussians (and a small LU) times the number
+// of keyframes, on every important frame.  Here: one kernel; a workgroup turns up to 256 keyframe poses (6D rotation
+// + translation, scene/keyframe.py:150-154) into camera centres in LDS and every thread tests its Gaussian against
+// them, so the Gaussians are read once per 256 keyframes.
+#define LOD_KF_CHUNK 256
+__global__ __launch_bounds__(256) void lod_visible_count_kernel(int N, const float* __restrict__ xyz, const float* __restrict__ d_max,
+                                                                int n_kf, const float* __restrict__ r6 /* [n_kf,3,2] */,
+                                                                const float* __restrict__ t /* [n_kf,3] */, int* __restrict__ counts)
+{
+    __shared__ float cen[LOD_KF_CHUNK][3];
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float x = 0.f, y = 0.f, z = 0.f, lim = -1.f;
+    if (g < N) { x = xyz[3 * g]; y = xyz[3 * g + 1]; z = xyz[3 * g + 2]; lim = 2.f * d_max[g]; }
+    int cnt = 0;
+    for (int k0 = 0; k0 < n_kf; k0 += LOD_KF_CHUNK) {
+        const int nk = min(LOD_KF_CHUNK, n_kf - k0);
+        __syncthreads();
+        if ((int)threadIdx.x < nk) { // camera centre -R^T t with R = sixD2mtx(rW2C) (utils.py:223-229)
+            const float* r = r6 + (int64_t)(k0 + threadIdx.x) * 6;
+            const float* tt = t + (int64_t)(k0 + threadIdx.x) * 3;
+            float a1[3] = {r[0], r[2], r[4]}, a2[3] = {r[1], r[3], r[5]};
+            const float n1 = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+            float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+            const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+            float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+            const float nu = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            float b2[3] = {u[0] / nu, u[1] / nu, u[2] / nu};
+            float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+            // R = [b1 b2 b3] (columns); centre = -R^T t: component c = -(column c of R) . t
+            cen[threadIdx.x][0] = -(b1[0] * tt[0] + b1[1] * tt[1] + b1[2] * tt[2]);
+            cen[threadIdx.x][1] = -(b2[0] * tt[0] + b2[1] * tt[1] + b2[2] * tt[2]);
+            cen[threadIdx.x][2] = -(b3[0] * tt[0] + b3[1] * tt[1] + b3[2] * tt[2]);
+        }
+        __syncthreads();
+        for (int k = 0; k < nk; ++k) {
+            const float dx = x - cen[k][0], dy = y - cen[k][1], dz = z - cen[k][2];
+            cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < lim) ? 1 : 0;
+        }
+    }
+    if (g < N) counts[g] = cnt;
+}
+
 } // namespace adk
 
 extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
@@ -479,5 +523,18 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, v_mlp);
+    ADK_RETURN_LAST_ERROR();
+}
+
+// counts[g] = number of keyframes k with |xyz[g] - centre_k| < 2 d_max[g], centre_k = -R_k^T t_k,
+// R_k = sixD2mtx(r6[k]) -- the loop of weed_out_gaussians (h3dgsv3.py:943-950) for all keyframes at once.
+extern "C" int adk_lod_visible_count(int N, const float* xyz, const float* d_max, int n_keyframes, const float* r6,
+                                     const float* t, int32_t* counts, hipStream_t stream)
+{
+    if (N < 0 || n_keyframes < 0) return ADK_EINVAL;
+    if (N == 0) return 0;
+    if (!xyz || !d_max || !counts || (n_keyframes > 0 && (!r6 || !t))) return ADK_EINVAL;
+    hipLaunchKernelGGL(adk::lod_visible_count_kernel, dim3((unsigned)adk::ceil_div(N, 256)), dim3(256), 0, stream, N, xyz, d_max,
+                       n_keyframes, r6, t, counts);
     ADK_RETURN_LAST_ERROR();
 }

@@ -568,6 +568,33 @@ def fused_add_and_prune(self, extension_tensors, valid_mask):
                 out.requires_grad = True
 
 
+def lod_visible_count(xyz, d_max, keyframes, device):
+    """counts [N] int32: in how many keyframes each Gaussian is within its LoD range (h3dgsv3.py:943-950), one launch."""
+    lib = _lib.load()
+    N, n_kf = xyz.shape[0], len(keyframes)
+    with torch.cuda.device(device):
+        counts = torch.zeros(N, dtype=torch.int32, device=device)
+        if N == 0 or n_kf == 0:
+            return counts
+        r6 = torch.stack([kf.rW2C.detach().to(device, non_blocking=True) for kf in keyframes]).float().contiguous()
+        t = torch.stack([kf.tW2C.detach().to(device, non_blocking=True) for kf in keyframes]).float().contiguous()
+        xyz_c, dm = xyz.detach().float().contiguous(), d_max.detach().float().contiguous()
+        rc = lib.adk_lod_visible_count(N, xyz_c.data_ptr(), dm.data_ptr(), n_kf, r6.data_ptr(), t.data_ptr(), counts.data_ptr(),
+                                       torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(rc, "adk_lod_visible_count")
+    return counts
+
+
+def fused_weed_out_gaussians(self):
+    """Drop-in body for SceneModel.weed_out_gaussians (h3dgsv3.py:942-953): same mask, one kernel over all keyframes
+    instead of five full passes over the Gaussians (and a 4x4 torch.inverse) per keyframe."""
+    counts = lod_visible_count(self.xyz, self.d_max, self.keyframes, self.device)
+    visible_count = counts / len(self.keyframes)
+    thr = self.args.visible_threshold if hasattr(self, "args") else self.visible_threshold
+    weed_mask = visible_count > thr
+    self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
+
+
 def patch_scene_model(scene) -> bool:
     """Install fused_render on this scene-model instance (ARTDECO's SceneModel or artdeco_amd.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
@@ -589,4 +616,7 @@ def patch_scene_model(scene) -> bool:
         scene._unfused_optimization_step = scene.optimization_step
         body = fused_optimization_step if hasattr(scene, "get_training_id") else fused_optimization_step_mirror
         scene.optimization_step = types.MethodType(body, scene)
+    if hasattr(scene, "weed_out_gaussians") and hasattr(scene, "make_dummy_ext_tensor"):
+        scene._unfused_weed_out_gaussians = scene.weed_out_gaussians
+        scene.weed_out_gaussians = types.MethodType(fused_weed_out_gaussians, scene)
     return True

@@ -93,11 +93,11 @@ class SparseGaussianAdam(BaseAdam):
     per-element tensor for keys in lr_dict (xyz), python floats for the mlp_* entries."""
 
     def __init__(self, params, betas=(0.9, 0.999), eps=1e-15, lr_dict=None, device="cuda:0"):
-        super().__init__({k: v for k, v in params.items() if k not in _NO_OPT}, betas, eps)
+        super().__init__(params, betas, eps)  # the reference keeps id / cls_id / d_max in the same dict (optimizers.py:61-68)
         self.all_params = params
         self.lr_dict = lr_dict or {}
         for key, p in self.params.items():
-            if key.startswith("mlp"):
+            if key in _NO_OPT or key.startswith("mlp"):
                 continue
             if key not in self.lr_dict:
                 p["lr"] = torch.tensor(p["lr"], dtype=torch.float, device=device)
@@ -110,6 +110,8 @@ class SparseGaussianAdam(BaseAdam):
     def step(self, visibility, N, global_visibility, N_global):
         b1, b2 = self.betas
         for key, p in self.params.items():
+            if key in _NO_OPT:
+                continue
             v = p["val"]
             if v.grad is None:
                 continue
@@ -303,6 +305,27 @@ class MapperScene:
         pkg["render"] = (kf.exposure[:3, :3] @ pkg["render"].view(3, -1)) + kf.exposure[:3, 3, None]
         pkg["render"] = pkg["render"].clamp(0, 1).view(3, height, width)
         return pkg
+
+    # -- weed_out_gaussians: h3dgsv3.py:942-953 (+ make_dummy_ext_tensor :750-763) ------------------------------------
+    visible_threshold = 0.0  # run.sh --visible_threshold 0
+
+    def make_dummy_ext_tensor(self):
+        P = self.gaussian_params
+        keys = ("cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "local_feat", "global_feat")
+        return {k: P[k]["val"][:0].detach() for k in keys}
+
+    @torch.no_grad()
+    def weed_out_gaussians(self):
+        visible_count = torch.zeros(self.xyz.shape[0], dtype=torch.int, device=self.device)
+        for keyframe in self.keyframes:
+            view_matrix = keyframe.get_Rt().transpose(0, 1).to(self.device)
+            cam_centre = view_matrix.detach().inverse()[3, :3].to(self.device)
+            ob_dist = (self.xyz - cam_centre).norm(dim=1, keepdim=True)
+            selection_mask = (ob_dist < 2 * self.d_max).squeeze(-1)
+            visible_count += selection_mask.int()
+        visible_count = visible_count / len(self.keyframes)
+        weed_mask = visible_count > self.visible_threshold
+        self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
 
     def _rdk_for(self, h, w):
         key = (h, w)

@@ -260,6 +260,12 @@ int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_raw, const 
                        float* v_local_feat, float* v_global_feat, float* v_mlp, void* workspace,
                        int64_t workspace_bytes, adk_stream_t stream);
 
+/* Replaces the per-keyframe loop of SceneModel.weed_out_gaussians (h3dgsv3.py:943-950): counts[g] = number of
+ * keyframes whose camera centre -R^T t (R = sixD2mtx(r6[k]), r6 [n_kf,3,2], t [n_kf,3]) lies within 2 d_max[g]
+ * of xyz[g].  One launch for all keyframes. */
+int adk_lod_visible_count(int N, const float* xyz, const float* d_max, int n_keyframes, const float* r6,
+                          const float* t, int32_t* counts, adk_stream_t stream);
+
 /* Replaces the exposure correction of SceneModel.render_from_id (h3dgsv3.py:611-614):
  * out[3,P] = clamp(E[:3,:3] @ img[3,P] + E[:3,3,None], 0, 1), E [3,4] row-major (device). */
 int adk_exposure_fwd(const float* E, const float* img, int64_t P, float* out, adk_stream_t stream);

@@ -76,3 +76,45 @@ def test_patch_installs_add_and_prune(dev):
     sc = _scene(dev, N=2000, seed=2)
     assert fused.patch_scene_model(sc)
     assert sc.optimizer.add_and_prune.__func__ is fused.fused_add_and_prune
+
+
+@pytest.mark.gpu
+def test_fused_weed_out_gaussians_matches_the_keyframe_loop(dev):
+    """adk_lod_visible_count over all keyframes == the reference's per-keyframe torch loop (h3dgsv3.py:943-950), and the
+    patched weed_out_gaussians prunes the same Gaussians (every parameter, moment and learning rate)."""
+    from artdeco_amd import fused
+    from tests.test_fused_glue import _scene
+    a, b = _scene(dev, N=30_000, seed=4), _scene(dev, N=30_000, seed=4)
+    g = torch.Generator().manual_seed(0)
+    for sc in (a, b):
+        with torch.no_grad():  # LoD ranges such that a good part of the cloud is out of range of every keyframe
+            sc.gaussian_params["d_max"]["val"].copy_((0.8 + 2.5 * torch.rand(30_000, 1, generator=torch.Generator().manual_seed(1))).to(dev))
+        for k in range(40):    # 42 keyframes: more than one would ever unroll by hand, fewer than one LDS chunk
+            Rt = torch.eye(4)
+            Rt[:3, 3] = torch.randn(3, generator=g) * (0.5 if sc is a else 0.0)
+            sc.add_keyframe(type(sc.keyframes[0])(sc.keyframes[0].image_pyr[0], sc.keyframes[0].idepth_pyr[0], Rt.to(dev), dev))
+    for ka, kb in zip(a.keyframes, b.keyframes):  # same poses in both scenes
+        with torch.no_grad():
+            kb.rW2C.copy_(ka.rW2C); kb.tW2C.copy_(ka.tW2C)
+    # counts
+    ref = torch.zeros(30_000, dtype=torch.int, device=dev)
+    for kf in a.keyframes:
+        c = kf.get_Rt().transpose(0, 1).detach().inverse()[3, :3]
+        ref += ((a.xyz - c).norm(dim=1, keepdim=True) < 2 * a.d_max).squeeze(-1).int()
+    got = fused.lod_visible_count(a.xyz, a.d_max, a.keyframes, dev)
+    assert float((got != ref).float().mean()) <= 1e-4 and int((got - ref).abs().max()) <= 1  # only exactly-on-the-boundary cases
+    assert 0.05 < float((ref == 0).float().mean()) < 0.95
+    # end to end
+    assert fused.patch_scene_model(b)
+    a.weed_out_gaussians()
+    b.weed_out_gaussians()
+    na, nb = a.xyz.shape[0], b.xyz.shape[0]
+    assert abs(na - nb) <= 3 and na < 30_000
+    if na == nb:
+        for k in ("xyz", "f_rest", "cls_id", "d_max"):
+            assert torch.equal(a.gaussian_params[k]["val"], b.gaussian_params[k]["val"]), k
+        assert torch.equal(a.gaussian_params["xyz"]["exp_avg_sq"], b.gaussian_params["xyz"]["exp_avg_sq"])
+        assert torch.equal(a.gaussian_params["xyz"]["lr"], b.gaussian_params["xyz"]["lr"])
+    # the scene still trains after pruning
+    torch.manual_seed(0)
+    assert torch.isfinite(b.optimization_step(0))

@@ -201,9 +201,11 @@ def test_fused_optimizer_step_is_bit_identical(dev):
     vis = torch.rand(6000, device=dev) < 0.6
     gvis = torch.rand(a.global_feat.shape[0], device=dev) < 0.5
 
+    meta = ("id", "cls_id", "d_max")  # carried in the optimiser's dict like the reference does, never stepped
+
     def snapshot(opt):
         return {k: [v["val"].detach().clone(), v["exp_avg"].clone(), v["exp_avg_sq"].clone(),
-                    (v["lr"].clone() if torch.is_tensor(v["lr"]) else float(v["lr"]))] for k, v in opt.params.items()}
+                    (v["lr"].clone() if torch.is_tensor(v["lr"]) else float(v["lr"]))] for k, v in opt.params.items() if k not in meta}
 
     def restore(opt, snap):
         with torch.no_grad():
