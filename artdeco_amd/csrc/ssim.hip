@@ -14,8 +14,8 @@
 //   * vertical 11-tap pass: an 11-row ring of the 5 (fwd) / 3 (bwd) horizontal
 //     sums lives in VGPRs (loop unrolled by 11 so every ring index is static);
 //     no second LDS round trip, no 26x16x5 scratch tile as in the reference.
-//   * all global loads/stores are 64-lane row-contiguous (256 B) and the next
-//     input row is prefetched into registers while the current one is reduced.
+//   * all global loads/stores are 64-lane row-contiguous (256 B) and input rows
+//     are prefetched into registers two iterations ahead of their use.
 //
 // HBM traffic per pixel-channel: fwd(train) 8 B in + 16 B out, bwd 24 B in +
 // 4 B out (+ halo re-reads that hit L2).  Roofline: HBM.
@@ -64,17 +64,21 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(
 
     constexpr int NROWS = RH + 2 * SSIM_HALO;
 
-    // prefetch row 0
-    float a1, a2, b1, b2;
-    {
-        const int r = y0 - SSIM_HALO;
-        const bool rok = (r >= 0) && (r < H);
+    // Rows are fetched TWO iterations ahead of their use: one wavefront keeps only a handful of 256 B loads in flight,
+    // and with a one-row lead every row waited most of an HBM round trip (the kernel ran at 1.5 TB/s).
+    float a1, a2, b1, b2;     // row i   (written to the row buffer this iteration)
+    float n1, n2, m1, m2;     // row i+1 (in flight or landed)
+    auto fetch_row = [&](int i, float& r1, float& r2, float& e1, float& e2) {
+        const int r = y0 - SSIM_HALO + i;
+        const bool rok = (r >= 0) && (r < H) && (i < NROWS);
         const int64_t off = (int64_t)r * W;
-        a1 = (rok && xa_ok) ? p1[off + xa] : 0.f;
-        a2 = (rok && xa_ok) ? p2[off + xa] : 0.f;
-        b1 = (rok && xb_ok) ? p1[off + xb] : 0.f;
-        b2 = (rok && xb_ok) ? p2[off + xb] : 0.f;
-    }
+        r1 = (rok && xa_ok) ? p1[off + xa] : 0.f;
+        r2 = (rok && xa_ok) ? p2[off + xa] : 0.f;
+        e1 = (rok && xb_ok) ? p1[off + xb] : 0.f;
+        e2 = (rok && xb_ok) ? p2[off + xb] : 0.f;
+    };
+    fetch_row(0, a1, a2, b1, b2);
+    fetch_row(1, n1, n2, m1, m2);
 
     for (int base = 0; base < NROWS; base += 11) {
 #pragma unroll
@@ -89,16 +93,9 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(
                     rowbuf[par][0][64 + lane] = b1;
                     rowbuf[par][1][64 + lane] = b2;
                 }
-                // prefetch next row while this one is being reduced
-                {
-                    const int r = y0 - SSIM_HALO + i + 1;
-                    const bool rok = (r >= 0) && (r < H) && (i + 1 < NROWS);
-                    const int64_t off = (int64_t)r * W;
-                    a1 = (rok && xa_ok) ? p1[off + xa] : 0.f;
-                    a2 = (rok && xa_ok) ? p2[off + xa] : 0.f;
-                    b1 = (rok && xb_ok) ? p1[off + xb] : 0.f;
-                    b2 = (rok && xb_ok) ? p2[off + xb] : 0.f;
-                }
+                // rotate the prefetch queue and fetch row i+2 while this one is being reduced
+                a1 = n1; a2 = n2; b1 = m1; b2 = m2;
+                fetch_row(i + 2, n1, n2, m1, m2);
                 __syncthreads();
 
                 // horizontal 11-tap pass (pairs around the centre, as ssim.cu:134-158)
@@ -206,22 +203,23 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(
     float win[11][3];
     constexpr int NROWS = RH + 2 * SSIM_HALO;
 
-    // fused (dm_d* x dL_dmap) products for one row, main + extra slot
-    float fa[3], fb[3];
-    auto fetch = [&](int i) {
+    // fused (dm_d* x dL_dmap) products for one row, main + extra slot; fetched two rows ahead of their use
+    float fa[3], fb[3], na[3], nb[3];
+    auto fetch = [&](int i, float* ra, float* rb) {
         const int r = y0 - SSIM_HALO + i;
         const bool rok = (r >= 0) && (r < H) && (i < NROWS);
         const int64_t off = plane + (int64_t)r * W;
         if (rok && xa_ok) {
             const float c = dL_dmap ? dL_dmap[off + xa] : dL_scalar;
-            fa[0] = dm_dmu1[off + xa] * c; fa[1] = dm_dsigma1_sq[off + xa] * c; fa[2] = dm_dsigma12[off + xa] * c;
-        } else { fa[0] = fa[1] = fa[2] = 0.f; }
+            ra[0] = dm_dmu1[off + xa] * c; ra[1] = dm_dsigma1_sq[off + xa] * c; ra[2] = dm_dsigma12[off + xa] * c;
+        } else { ra[0] = ra[1] = ra[2] = 0.f; }
         if (rok && xb_ok) {
             const float c = dL_dmap ? dL_dmap[off + xb] : dL_scalar;
-            fb[0] = dm_dmu1[off + xb] * c; fb[1] = dm_dsigma1_sq[off + xb] * c; fb[2] = dm_dsigma12[off + xb] * c;
-        } else { fb[0] = fb[1] = fb[2] = 0.f; }
+            rb[0] = dm_dmu1[off + xb] * c; rb[1] = dm_dsigma1_sq[off + xb] * c; rb[2] = dm_dsigma12[off + xb] * c;
+        } else { rb[0] = rb[1] = rb[2] = 0.f; }
     };
-    fetch(0);
+    fetch(0, fa, fb);
+    fetch(1, na, nb);
 
     for (int base = 0; base < NROWS; base += 11) {
 #pragma unroll
@@ -235,7 +233,9 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(
 #pragma unroll
                     for (int q = 0; q < 3; ++q) rowbuf[par][q][64 + lane] = fb[q];
                 }
-                fetch(i + 1);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { fa[q] = na[q]; fb[q] = nb[q]; }
+                fetch(i + 2, na, nb);
                 __syncthreads();
 
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f;
