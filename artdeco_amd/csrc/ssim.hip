@@ -321,7 +321,7 @@ extern "C" int adk_fused_ssim_bwd(const float* img1, const float* img2, const fl
     if ((int64_t)B * CH > 65535) return ADK_EUNSUPPORTED;
     const int64_t waves32 = adk::ceil_div(W, 64) * adk::ceil_div(H, 32) * B * CH;
     const dim3 block(64);
-    if (waves32 >= 4096) {
+    if (waves32 >= 2048) {
         const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 32), (unsigned)(B * CH));
         hipLaunchKernelGGL((adk::ssim_bwd_kernel<32>), grid, block, 0, stream, H, W, img1, img2, dL_dmap, dL_scalar, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
     } else {
