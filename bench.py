@@ -185,6 +185,7 @@ def extra_configs(args, dev):
     res = {}
     cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True),
              ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True),
+             ("run.sh training resolution (map 1296x972, pyr_lvl 1): 1M Gaussians 648x486", 1_000_000, 648, 486, True),
              ("configs[3] 4M Gaussians 2592x1944", 4_000_000, 2592, 1944, True),
              (f"headline config, unfused torch glue ({args.gaussians} Gaussians {args.width}x{args.height})",
               args.gaussians, args.width, args.height, False)]
