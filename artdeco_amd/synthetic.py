@@ -152,3 +152,52 @@ def calib_keyframe_graph(num_poses=4, height=48, width=64, seed=0, extra_edges=2
         valid[e, :, 0] = ok
         Q[e, rng.random(n) < 0.1, 0] = 1.0
     return dict(T_gt=T_gt, Xs=Xs, Cs=Cs, K=K, ii=ii, jj=jj, idx=idx, valid=valid, Q=Q, height=height, width=width)
+
+
+def tracker_scene(height=48, width=64, seed=0, fx=70.0, pose_noise=0.03, depth_noise=0.01, outlier_frac=0.03,
+                  kf_pose=None, drop_frac=0.0, rough_cols=0.0):
+    """One frame-to-keyframe tracking problem (VSLAM/CameraTracker.py:53-155): a keyframe (pose 0 of a 2-pose
+    `calib_keyframe_graph`, i.e. points on its own pixel rays of one smooth world surface) and a frame (pose 1), with
+    what `mast3r_match_asymmetric` hands the tracker (utils_mast3r.py:144-170):
+
+      Xff / Cff / Qff [n,3],[n,1],[n,1]   the frame's pointmap, confidence and descriptor confidence in its own camera
+      Xkf / Ckf / Qkf                     the KEYFRAME's points as predicted in the FRAME's camera
+      idx_f2k [n] int64, valid_match [n,1] bool   for every keyframe pixel, the matched frame pixel
+
+    plus the keyframe's stored canonical pointmap `Xk_canon`/`Ck` (N = 1), the drifted initial frame pose `T_WCf0`,
+    the keyframe pose `T_WCk`, the exact frame pose `T_WCf_gt` and `K`.  Depth noise makes the 5x5 local variances
+    non-trivial (covariance filter); `outlier_frac` of the matches point at random frame pixels; 10 % carry a
+    descriptor confidence below the 1.5 threshold; `drop_frac` of the matches are flagged invalid (a frame that
+    barely overlaps the keyframe); the right-hand `rough_cols` of the frame's columns get a very noisy depth
+    (local pixel-covariance determinants above 1: the 0.9-quantile branch of the covariance filter).  float32 / int64 / bool numpy arrays."""
+    rng = np.random.default_rng(seed + 1000)
+    g = calib_keyframe_graph(num_poses=2, height=height, width=width, seed=seed, extra_edges=0, fx=fx)
+    n = height * width
+    T = g["T_gt"].copy()
+    if kf_pose is not None:  # move both poses by a common world transform so that the keyframe is not the identity
+        for k in range(2):
+            t, q, s = T[k, 0:3].astype(np.float64), T[k, 3:7].astype(np.float64), float(T[k, 7])
+            T[k, 0:3] = quat_rotate(kf_pose[3:7].astype(np.float64), t[None])[0] * kf_pose[7] + kf_pose[0:3]
+            T[k, 3:7] = quat_mul(kf_pose[3:7].astype(np.float64), q)
+            T[k, 7] = kf_pose[7] * s
+    e = int(np.nonzero((g["ii"] == 1) & (g["jj"] == 0))[0][0])  # points of the keyframe (j = 0) matched into the frame (i = 1)
+    idx, valid = g["idx"][e].copy(), g["valid"][e].copy()
+    out = (rng.random(n) < outlier_frac) & valid[:, 0]
+    idx[out] = rng.integers(0, n, out.sum())
+    if drop_frac > 0:
+        valid[rng.random(n) < drop_frac, 0] = False
+    noisy = lambda X: (X * (1.0 + depth_noise * rng.standard_normal((n, 1))) + 0.002 * rng.standard_normal((n, 3))).astype(np.float32)
+    Xk_canon, Xff = noisy(g["Xs"][0]), noisy(g["Xs"][1])
+    if rough_cols > 0:
+        rough = (np.arange(n) % width) >= int(round(width * (1.0 - rough_cols)))
+        Xff[rough] *= np.exp(0.6 * rng.standard_normal((int(rough.sum()), 1))).astype(np.float32)
+    # the keyframe's points seen from the frame: T_CfCk Xk
+    tfk, qfk, sfk = relative_pose(g["T_gt"][1], g["T_gt"][0])
+    Xkf = noisy(quat_rotate(qfk, g["Xs"][0].astype(np.float64)) * sfk + tfk)
+    conf = lambda lo: (lo + rng.random((n, 1))).astype(np.float32)
+    Qff, Qkf = conf(1.6), conf(1.6)
+    Qkf[rng.random(n) < 0.1, 0] = 1.0
+    T0 = perturb_poses(T, rng, pose_noise)
+    return dict(height=height, width=width, K=g["K"], Xff=Xff, Cff=conf(1.0), Qff=Qff, Xkf=Xkf, Ckf=conf(1.0), Qkf=Qkf,
+                Xk_canon=Xk_canon, Ck=conf(1.0), idx_f2k=idx, valid_match=valid, T_WCk=T[0:1].copy(), T_WCf0=T0[1:2].copy(),
+                T_WCf_gt=T[1:2].copy())
