@@ -30,6 +30,7 @@ EXTRA_FLAGS = {
     "raster_project.hip": ["-ffp-contract=off"],
     "matching.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],
+    "tracker.hip": ["-ffp-contract=off"],  # same arithmetic as the host-compiled test harness (tests/host/)
 }
 
 

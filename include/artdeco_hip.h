@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 2
+#define ADK_ABI_VERSION 3
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -344,6 +344,38 @@ int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_points, flo
                      float Q_thresh, int max_iter, float delta_thresh, int num_fix, float* dx_out,
                      float* Hs_dbg, float* gs_dbg, void* workspace, int64_t workspace_bytes,
                      adk_stream_t stream);
+
+/* ------------------------------------------------------- frontend Sim(3) tracker
+ * Replaces the body of CameraTracker.track between the MASt3R match and the keyframe decision --
+ * VSLAM/CameraTracker.py:62-153: get_points_poses (:189-219; constrain_points_to_ray geometry.py:38-43,
+ * local_diag_cov_from_X1 utils_uncertainty.py:5-53), the validity masks (:83-87), the insufficient-match test
+ * (:90-91), opt_pose_calib_sim3 (:296-396, with the covariance filter :335-346; optimize_focal is not supported),
+ * and the counts / quantile behind check_keyframe (:159-167) and check_keyframe_map (:170-186).
+ * Xf_canon / Cf / Qf [n,3],[n],[n]: the frame's canonical pointmap, summed confidence (average = Cf * inv_Nf,
+ * ImageFrame.get_average_conf) and descriptor confidence, frame pixel order; Xk_canon / Ck / Qk: the keyframe's
+ * (Qk = the keyframe-in-frame descriptor confidence Qkf); idx_f2k [n] int64 and valid_match [n] bytes in keyframe
+ * pixel order; K [3,3] row-major, T_WCf / T_WCk [8] = (t3, q xyzw, s): all DEVICE memory.  n = height * width.
+ * result [24] floats (device): [0..7] new T_WCf (quat2unit'd; the input pose when lost or failed), [8..15] T_CkCf,
+ * [16] lost (matches below min_match_frac), [17] Cholesky failed, [18] iterations, [19] valid_opt count,
+ * [20] valid_kf count, [21] number of distinct matched frame pixels, [22] dist_quantile_q-quantile of the match
+ * displacement over valid_opt (torch.quantile semantics), [23] cost of the last linearisation.
+ * dbg_* (optional): constrained frame points [n,3], local variances [n,3], valid_opt [n] bytes, the summed
+ * accumulators of iteration 0 [36] (28 lower-triangle H, 7 J^T e, cost).
+ * All max_iters iterations are enqueued and become no-ops once converged; the call never synchronises. */
+int64_t adk_track_workspace_bytes(int height, int width);
+int adk_track_frame(int height, int width, const float* K, const float* Xf_canon, const float* Cf, float inv_Nf,
+                    const float* Qf, const float* Xk_canon, const float* Ck, float inv_Nk, const float* Qk,
+                    const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
+                    float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
+                    float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
+                    int max_iters, int covariance_filter, float dist_quantile_q, float* result, float* dbg_Xc,
+                    float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace,
+                    int64_t workspace_bytes, adk_stream_t stream);
+/* Point fusion after a successful track (CameraTracker.py:136-141 + ImageFrame.update_pointmap, ImageFrame.py:30-48):
+ * X_canon = (C X_canon + Ckf (T_CkCf Xkf)) / (C + Ckf), C += Ckf, in place; a no-op when result[16] or result[17]
+ * is set (decided on the device: no host read needed in between). */
+int adk_track_fuse_pointmap(int64_t n, const float* result, const float* Xkf, const float* Ckf, float* X_canon,
+                            float* C, adk_stream_t stream);
 
 /* ------------------------------------------------------- prune-and-append
  * Replaces the body of SparseGaussianAdam.add_and_prune (Reconstruct/scene/optimizers.py:163-219; called on
