@@ -167,15 +167,20 @@ class CameraTracker:
         self.last_outcome = None
         self.reset_idx_f2k()
 
-    def _resolve(self):
-        if self._match_fn is None or self._mono_fn is None:
-            from VSLAM.utils_mast3r import mast3r_inference_mono, mast3r_match_asymmetric
-            self._match_fn = self._match_fn or mast3r_match_asymmetric
-            self._mono_fn = self._mono_fn or mast3r_inference_mono
+    def _match(self):
+        if self._match_fn is None:
+            from VSLAM.utils_mast3r import mast3r_match_asymmetric
+            self._match_fn = mast3r_match_asymmetric
+        return self._match_fn
+
+    def _mono(self):
+        if self._mono_fn is None:
+            from VSLAM.utils_mast3r import mast3r_inference_mono
+            self._mono_fn = mast3r_inference_mono
+        return self._mono_fn
 
     def track_init(self, frame):
-        self._resolve()
-        X_init, C_init, feat, pos = self._mono_fn(self.model, frame)
+        X_init, C_init, feat, pos = self._mono()(self.model, frame)
         frame.update_pointmap(X_init, C_init)
         self.last_embedding = [feat, pos]
         return False, True, True
@@ -186,9 +191,8 @@ class CameraTracker:
     def track(self, frame):
         if frame.frame_id == 0:
             return self.track_init(frame)
-        self._resolve()
         keyframe = self.keyframes.last_keyframe().to(self.device)
-        idx_f2k, valid_match_k, Xff, Cff, Qff, Xkf, Ckf, Qkf, featf, posf = self._match_fn(
+        idx_f2k, valid_match_k, Xff, Cff, Qff, Xkf, Ckf, Qkf, featf, posf = self._match()(
             self.config, self.model, frame, keyframe, idx_i2j_init=self.idx_f2k, embeddings_j=self.last_embedding)
         self.idx_f2k = idx_f2k.clone()
         frame.update_pointmap(Xff, Cff)
