@@ -1,5 +1,5 @@
 // Frontend Sim(3) tracker for gfx950: everything CameraTracker.track does between the MASt3R match
-// and the keyframe decision, on the device, without a host round trip.
+// and the keyframe decision, on the device.
 //
 // Replaces VSLAM/CameraTracker.py:62-153 -- get_points_poses (:189-219: constrain_points_to_ray, local_diag_cov_from_X1,
 // keyframe measurements), the validity masks (:83-87), the insufficient-match test (:90-91), opt_pose_calib_sim3
@@ -11,13 +11,18 @@
 //
 // Here (MI355X-first):
 //   * one gather pass builds a 24-byte record per keyframe pixel (matched frame point, variance product, weight,
-//     keyframe log-depth), so an iteration streams 4.7 MB at 512x384 instead of re-gathering through idx_f2k;
+//     keyframe log-depth), so an iteration streams 5.5 MB at 512x384 instead of re-gathering through idx_f2k;
 //   * the covariance determinant is evaluated in closed form, (fx fy s^3 / Z^3)^2 vx vy vz, instead of an LU of J S J^T;
-//   * torch.quantile's order statistics come from a two-level (16 + 16 bit) radix SELECT over order-preserving keys --
-//     exact, no sort;
-//   * the normal equations are accumulated per workgroup (28 + 7 + 1 values), summed in a fixed order in fp64, solved by
-//     a 7x7 Cholesky, retracted and tested for convergence by one wavefront; a device flag turns the remaining
-//     pre-enqueued iterations into no-ops.  The host reads ONE 24-float result at the end.
+//   * torch.quantile's two order statistics come from a three-level (11 + 11 + 10 bit) radix SELECT over order-preserving
+//     keys: exact, no sort.  Histograms are built in LDS per workgroup and written out as per-workgroup partials; NO
+//     global atomics on the data path -- measured on MI355X, a device-scope atomic costs ~3 ns wherever it lands (it is
+//     resolved below the per-XCD L2s), so the first version's 196 608 atomicAdds per pass took 0.5 ms per kernel;
+//   * "last workgroup to arrive finishes the job": the workgroup that draws the last ticket of a launch reduces the
+//     partials (histogram totals + rank search, or the 36 normal-equation sums + 7x7 Cholesky + retraction +
+//     convergence test), so an iteration is 4 launches (3 select passes + accumulate) and a device flag turns the
+//     remaining enqueued iterations into no-ops;
+//   * a call enqueues a CHUNK of iterations (no-op launches still cost ~4 us each on the GPU); the host reads one
+//     32-float result and only calls again (resume = 1) in the rare case the chunk did not converge.
 // The arithmetic lives in tracker_math.hpp (also compiled on the host by the tests); this file is the parallel plumbing.
 #include "adk_common.hpp"
 #include "tracker_math.hpp"
@@ -26,32 +31,61 @@ namespace adk {
 using namespace trk;
 
 #define TRK_BLOCK 256
-#define TRK_MAX_BLOCKS 256
-#define TRK_HI_BINS 65536
+#define TRK_SEL_BLOCKS 16
+#define TRK_SEL_THREADS 1024
+#define TRK_ACC_BLOCKS 64
 #define TRK_SKIP_KEY 0xFFFFFFFFu
 
 // per keyframe pixel: recA = (x, y, z, varprod) of the matched frame point, recB = (w0, logz_k): 24 bytes
-
-struct Sel { int bin_lo, bin_hi; int64_t rem_lo, rem_hi, n; float w; };
-
 struct TrkWs {
     State* state;
     Sel* sel;
-    unsigned* counts;      // [4]: n_opt, n_kf, n_unique, (unused)
-    unsigned* hist_hi;     // [65536]
-    unsigned* hist_lo;     // [2][65536]
-    unsigned* seen;        // [n] first-visit flags for the unique count
+    unsigned* arrive;      // [4] arrival tickets: 1 select passes, 2 accumulate
+    unsigned* blk_counts;  // [pt_blocks][2] valid_opt / valid_kf per gather workgroup
+    unsigned* blk_seen;    // [TRK_SEL_BLOCKS]
+    unsigned* hist;        // [TRK_SEL_BLOCKS][2][TRK_BINS]
+    uint8_t* seen;         // [n] frame pixels hit by a valid match (unique count)
     float4* Xfc;           // [n] constrained frame point + variance product
     float4* recA;          // [n]
     float2* recB;          // [n]
     unsigned* keys;        // [n] selection keys (displacement, then determinants)
-    float* partials;       // [TRK_MAX_BLOCKS][TRK_NACC]
+    float* partials;       // [TRK_ACC_BLOCKS][TRK_NACC]
 };
 
 __device__ __forceinline__ Cam load_cam(const float* __restrict__ K, int H, int W) {
     Cam c;
     c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5]; c.H = H; c.W = W;
     return c;
+}
+
+__device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Every workgroup calls this after its global writes; exactly one (the last to arrive) gets `true` and may read what
+// all the others wrote.  Release: fence, then the ticket; acquire: the ticket, then fence.  The counter is left at 0.
+__device__ __forceinline__ bool arrive_last(unsigned* counter, int* flag_lds) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(counter, 1u);
+        const int last = (t == gridDim.x - 1) ? 1 : 0;
+        if (last) atomicExch(counter, 0u);
+        *flag_lds = last;
+    }
+    __syncthreads();
+    const bool last = *flag_lds != 0;
+    if (last) __threadfence();
+    return last;
+}
+
+// Clears the header of the workspace (state, tickets, `seen`).  A kernel rather than hipMemsetAsync: inside a captured
+// hipGraph the memset node was observed (ROCm 7.2, MI355X) not to be ordered before the kernels that follow it.
+__global__ __launch_bounds__(TRK_BLOCK) void trk_clear_kernel(uint4* __restrict__ p, int64_t n16)
+{
+    for (int64_t i = blockIdx.x * (int64_t)TRK_BLOCK + threadIdx.x; i < n16; i += (int64_t)gridDim.x * TRK_BLOCK) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---- 1. frame side: constrain_points_to_ray + local_diag_cov_from_X1 (diagonal only) ------------------------------
@@ -78,8 +112,9 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_gather_kernel(
     float inv_Nf, const float* __restrict__ Ck, float inv_Nk, const float* __restrict__ Qf, const float* __restrict__ Qk,
     const float* __restrict__ Xk_canon, Cfg g, TrkWs ws, uint8_t* __restrict__ dbg_valid_opt)
 {
+    __shared__ unsigned wcnt[TRK_BLOCK / 64][2];
     const int k = blockIdx.x * TRK_BLOCK + threadIdx.x;
-    bool opt = false, kf = false, first = false;
+    bool opt = false, kf = false;
     if (k < n) {
         int64_t ix = idx_f2k[k];
         ix = ix < 0 ? 0 : (ix >= n ? n - 1 : ix);
@@ -91,99 +126,150 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_gather_kernel(
         const bool vmeas = zk > g.z_eps;
         ws.recA[k] = ws.Xfc[ix];
         ws.recB[k] = make_float2((opt && vmeas) ? sqrtf(q) : 0.f, vmeas ? logf(zk) : 0.f);
-        if (vm) first = atomicExch(&ws.seen[ix], 1u) == 0u;
+        if (vm) ws.seen[ix] = 1; // benign race: every writer stores the same byte
         unsigned key = TRK_SKIP_KEY;
         if (opt) {
             const float du = (float)((int)(ix % W) - (k % W)), dv = (float)((int)(ix / W) - (k / W));
             key = float_key(sqrtf(du * du + dv * dv));
-            atomicAdd(&ws.hist_hi[key >> 16], 1u);
         }
         ws.keys[k] = key;
         if (dbg_valid_opt) dbg_valid_opt[k] = opt ? 1 : 0;
     }
-    const unsigned c0 = __popcll(__ballot(opt)), c1 = __popcll(__ballot(kf)), c2 = __popcll(__ballot(first));
-    if ((threadIdx.x & 63) == 0) {
-        if (c0) atomicAdd(&ws.counts[0], c0);
-        if (c1) atomicAdd(&ws.counts[1], c1);
-        if (c2) atomicAdd(&ws.counts[2], c2);
-    }
+    const unsigned c0 = __popcll(__ballot(opt)), c1 = __popcll(__ballot(kf));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { wcnt[wv][0] = c0; wcnt[wv][1] = c1; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        ws.blk_counts[blockIdx.x * 2 + threadIdx.x] = (wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x]) + (wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x]);
 }
 
 // ---- radix select: torch.quantile without a sort ---------------------------------------------------------------------
-// (a) one workgroup: locate the high-16-bit bins that hold ranks floor(q (n-1)) and ceil(q (n-1)); clears hist_hi.
-__global__ __launch_bounds__(1024) void trk_select_hi_kernel(TrkWs ws, float q, const unsigned* __restrict__ n_dev, int n_const,
-                                                             int gate_on_done)
+// Which bin of the (LDS) histogram h[TRK_BINS] holds 0-based rank `rank`, and the rank inside that bin.
+__device__ __forceinline__ void block_locate(const unsigned* h, int64_t rank, unsigned* wsum, int* out_bin, long long* out_rem)
 {
-    __shared__ unsigned chunk[1024];
-    if (gate_on_done && ws.state->done) return;
-    const int tid = threadIdx.x;
-    unsigned s = 0;
-    for (int b = 0; b < 64; ++b) s += ws.hist_hi[tid * 64 + b];
-    chunk[tid] = s;
+    const int t = threadIdx.x;
+    const unsigned a = h[2 * t], b = h[2 * t + 1], s = a + b;
+    unsigned inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += v; }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    if (t == 0) { *out_bin = TRK_BINS - 1; *out_rem = 0; }
     __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+    const int64_t excl = (int64_t)base + inc - s;
+    if (s > 0 && rank >= excl && rank < excl + (int64_t)s) {
+        const int64_t r = rank - excl;
+        if (r < (int64_t)a) { *out_bin = 2 * t; *out_rem = r; } else { *out_bin = 2 * t + 1; *out_rem = r - a; }
+    }
+    __syncthreads();
+}
+
+// One pass (0, 1, 2) of the select.  MODE 0: the keys are the match displacements written by the gather kernel (population
+// = the valid_opt matches; pass 0 also counts the distinct matched frame pixels).  MODE 1: the keys are the covariance
+// determinants of the current pose, computed and stored by pass 0 (population = all n points, as the reference).
+// The last workgroup to arrive totals the per-workgroup histograms, finds the bins of the two ranks and advances *ws.sel;
+// after pass 2 it writes max(quantile, floor_value) to *out_value.
+template <int MODE>
+__global__ __launch_bounds__(TRK_SEL_THREADS) void trk_select_kernel(int n, int pass, int num_gather_blocks, int H, int W,
+                                                                     const float* __restrict__ K, TrkWs ws, float q, float floor_value,
+                                                                     float* __restrict__ out_value)
+{
+    __shared__ unsigned hA[TRK_BINS], hB[TRK_BINS];
+    __shared__ unsigned wsum[TRK_SEL_THREADS / 64];
+    __shared__ int lastf, bin_lo, bin_hi;
+    __shared__ long long rem_lo, rem_hi;
+    __shared__ unsigned popn;
+    if (MODE == 1 && ws.state->done) return;
+    if (pass > 0 && ws.sel->n < 0) return; // pass 0 already knew the answer (quantile below the floor)
+    const int tid = threadIdx.x;
+    Sel sel;
+    if (pass > 0) sel = *ws.sel;
+    else sel_begin(sel, q, 0);
+    const bool two = pass > 0 && !sel.same;
+    hA[tid] = 0u; hA[tid + TRK_SEL_THREADS] = 0u; hB[tid] = 0u; hB[tid + TRK_SEL_THREADS] = 0u;
+    __syncthreads();
+    Cam c;
+    Pose T;
+    if (MODE == 1 && pass == 0) { c = load_cam(K, H, W); T = load_pose(ws.state->T); }
+    unsigned seen_cnt = 0;
+    for (int k = blockIdx.x * TRK_SEL_THREADS + tid; k < n; k += TRK_SEL_BLOCKS * TRK_SEL_THREADS) {
+        unsigned key;
+        if (MODE == 1 && pass == 0) {
+            const float4 a = ws.recA[k];
+            const float X[3] = {a.x, a.y, a.z};
+            key = float_key(cov_det(T, c, X, a.w));
+            if (key == TRK_SKIP_KEY) key = TRK_SKIP_KEY - 1u; // keep every point in the population
+            ws.keys[k] = key;
+        } else {
+            key = ws.keys[k];
+        }
+        if (MODE == 0 && pass == 0) seen_cnt += ws.seen[k];
+        if (key == TRK_SKIP_KEY) continue;
+        const unsigned d = digit_of(key, pass);
+        if (pass == 0) {
+            atomicAdd(&hA[d], 1u);
+        } else {
+            const unsigned pf = prefix_of(key, pass);
+            if (pf == sel.pfx_lo) atomicAdd(&hA[d], 1u);
+            if (two && pf == sel.pfx_hi) atomicAdd(&hB[d], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* out = ws.hist + (size_t)blockIdx.x * 2 * TRK_BINS;
+    out[tid] = hA[tid]; out[tid + TRK_SEL_THREADS] = hA[tid + TRK_SEL_THREADS];
+    if (two) { out[TRK_BINS + tid] = hB[tid]; out[TRK_BINS + tid + TRK_SEL_THREADS] = hB[tid + TRK_SEL_THREADS]; }
+    if (MODE == 0 && pass == 0) {
+        seen_cnt = wave_sum_u(seen_cnt);
+        if ((tid & 63) == 0) wsum[tid >> 6] = seen_cnt;
+        __syncthreads();
+        if (tid == 0) { unsigned s = 0; for (int w = 0; w < TRK_SEL_THREADS / 64; ++w) s += wsum[w]; ws.blk_seen[blockIdx.x] = s; }
+    }
+    if (!arrive_last(&ws.arrive[1], &lastf)) return;
+    // ---- the last workgroup: totals, rank search, next prefix
+    if (MODE == 0 && pass == 0) { // valid_opt / valid_kf counts of the gather workgroups (fixed order)
+        unsigned s0 = 0, s1 = 0;
+        for (int b = tid; b < num_gather_blocks; b += TRK_SEL_THREADS) { s0 += ws.blk_counts[2 * b]; s1 += ws.blk_counts[2 * b + 1]; }
+        s0 = wave_sum_u(s0); s1 = wave_sum_u(s1);
+        __syncthreads();
+        if ((tid & 63) == 0) { hA[tid >> 6] = s0; hB[tid >> 6] = s1; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned t0 = 0, t1 = 0;
+            for (int w = 0; w < TRK_SEL_THREADS / 64; ++w) { t0 += hA[w]; t1 += hB[w]; }
+            ws.state->n_opt = t0; ws.state->n_kf = t1;
+            popn = t0;
+        }
+        __syncthreads();
+    }
+    if (pass == 0) sel_begin(sel, q, MODE == 0 ? (int64_t)popn : (int64_t)n);
+    __syncthreads(); // everybody is done with hA / hB / wsum of the counting phase
+    for (int i = tid; i < TRK_BINS; i += TRK_SEL_THREADS) {
+        unsigned a = 0, b = 0;
+        for (int blk = 0; blk < TRK_SEL_BLOCKS; ++blk) {
+            a += ws.hist[((size_t)blk * 2) * TRK_BINS + i];
+            if (two) b += ws.hist[((size_t)blk * 2 + 1) * TRK_BINS + i];
+        }
+        hA[i] = a; hB[i] = b;
+    }
+    __syncthreads();
+    block_locate(hA, sel.rem_lo, wsum, &bin_lo, &rem_lo);
+    block_locate(two ? hB : hA, sel.rem_hi, wsum, &bin_hi, &rem_hi);
     if (tid == 0) {
-        const int64_t n = n_dev ? (int64_t)*n_dev : (int64_t)n_const;
-        Sel sel;
-        sel.n = n; sel.bin_lo = sel.bin_hi = 0; sel.rem_lo = sel.rem_hi = 0; sel.w = 0.f;
-        if (n > 0) {
-            int64_t lo, hi;
-            quantile_rank(q, n, &lo, &hi, &sel.w);
-            if (hi > n - 1) hi = n - 1;
-            int64_t r0, r1;
-            const int c_lo = locate_rank(chunk, 1024, lo, &r0), c_hi = locate_rank(chunk, 1024, hi, &r1);
-            sel.bin_lo = c_lo * 64 + locate_rank(ws.hist_hi + c_lo * 64, 64, r0, &sel.rem_lo);
-            sel.bin_hi = c_hi * 64 + locate_rank(ws.hist_hi + c_hi * 64, 64, r1, &sel.rem_hi);
+        if (sel.n > 0) sel_advance(sel, pass, (unsigned)bin_lo, rem_lo, (unsigned)bin_hi, rem_hi);
+        // every key whose leading digit is below the floor's is below the floor: max(quantile, floor) = floor, passes 1-2 idle
+        if (pass == 0 && sel.n > 0 && floor_value > -INFINITY && sel.pfx_hi < digit_of(float_key(floor_value), 0)) {
+            sel.n = -1;
+            *out_value = floor_value;
         }
         *ws.sel = sel;
-    }
-    __syncthreads();
-    for (int b = 0; b < 64; ++b) ws.hist_hi[tid * 64 + b] = 0u;
-}
-
-// (b) low-16-bit histograms of the keys inside those two bins.
-__global__ __launch_bounds__(TRK_BLOCK) void trk_hist_lo_kernel(int n, TrkWs ws, int gate_on_done)
-{
-    if (gate_on_done && ws.state->done) return;
-    const Sel sel = *ws.sel;
-    if (sel.n <= 0) return;
-    for (int k = blockIdx.x * TRK_BLOCK + threadIdx.x; k < n; k += gridDim.x * TRK_BLOCK) {
-        const unsigned key = ws.keys[k];
-        if (key == TRK_SKIP_KEY) continue;
-        const int hb = (int)(key >> 16);
-        if (hb == sel.bin_lo) atomicAdd(&ws.hist_lo[key & 0xffffu], 1u);
-        if (hb == sel.bin_hi) atomicAdd(&ws.hist_lo[TRK_HI_BINS + (key & 0xffffu)], 1u);
-    }
-}
-
-// (c) one workgroup: the two order statistics, torch.lerp, optional floor (covariance filter: max(q90, 1)); clears hist_lo.
-__global__ __launch_bounds__(1024) void trk_select_lo_kernel(TrkWs ws, float floor_value, float* __restrict__ out, int gate_on_done)
-{
-    __shared__ unsigned chunk[2][1024];
-    if (gate_on_done && ws.state->done) return;
-    const int tid = threadIdx.x;
-    const Sel sel = *ws.sel;
-    for (int h = 0; h < 2; ++h) {
-        unsigned s = 0;
-        for (int b = 0; b < 64; ++b) s += ws.hist_lo[h * TRK_HI_BINS + tid * 64 + b];
-        chunk[h][tid] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float v = 0.f;
-        if (sel.n > 0) {
-            int64_t r;
-            const int ca = locate_rank(chunk[0], 1024, sel.rem_lo, &r);
-            const unsigned la = (unsigned)(ca * 64 + locate_rank(ws.hist_lo + ca * 64, 64, r, &r));
-            const int cb = locate_rank(chunk[1], 1024, sel.rem_hi, &r);
-            const unsigned lb = (unsigned)(cb * 64 + locate_rank(ws.hist_lo + TRK_HI_BINS + cb * 64, 64, r, &r));
-            const float a = key_float(((unsigned)sel.bin_lo << 16) | la), b = key_float(((unsigned)sel.bin_hi << 16) | lb);
-            v = lerp_torch(a, b, sel.w);
+        if (pass == 2) *out_value = fmaxf(sel_value(sel), floor_value);
+        if (MODE == 0 && pass == 0) {
+            unsigned s = 0;
+            for (int blk = 0; blk < TRK_SEL_BLOCKS; ++blk) s += ws.blk_seen[blk];
+            ws.state->n_unique = s;
         }
-        *out = fmaxf(v, floor_value);
     }
-    __syncthreads();
-    for (int h = 0; h < 2; ++h)
-        for (int b = 0; b < 64; ++b) ws.hist_lo[h * TRK_HI_BINS + tid * 64 + b] = 0u;
 }
 
 // ---- 3. optimisation -----------------------------------------------------------------------------------------------------
@@ -200,30 +286,18 @@ __global__ void trk_init_kernel(int n, const float* __restrict__ T_WCf, const fl
     s.thr = INFINITY;
     for (int r = 0; r < 7; ++r) s.tau[r] = 0.f;
     // CameraTracker.py:90-91: valid_opt.sum() / numel < min_match_frac -> lost, no optimisation
-    s.lost = ((float)ws.counts[0] / (float)n < g.min_match_frac) ? 1 : 0;
+    s.lost = ((float)s.n_opt / (float)n < g.min_match_frac) ? 1 : 0;
     s.done = s.lost;
 }
 
-// determinant keys + high histogram for the covariance filter's 0.9 quantile (over ALL n points, as the reference)
-__global__ __launch_bounds__(TRK_BLOCK) void trk_det_kernel(int n, int H, int W, const float* __restrict__ K, TrkWs ws)
-{
-    if (ws.state->done) return;
-    const Cam c = load_cam(K, H, W);
-    const Pose T = load_pose(ws.state->T);
-    for (int k = blockIdx.x * TRK_BLOCK + threadIdx.x; k < n; k += gridDim.x * TRK_BLOCK) {
-        const float4 a = ws.recA[k];
-        const float X[3] = {a.x, a.y, a.z};
-        unsigned key = float_key(cov_det(T, c, X, a.w));
-        if (key == TRK_SKIP_KEY) key = TRK_SKIP_KEY - 1u; // keep every point in the population
-        ws.keys[k] = key;
-        atomicAdd(&ws.hist_hi[key >> 16], 1u);
-    }
-}
-
+// normal equations of the current linearisation; the last workgroup to arrive sums the partials in a fixed order (fp64),
+// solves the 7x7 system, retracts and tests for convergence (gn_step)
 __global__ __launch_bounds__(TRK_BLOCK) void trk_accumulate_kernel(int n, int H, int W, const float* __restrict__ K, Cfg g,
-                                                                   int use_cov, TrkWs ws)
+                                                                   int use_cov, TrkWs ws, float* __restrict__ dbg_acc0)
 {
     __shared__ float red[TRK_BLOCK / 64][TRK_NACC];
+    __shared__ double sum[TRK_NACC];
+    __shared__ int lastf;
     if (ws.state->done) return;
     const Cam c = load_cam(K, H, W);
     const Pose T = load_pose(ws.state->T);
@@ -231,7 +305,7 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_accumulate_kernel(int n, int H,
     float acc[TRK_NACC];
 #pragma unroll
     for (int l = 0; l < TRK_NACC; ++l) acc[l] = 0.f;
-    for (int k = blockIdx.x * TRK_BLOCK + threadIdx.x; k < n; k += gridDim.x * TRK_BLOCK) {
+    for (int k = blockIdx.x * TRK_BLOCK + threadIdx.x; k < n; k += TRK_ACC_BLOCKS * TRK_BLOCK) {
         const float4 a = ws.recA[k];
         const float2 b = ws.recB[k];
         const float X[3] = {a.x, a.y, a.z};
@@ -245,26 +319,20 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_accumulate_kernel(int n, int H,
     if (threadIdx.x < TRK_NACC)
         ws.partials[blockIdx.x * TRK_NACC + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// one wavefront: fixed-order fp64 sum of the workgroup partials, 7x7 Cholesky, retraction, convergence test
-__global__ __launch_bounds__(64) void trk_solve_kernel(int nblk, Cfg g, TrkWs ws, float* __restrict__ dbg_acc0)
-{
-    __shared__ double acc[TRK_NACC];
-    if (ws.state->done) return;
-    const int tid = threadIdx.x;
-    if (tid < TRK_NACC) {
+    if (!arrive_last(&ws.arrive[2], &lastf)) return;
+    if (threadIdx.x < TRK_NACC) {
         double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)ws.partials[b * TRK_NACC + tid];
-        acc[tid] = s;
-        if (dbg_acc0 && ws.state->iters == 0) dbg_acc0[tid] = (float)s;
+        for (int b = 0; b < TRK_ACC_BLOCKS; ++b) s += (double)ws.partials[b * TRK_NACC + threadIdx.x];
+        sum[threadIdx.x] = s;
+        if (dbg_acc0 && ws.state->iters == 0) dbg_acc0[threadIdx.x] = (float)s;
     }
     __syncthreads();
-    if (tid == 0) gn_step(*ws.state, acc, g);
+    if (threadIdx.x == 0) gn_step(*ws.state, sum, g);
 }
 
-// out[0..7] = new T_WCf (the input pose when lost / failed), out[8..15] = T_CkCf,
-// out[16..23] = lost, fail, iterations, n_opt, n_kf, n_unique, displacement quantile, final cost
+// result[0..7] = new T_WCf (the input pose when lost / failed), [8..15] = T_CkCf, [16] lost, [17] failed, [18] iterations,
+// [19] n_opt, [20] n_kf, [21] n_unique, [22] displacement quantile, [23] last cost, [24] finished (converged, lost or
+// failed: nothing left to iterate), [25] last covariance threshold, [26..31] 0
 __global__ void trk_finish_kernel(const float* __restrict__ T_WCf, TrkWs ws, float* __restrict__ out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -274,9 +342,9 @@ __global__ void trk_finish_kernel(const float* __restrict__ T_WCf, TrkWs ws, flo
     else for (int i = 0; i < 8; ++i) out[i] = T_WCf[i];
     for (int i = 0; i < 8; ++i) out[8 + i] = s.T[i];
     out[16] = (float)s.lost; out[17] = (float)s.fail; out[18] = (float)s.iters;
-    out[19] = (float)ws.counts[0]; out[20] = (float)ws.counts[1]; out[21] = (float)ws.counts[2];
-    // out[22] (displacement quantile) is written by trk_select_lo_kernel
-    out[23] = (float)s.cost;
+    out[19] = (float)s.n_opt; out[20] = (float)s.n_kf; out[21] = (float)s.n_unique;
+    out[22] = s.dist_q; out[23] = (float)s.cost; out[24] = (float)s.done; out[25] = s.thr;
+    for (int i = 26; i < 32; ++i) out[i] = 0.f;
 }
 
 // Point fusion (CameraTracker.py:136-141 + ImageFrame.update_pointmap :30-48), gated on the device-side success flags:
@@ -300,24 +368,25 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_fuse_kernel(int n, const float*
 
 static inline int64_t trk_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-struct TrkLayout { int64_t state, sel, counts, hist_hi, hist_lo, seen, xfc, recA, recB, keys, partials, total, zero_bytes; };
+struct TrkLayout { int64_t state, sel, arrive, seen, zero_bytes, blk_counts, blk_seen, hist, xfc, recA, recB, keys, partials, total; };
 
 static TrkLayout trk_layout(int64_t n)
 {
     TrkLayout L;
     int64_t o = 0;
     L.state = o; o += trk_align(sizeof(adk::trk::State));
-    L.sel = o; o += trk_align(sizeof(adk::Sel));
-    L.counts = o; o += 256;
-    L.hist_hi = o; o += TRK_HI_BINS * 4;
-    L.hist_lo = o; o += 2 * TRK_HI_BINS * 4;
-    L.seen = o; o += trk_align(n * 4);
-    L.zero_bytes = o; // everything above is cleared at the start of a call
+    L.sel = o; o += trk_align(sizeof(adk::trk::Sel));
+    L.arrive = o; o += 256;
+    L.seen = o; o += trk_align(n);
+    L.zero_bytes = o; // everything above is cleared at the start of a (non-resumed) call
+    L.blk_counts = o; o += trk_align(adk::ceil_div(n, TRK_BLOCK) * 2 * 4);
+    L.blk_seen = o; o += trk_align(TRK_SEL_BLOCKS * 4);
+    L.hist = o; o += trk_align((int64_t)TRK_SEL_BLOCKS * 2 * TRK_BINS * 4);
     L.xfc = o; o += trk_align(n * 16);
     L.recA = o; o += trk_align(n * 16);
     L.recB = o; o += trk_align(n * 8);
     L.keys = o; o += trk_align(n * 4);
-    L.partials = o; o += trk_align((int64_t)TRK_MAX_BLOCKS * TRK_NACC * 4);
+    L.partials = o; o += trk_align((int64_t)TRK_ACC_BLOCKS * TRK_NACC * 4);
     L.total = o;
     return L;
 }
@@ -333,12 +402,12 @@ extern "C" int adk_track_frame(int height, int width, const float* K, const floa
                                const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
                                float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
                                float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
-                               int max_iters, int covariance_filter, float dist_quantile_q, float* result, float* dbg_Xc,
-                               float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace, int64_t workspace_bytes,
-                               hipStream_t stream)
+                               int num_iters, int covariance_filter, float dist_quantile_q, int resume, float* result,
+                               float* dbg_Xc, float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace,
+                               int64_t workspace_bytes, hipStream_t stream)
 {
     using namespace adk;
-    if (height < 3 || width < 3 || max_iters < 0) return ADK_EINVAL; // the 5x5 reflect window needs >= 3 rows / columns
+    if (height < 3 || width < 3 || num_iters < 0) return ADK_EINVAL; // the 5x5 reflect window needs >= 3 rows / columns
     if (!K || !Xf_canon || !Cf || !Qf || !Xk_canon || !Ck || !Qk || !idx_f2k || !valid_match || !T_WCf || !T_WCk || !result || !workspace)
         return ADK_EINVAL;
     if (!(sigma_pixel > 0.f) || !(sigma_depth > 0.f) || !(dist_quantile_q >= 0.f && dist_quantile_q <= 1.f)) return ADK_EINVAL;
@@ -349,36 +418,34 @@ extern "C" int adk_track_frame(int height, int width, const float* K, const floa
     if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
     char* w = (char*)workspace;
     TrkWs ws;
-    ws.state = (State*)(w + L.state); ws.sel = (Sel*)(w + L.sel); ws.counts = (unsigned*)(w + L.counts);
-    ws.hist_hi = (unsigned*)(w + L.hist_hi); ws.hist_lo = (unsigned*)(w + L.hist_lo); ws.seen = (unsigned*)(w + L.seen);
-    ws.Xfc = (float4*)(w + L.xfc); ws.recA = (float4*)(w + L.recA); ws.recB = (float2*)(w + L.recB); ws.keys = (unsigned*)(w + L.keys);
-    ws.partials = (float*)(w + L.partials);
+    ws.state = (State*)(w + L.state); ws.sel = (Sel*)(w + L.sel); ws.arrive = (unsigned*)(w + L.arrive);
+    ws.blk_counts = (unsigned*)(w + L.blk_counts); ws.blk_seen = (unsigned*)(w + L.blk_seen); ws.hist = (unsigned*)(w + L.hist);
+    ws.seen = (uint8_t*)(w + L.seen); ws.Xfc = (float4*)(w + L.xfc); ws.recA = (float4*)(w + L.recA); ws.recB = (float2*)(w + L.recB);
+    ws.keys = (unsigned*)(w + L.keys); ws.partials = (float*)(w + L.partials);
     Cfg g;
     g.sigma_pixel_inv = 1.0f / sigma_pixel; g.sigma_depth_inv = 1.0f / sigma_depth; g.huber_k = huber_k; g.z_eps = depth_eps;
     g.border = (float)pixel_border; g.C_conf = C_conf; g.Q_conf = Q_conf; g.min_match_frac = min_match_frac;
     g.rel_error = (double)rel_error; g.delta_norm = (double)delta_norm;
 
-    hipError_t err = hipMemsetAsync(w, 0, (size_t)L.zero_bytes, stream);
-    if (err != hipSuccess) return (int)err;
     const int pt_blocks = (int)ceil_div(n, TRK_BLOCK);
-    const int it_blocks = pt_blocks < TRK_MAX_BLOCKS ? pt_blocks : TRK_MAX_BLOCKS;
-    hipLaunchKernelGGL(trk_prepare_kernel, dim3(pt_blocks), dim3(TRK_BLOCK), 0, stream, n, height, width, K, Xf_canon, ws.Xfc, dbg_Xc, dbg_var);
-    hipLaunchKernelGGL(trk_gather_kernel, dim3(pt_blocks), dim3(TRK_BLOCK), 0, stream, n, width, idx_f2k, valid_match, Cf, inv_Nf, Ck, inv_Nk,
-                       Qf, Qk, Xk_canon, g, ws, dbg_valid_opt);
-    // displacement quantile over the valid_opt matches (check_keyframe_map :181-183)
-    hipLaunchKernelGGL(trk_select_hi_kernel, dim3(1), dim3(1024), 0, stream, ws, dist_quantile_q, (const unsigned*)ws.counts, 0, 0);
-    hipLaunchKernelGGL(trk_hist_lo_kernel, dim3(it_blocks), dim3(TRK_BLOCK), 0, stream, n, ws, 0);
-    hipLaunchKernelGGL(trk_select_lo_kernel, dim3(1), dim3(1024), 0, stream, ws, -INFINITY, result + 22, 0);
-    hipLaunchKernelGGL(trk_init_kernel, dim3(1), dim3(64), 0, stream, n, T_WCf, T_WCk, g, ws);
-    for (int it = 0; it < max_iters; ++it) {
-        if (covariance_filter) {
-            hipLaunchKernelGGL(trk_det_kernel, dim3(it_blocks), dim3(TRK_BLOCK), 0, stream, n, height, width, K, ws);
-            hipLaunchKernelGGL(trk_select_hi_kernel, dim3(1), dim3(1024), 0, stream, ws, 0.9f, (const unsigned*)nullptr, n, 1);
-            hipLaunchKernelGGL(trk_hist_lo_kernel, dim3(it_blocks), dim3(TRK_BLOCK), 0, stream, n, ws, 1);
-            hipLaunchKernelGGL(trk_select_lo_kernel, dim3(1), dim3(1024), 0, stream, ws, 1.0f, &ws.state->thr, 1);
-        }
-        hipLaunchKernelGGL(trk_accumulate_kernel, dim3(it_blocks), dim3(TRK_BLOCK), 0, stream, n, height, width, K, g, covariance_filter, ws);
-        hipLaunchKernelGGL(trk_solve_kernel, dim3(1), dim3(64), 0, stream, it_blocks, g, ws, dbg_acc0);
+    if (!resume) {
+        hipLaunchKernelGGL(trk_clear_kernel, dim3(stream_grid(L.zero_bytes / 16, TRK_BLOCK)), dim3(TRK_BLOCK), 0, stream, (uint4*)w, L.zero_bytes / 16);
+        hipLaunchKernelGGL(trk_prepare_kernel, dim3(pt_blocks), dim3(TRK_BLOCK), 0, stream, n, height, width, K, Xf_canon, ws.Xfc, dbg_Xc, dbg_var);
+        hipLaunchKernelGGL(trk_gather_kernel, dim3(pt_blocks), dim3(TRK_BLOCK), 0, stream, n, width, idx_f2k, valid_match, Cf, inv_Nf, Ck, inv_Nk,
+                           Qf, Qk, Xk_canon, g, ws, dbg_valid_opt);
+        // displacement quantile over the valid_opt matches (check_keyframe_map :181-183) + distinct matched frame pixels
+        for (int pass = 0; pass < 3; ++pass)
+            hipLaunchKernelGGL(trk_select_kernel<0>, dim3(TRK_SEL_BLOCKS), dim3(TRK_SEL_THREADS), 0, stream, n, pass, pt_blocks, height, width, K,
+                               ws, dist_quantile_q, -INFINITY, &ws.state->dist_q);
+        hipLaunchKernelGGL(trk_init_kernel, dim3(1), dim3(64), 0, stream, n, T_WCf, T_WCk, g, ws);
+    }
+    for (int it = 0; it < num_iters; ++it) {
+        if (covariance_filter)
+            for (int pass = 0; pass < 3; ++pass)
+                hipLaunchKernelGGL(trk_select_kernel<1>, dim3(TRK_SEL_BLOCKS), dim3(TRK_SEL_THREADS), 0, stream, n, pass, pt_blocks, height, width, K,
+                                   ws, 0.9f, 1.0f, &ws.state->thr);
+        hipLaunchKernelGGL(trk_accumulate_kernel, dim3(TRK_ACC_BLOCKS), dim3(TRK_BLOCK), 0, stream, n, height, width, K, g, covariance_filter,
+                           ws, dbg_acc0);
     }
     hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(64), 0, stream, T_WCf, ws, result);
     ADK_RETURN_LAST_ERROR();

@@ -170,6 +170,43 @@ ADK_HD void quantile_rank(float q, int64_t n, int64_t* lo, int64_t* hi, float* w
 }
 ADK_HD float lerp_torch(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w); }
 
+// Three-level radix select over the 32-bit keys, most significant digit first: 11 + 11 + 10 bits.
+#define TRK_BINS 2048
+ADK_HD int digit_shift(int pass) { return pass == 0 ? 21 : (pass == 1 ? 10 : 0); }
+ADK_HD uint32_t digit_of(uint32_t key, int pass) { return pass == 0 ? (key >> 21) : (pass == 1 ? ((key >> 10) & 2047u) : (key & 1023u)); }
+// the digits above `pass` (pass 1: the top 11 bits, pass 2: the top 22 bits); pass 0 has no prefix
+ADK_HD uint32_t prefix_of(uint32_t key, int pass) { return pass == 0 ? 0u : (pass == 1 ? (key >> 21) : (key >> 10)); }
+ADK_HD uint32_t extend_prefix(uint32_t prefix, uint32_t digit, int pass) { return pass == 0 ? digit : (pass == 1 ? ((prefix << 11) | digit) : ((prefix << 10) | digit)); }
+
+// State of one selection: after pass p, pfx_* hold the digits fixed so far and rem_* the ranks inside them.
+struct Sel {
+    int64_t n, rem_lo, rem_hi;
+    uint32_t pfx_lo, pfx_hi;
+    float w;
+    int same; // pfx_lo == pfx_hi (one histogram serves both ranks)
+};
+
+// rem_* start as the global ranks floor / ceil of q (n - 1) and are refined pass by pass.
+ADK_HD void sel_begin(Sel& s, float q, int64_t n) {
+    s.n = n; s.pfx_lo = s.pfx_hi = 0u; s.same = 1; s.w = 0.f; s.rem_lo = s.rem_hi = 0;
+    if (n > 0) {
+        int64_t lo, hi;
+        quantile_rank(q, n, &lo, &hi, &s.w);
+        if (lo < 0) lo = 0;
+        if (hi > n - 1) hi = n - 1;
+        if (lo > hi) lo = hi;
+        s.rem_lo = lo; s.rem_hi = hi;
+    }
+}
+ADK_HD void sel_advance(Sel& s, int pass, uint32_t d_lo, int64_t r_lo, uint32_t d_hi, int64_t r_hi) {
+    s.pfx_lo = extend_prefix(s.pfx_lo, d_lo, pass);
+    s.pfx_hi = extend_prefix(s.pfx_hi, d_hi, pass);
+    s.rem_lo = r_lo; s.rem_hi = r_hi;
+    s.same = s.pfx_lo == s.pfx_hi;
+}
+// after pass 2 the prefixes are the two order statistics' keys
+ADK_HD float sel_value(const Sel& s) { return s.n > 0 ? lerp_torch(key_float(s.pfx_lo), key_float(s.pfx_hi), s.w) : 0.f; }
+
 // Walk `nbins` histogram bins until the cumulative count passes `rank` (0-based): returns the bin, *rem = rank inside it.
 ADK_HD int locate_rank(const uint32_t* hist, int nbins, int64_t rank, int64_t* rem) {
     int64_t acc = 0;
@@ -243,6 +280,8 @@ struct State {
     int iters, done, fail, lost;
     float thr;         // covariance-filter threshold of the current iteration
     float tau[7];      // last step
+    float dist_q;      // displacement quantile (check_keyframe_map)
+    unsigned n_opt, n_kf, n_unique;
 };
 
 // H tau = -v by Cholesky in double; false when a pivot is not positive (torch.linalg.cholesky would raise).

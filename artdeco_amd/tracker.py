@@ -3,7 +3,7 @@
 `CameraTracker` keeps the reference's constructor, attributes and `track(frame) -> (lost, is_keyframe,
 is_keyframe_map)` contract (CameraTracker.py:19-155), so `VSLAM/Frontend.py:34,80` can use it unchanged; everything
 between the MASt3R match and the keyframe decision is ONE C-ABI call (`adk_track_frame`, artdeco_amd/csrc/tracker.hip)
-and ONE 24-float host read, where the reference issues ~100 torch launches and three blocking reads per
+and ONE 32-float host read (more only when six iterations did not converge), where the reference issues ~100 torch launches and three blocking reads per
 Gauss-Newton iteration.  Poses may be pypose `Sim3` LieTensors (the reference's type) or plain [1,8] tensors
 (t, q xyzw, s).  There is no CPU fallback: CPU tensors raise.
 """
@@ -54,50 +54,91 @@ def wrap_pose(like, raw: torch.Tensor):
     return type(like)(raw.reshape(1, 8))
 
 
-def track_frame(height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
-                covariance_filter=True, thres_keyframe=0.8, debug=False):
-    """Enqueue one tracking problem; returns (result [24] device tensor, debug dict).  No host synchronisation.
+class TrackJob:
+    """One tracking problem on the device.  Construction enqueues the preparation and the first CHUNK of Gauss-Newton
+    iterations (no host synchronisation); `outcome()` reads the 32-float result and, only if that chunk did not converge,
+    enqueues further chunks (resume) up to cfg["max_iters"].  Inputs, workspace and result stay referenced here.
 
     Xf_canon / Cf / Qf: the frame's canonical pointmap [n,3], SUMMED confidence [n] (average = Cf / Nf) and descriptor
     confidence [n]; Xk_canon / Ck / Nk / Qk the keyframe's (Qk = Qkf of the match); idx_f2k [n] int64, valid_match [n]
-    bool in keyframe pixel order; T_WCf / T_WCk [8]; cfg = config["tracking"] (config/base.yaml:19-34)."""
-    n = int(height) * int(width)
-    tens = dict(K=K, Xf_canon=Xf_canon, Cf=Cf, Qf=Qf, Xk_canon=Xk_canon, Ck=Ck, Qk=Qk, idx_f2k=idx_f2k, valid_match=valid_match,
-                T_WCf=T_WCf, T_WCk=T_WCk)
-    _lib.require_cuda(*tens.values())
-    dev = Xf_canon.device
-    K = _f32c(K.to(dev), "K")
-    Xf_canon, Xk_canon = _f32c(Xf_canon, "Xf_canon"), _f32c(Xk_canon, "Xk_canon")
-    Cf, Ck, Qf, Qk = (_f32c(t.reshape(-1), s) for t, s in ((Cf, "Cf"), (Ck, "Ck"), (Qf, "Qf"), (Qk, "Qk")))
-    if Xf_canon.shape != (n, 3) or Xk_canon.shape != (n, 3) or any(t.numel() != n for t in (Cf, Ck, Qf, Qk)):
-        raise ValueError("tracker: pointmaps [H*W,3] and confidences [H*W] expected")
-    if idx_f2k.dtype != torch.int64 or idx_f2k.numel() != n:
-        raise TypeError("tracker: idx_f2k must be int64 [H*W]")
-    if valid_match.dtype != torch.bool or valid_match.numel() != n:
-        raise TypeError("tracker: valid_match must be bool [H*W]")
-    idx_f2k, valid_match = idx_f2k.reshape(-1).contiguous(), valid_match.reshape(-1).contiguous()
-    T_WCf, T_WCk = _f32c(T_WCf.reshape(-1), "T_WCf"), _f32c(T_WCk.reshape(-1), "T_WCk")
-    if K.numel() != 9 or T_WCf.numel() != 8 or T_WCk.numel() != 8:
-        raise ValueError("tracker: K [3,3] and poses [8] expected")
-    lib = _lib.load()
-    with torch.cuda.device(dev):
-        result = torch.empty(24, dtype=torch.float32, device=dev)
-        dbg = {}
-        if debug:
-            dbg = dict(Xc=torch.empty(n, 3, dtype=torch.float32, device=dev), var=torch.empty(n, 3, dtype=torch.float32, device=dev),
-                       valid_opt=torch.empty(n, dtype=torch.uint8, device=dev), acc0=torch.zeros(36, dtype=torch.float32, device=dev))
-        ws = torch.empty(int(lib.adk_track_workspace_bytes(int(height), int(width))), dtype=torch.uint8, device=dev)
-        rc = lib.adk_track_frame(int(height), int(width), K.data_ptr(), Xf_canon.data_ptr(), Cf.data_ptr(), 1.0 / float(Nf),
-                                 Qf.data_ptr(), Xk_canon.data_ptr(), Ck.data_ptr(), 1.0 / float(Nk), Qk.data_ptr(), idx_f2k.data_ptr(),
-                                 valid_match.data_ptr(), T_WCf.data_ptr(), T_WCk.data_ptr(), float(cfg["sigma_pixel"]),
-                                 float(cfg["sigma_depth"]), float(cfg["huber"]), float(cfg["C_conf"]), float(cfg["Q_conf"]),
-                                 float(cfg["min_match_frac"]), int(cfg["pixel_border"]), float(cfg["depth_eps"]),
-                                 float(cfg["rel_error"]), float(cfg["delta_norm"]), int(cfg["max_iters"]), int(bool(covariance_filter)),
-                                 float(thres_keyframe), result.data_ptr(), _lib.ptr(dbg.get("Xc")), _lib.ptr(dbg.get("var")),
-                                 _lib.ptr(dbg.get("valid_opt")), _lib.ptr(dbg.get("acc0")), ws.data_ptr(), ws.numel(),
-                                 _lib.stream_of(Xf_canon))
-    _lib.check(rc, "adk_track_frame")
-    return result, dbg
+    bool in keyframe pixel order; T_WCf / T_WCk [8]; cfg = config["tracking"] (config/base.yaml:19-34).
+    chunk: iterations per call (None = all of cfg["max_iters"] at once, i.e. never more than one host read)."""
+
+    def __init__(self, height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
+                 covariance_filter=True, thres_keyframe=0.8, debug=False, chunk=6):
+        n = int(height) * int(width)
+        _lib.require_cuda(K, Xf_canon, Cf, Qf, Xk_canon, Ck, Qk, idx_f2k, valid_match, T_WCf, T_WCk)
+        dev = Xf_canon.device
+        K = _f32c(K.to(dev), "K")
+        Xf_canon, Xk_canon = _f32c(Xf_canon, "Xf_canon"), _f32c(Xk_canon, "Xk_canon")
+        Cf, Ck, Qf, Qk = (_f32c(t.reshape(-1), s) for t, s in ((Cf, "Cf"), (Ck, "Ck"), (Qf, "Qf"), (Qk, "Qk")))
+        if Xf_canon.shape != (n, 3) or Xk_canon.shape != (n, 3) or any(t.numel() != n for t in (Cf, Ck, Qf, Qk)):
+            raise ValueError("tracker: pointmaps [H*W,3] and confidences [H*W] expected")
+        if idx_f2k.dtype != torch.int64 or idx_f2k.numel() != n:
+            raise TypeError("tracker: idx_f2k must be int64 [H*W]")
+        if valid_match.dtype != torch.bool or valid_match.numel() != n:
+            raise TypeError("tracker: valid_match must be bool [H*W]")
+        idx_f2k, valid_match = idx_f2k.reshape(-1).contiguous(), valid_match.reshape(-1).contiguous()
+        T_WCf, T_WCk = _f32c(T_WCf.reshape(-1), "T_WCf"), _f32c(T_WCk.reshape(-1), "T_WCk")
+        if K.numel() != 9 or T_WCf.numel() != 8 or T_WCk.numel() != 8:
+            raise ValueError("tracker: K [3,3] and poses [8] expected")
+        self.height, self.width, self.n, self.dev = int(height), int(width), n, dev
+        self.cfg, self.cov, self.thres = cfg, bool(covariance_filter), float(thres_keyframe)
+        self.max_iters = int(cfg["max_iters"])
+        self.chunk = self.max_iters if chunk is None else max(1, int(chunk))
+        self.inv_Nf, self.inv_Nk = 1.0 / float(Nf), 1.0 / float(Nk)
+        self._t = (K, Xf_canon, Cf, Qf, Xk_canon, Ck, Qk, idx_f2k, valid_match, T_WCf, T_WCk)  # keep alive across resumes
+        self.lib = _lib.load()
+        with torch.cuda.device(dev):
+            self.result = torch.empty(32, dtype=torch.float32, device=dev)
+            self.dbg = {}
+            if debug:
+                self.dbg = dict(Xc=torch.empty(n, 3, dtype=torch.float32, device=dev), var=torch.empty(n, 3, dtype=torch.float32, device=dev),
+                                valid_opt=torch.empty(n, dtype=torch.uint8, device=dev), acc0=torch.zeros(36, dtype=torch.float32, device=dev))
+            self.ws = torch.empty(int(self.lib.adk_track_workspace_bytes(self.height, self.width)), dtype=torch.uint8, device=dev)
+        self.enqueued = 0
+        self.host_reads = 0
+        self._enqueue(resume=False)
+
+    def _enqueue(self, resume: bool) -> None:
+        K, Xf_canon, Cf, Qf, Xk_canon, Ck, Qk, idx_f2k, valid_match, T_WCf, T_WCk = self._t
+        cfg, dbg = self.cfg, ({} if resume else self.dbg)
+        num = min(self.chunk, self.max_iters - self.enqueued)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.adk_track_frame(
+                self.height, self.width, K.data_ptr(), Xf_canon.data_ptr(), Cf.data_ptr(), self.inv_Nf, Qf.data_ptr(), Xk_canon.data_ptr(),
+                Ck.data_ptr(), self.inv_Nk, Qk.data_ptr(), idx_f2k.data_ptr(), valid_match.data_ptr(), T_WCf.data_ptr(), T_WCk.data_ptr(),
+                float(cfg["sigma_pixel"]), float(cfg["sigma_depth"]), float(cfg["huber"]), float(cfg["C_conf"]), float(cfg["Q_conf"]),
+                float(cfg["min_match_frac"]), int(cfg["pixel_border"]), float(cfg["depth_eps"]), float(cfg["rel_error"]),
+                float(cfg["delta_norm"]), int(num), int(self.cov), self.thres, int(resume), self.result.data_ptr(), _lib.ptr(dbg.get("Xc")),
+                _lib.ptr(dbg.get("var")), _lib.ptr(dbg.get("valid_opt")), _lib.ptr(dbg.get("acc0")), self.ws.data_ptr(), self.ws.numel(),
+                _lib.stream_of(Xf_canon))
+        _lib.check(rc, "adk_track_frame")
+        self.enqueued += num
+
+    def outcome(self) -> "TrackOutcome":
+        """The host synchronisation(s) of a tracked frame: one 128-byte copy per enqueued chunk (normally one)."""
+        while True:
+            h = self.result.cpu().numpy()
+            self.host_reads += 1
+            if h[24] != 0 or self.enqueued >= self.max_iters:
+                break
+            self._enqueue(resume=True)
+        r = self.result
+        return TrackOutcome(T_WCf=r[0:8], T_CkCf=r[8:16], lost=bool(h[16] != 0), failed=bool(h[17] != 0), iterations=int(h[18]),
+                            n_opt=int(h[19]), n_kf=int(h[20]), n_unique=int(h[21]), dist_quantile=float(h[22]), cost=float(h[23]))
+
+
+def track_frame(height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
+                covariance_filter=True, thres_keyframe=0.8, debug=False, chunk=None):
+    """Run one tracking problem to completion; returns (result [32] device tensor, debug dict).  With chunk=None all
+    cfg["max_iters"] iterations are enqueued at once and nothing synchronises; with a chunk size the host reads the
+    result between chunks (see TrackJob)."""
+    job = TrackJob(height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
+                   covariance_filter, thres_keyframe, debug, chunk)
+    if chunk is not None:
+        job.outcome()
+    return job.result, job.dbg
 
 
 def fuse_pointmap(result, Xkf, Ckf, X_canon, C):
@@ -117,7 +158,7 @@ def fuse_pointmap(result, Xkf, Ckf, X_canon, C):
 
 
 def read_outcome(result: torch.Tensor) -> TrackOutcome:
-    """THE host synchronisation of a tracked frame: one 96-byte copy."""
+    """Host view of a FINISHED result (one 128-byte copy)."""
     h = result.cpu().numpy()
     return TrackOutcome(T_WCf=result[0:8], T_CkCf=result[8:16], lost=bool(h[16] != 0), failed=bool(h[17] != 0), iterations=int(h[18]),
                         n_opt=int(h[19]), n_kf=int(h[20]), n_unique=int(h[21]), dist_quantile=float(h[22]), cost=float(h[23]))
@@ -165,6 +206,7 @@ class CameraTracker:
         self.last_embedding = None
         self.last_dist = 0
         self.last_outcome = None
+        self.iters_per_call = 6  # Gauss-Newton iterations enqueued per host read (typical convergence: 3-5)
         self.reset_idx_f2k()
 
     def _match(self):
@@ -197,14 +239,15 @@ class CameraTracker:
         self.idx_f2k = idx_f2k.clone()
         frame.update_pointmap(Xff, Cff)
         n = self.H_slam * self.W_slam
-        result, _ = track_frame(self.H_slam, self.W_slam, self.K_slam, frame.X_canon, frame.C, frame.N, Qff, keyframe.X_canon,
-                                keyframe.C, keyframe.N, Qkf, idx_f2k[0], valid_match_k[0], raw_pose(frame.T_WC).to(self.device),
-                                raw_pose(keyframe.T_WC).to(self.device), self.cfg, self.covariance_filter, self.thres_keyframe)
+        job = TrackJob(self.H_slam, self.W_slam, self.K_slam, frame.X_canon, frame.C, frame.N, Qff, keyframe.X_canon, keyframe.C,
+                       keyframe.N, Qkf, idx_f2k[0], valid_match_k[0], raw_pose(frame.T_WC).to(self.device),
+                       raw_pose(keyframe.T_WC).to(self.device), self.cfg, self.covariance_filter, self.thres_keyframe,
+                       chunk=self.iters_per_call)
+        o = self.last_outcome = job.outcome()
         X_new = C_new = None
-        if self.point_fusion_frontend:
+        if self.point_fusion_frontend and not (o.lost or o.failed):
             X_new, C_new = keyframe.X_canon.clone().contiguous(), keyframe.C.clone().contiguous()
-            fuse_pointmap(result, Xkf, Ckf, X_new, C_new)
-        o = self.last_outcome = read_outcome(result)
+            fuse_pointmap(job.result, Xkf, Ckf, X_new, C_new)
         if o.lost:
             print(f"Insufficient match {frame.frame_id}")
             return True, False, False

@@ -355,21 +355,26 @@ int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_points, flo
  * ImageFrame.get_average_conf) and descriptor confidence, frame pixel order; Xk_canon / Ck / Qk: the keyframe's
  * (Qk = the keyframe-in-frame descriptor confidence Qkf); idx_f2k [n] int64 and valid_match [n] bytes in keyframe
  * pixel order; K [3,3] row-major, T_WCf / T_WCk [8] = (t3, q xyzw, s): all DEVICE memory.  n = height * width.
- * result [24] floats (device): [0..7] new T_WCf (quat2unit'd; the input pose when lost or failed), [8..15] T_CkCf,
- * [16] lost (matches below min_match_frac), [17] Cholesky failed, [18] iterations, [19] valid_opt count,
- * [20] valid_kf count, [21] number of distinct matched frame pixels, [22] dist_quantile_q-quantile of the match
- * displacement over valid_opt (torch.quantile semantics), [23] cost of the last linearisation.
- * dbg_* (optional): constrained frame points [n,3], local variances [n,3], valid_opt [n] bytes, the summed
- * accumulators of iteration 0 [36] (28 lower-triangle H, 7 J^T e, cost).
- * All max_iters iterations are enqueued and become no-ops once converged; the call never synchronises. */
+ * result [32] floats (device): [0..7] new T_WCf (quat2unit'd; the input pose when lost or failed), [8..15] T_CkCf,
+ * [16] lost (matches below min_match_frac), [17] Cholesky failed, [18] iterations done so far, [19] valid_opt
+ * count, [20] valid_kf count, [21] number of distinct matched frame pixels, [22] dist_quantile_q-quantile of the
+ * match displacement over valid_opt (torch.quantile semantics), [23] cost of the last linearisation, [24] finished
+ * (converged, lost or failed), [25] last covariance-filter threshold, [26..31] zero.
+ * A call enqueues num_iters Gauss-Newton iterations (they become no-ops once converged) and never synchronises.
+ * resume = 0: full call (prepare, gather, statistics, init, iterations).  resume = 1: only further iterations on the
+ * state left in the SAME workspace by the previous call (same inputs): the host reads result[24] and continues in
+ * chunks until finished or the reference's max_iters (50) is reached -- a no-op launch still costs ~4 us of GPU time,
+ * so enqueueing all 50 iterations up front would triple the cost of a frame that converges in three.
+ * dbg_* (optional, resume = 0): constrained frame points [n,3], local variances [n,3], valid_opt [n] bytes, the
+ * summed accumulators of iteration 0 [36] (28 lower-triangle H, 7 J^T e, cost). */
 int64_t adk_track_workspace_bytes(int height, int width);
 int adk_track_frame(int height, int width, const float* K, const float* Xf_canon, const float* Cf, float inv_Nf,
                     const float* Qf, const float* Xk_canon, const float* Ck, float inv_Nk, const float* Qk,
                     const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
                     float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
                     float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
-                    int max_iters, int covariance_filter, float dist_quantile_q, float* result, float* dbg_Xc,
-                    float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace,
+                    int num_iters, int covariance_filter, float dist_quantile_q, int resume, float* result,
+                    float* dbg_Xc, float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace,
                     int64_t workspace_bytes, adk_stream_t stream);
 /* Point fusion after a successful track (CameraTracker.py:136-141 + ImageFrame.update_pointmap, ImageFrame.py:30-48):
  * X_canon = (C X_canon + Ckf (T_CkCf Xkf)) / (C + Ckf), C += Ckf, in place; a no-op when result[16] or result[17]

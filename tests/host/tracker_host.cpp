@@ -16,27 +16,30 @@ using namespace adk::trk;
 namespace {
 
 struct Select {
-    std::vector<uint32_t> hist_hi, hist_lo_a, hist_lo_b;
-    Select() : hist_hi(65536), hist_lo_a(65536), hist_lo_b(65536) {}
-    // keys: TRK skip key 0xFFFFFFFF is ignored; n = population size
+    std::vector<uint32_t> hA, hB;
+    Select() : hA(TRK_BINS), hB(TRK_BINS) {}
+    // keys: the skip key 0xFFFFFFFF is ignored; n = population size.  Same three passes as trk_select_kernel.
     float run(const std::vector<uint32_t>& keys, int64_t n, float q) {
-        std::fill(hist_hi.begin(), hist_hi.end(), 0u);
-        std::fill(hist_lo_a.begin(), hist_lo_a.end(), 0u);
-        std::fill(hist_lo_b.begin(), hist_lo_b.end(), 0u);
-        if (n <= 0) return 0.f;
-        for (uint32_t k : keys) if (k != 0xFFFFFFFFu) hist_hi[k >> 16]++;
-        int64_t lo, hi, rem_lo, rem_hi, r;
-        float w;
-        quantile_rank(q, n, &lo, &hi, &w);
-        if (hi > n - 1) hi = n - 1;
-        const int bin_lo = locate_rank(hist_hi.data(), 65536, lo, &rem_lo), bin_hi = locate_rank(hist_hi.data(), 65536, hi, &rem_hi);
-        for (uint32_t k : keys) {
-            if (k == 0xFFFFFFFFu) continue;
-            if ((int)(k >> 16) == bin_lo) hist_lo_a[k & 0xffffu]++;
-            if ((int)(k >> 16) == bin_hi) hist_lo_b[k & 0xffffu]++;
+        Sel sel;
+        sel_begin(sel, q, n);
+        for (int pass = 0; pass < 3; ++pass) {
+            std::fill(hA.begin(), hA.end(), 0u);
+            std::fill(hB.begin(), hB.end(), 0u);
+            const bool two = pass > 0 && !sel.same;
+            for (uint32_t k : keys) {
+                if (k == 0xFFFFFFFFu) continue;
+                const uint32_t d = digit_of(k, pass);
+                if (pass == 0) { hA[d]++; continue; }
+                const uint32_t pf = prefix_of(k, pass);
+                if (pf == sel.pfx_lo) hA[d]++;
+                if (two && pf == sel.pfx_hi) hB[d]++;
+            }
+            int64_t r_lo, r_hi;
+            const int b_lo = locate_rank(hA.data(), TRK_BINS, sel.rem_lo, &r_lo);
+            const int b_hi = locate_rank(two ? hB.data() : hA.data(), TRK_BINS, sel.rem_hi, &r_hi);
+            if (sel.n > 0) sel_advance(sel, pass, (uint32_t)b_lo, r_lo, (uint32_t)b_hi, r_hi);
         }
-        const uint32_t la = (uint32_t)locate_rank(hist_lo_a.data(), 65536, rem_lo, &r), lb = (uint32_t)locate_rank(hist_lo_b.data(), 65536, rem_hi, &r);
-        return lerp_torch(key_float(((uint32_t)bin_lo << 16) | la), key_float(((uint32_t)bin_hi << 16) | lb), w);
+        return sel_value(sel);
     }
 };
 
@@ -61,7 +64,7 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
                               const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
                               float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
                               float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
-                              int max_iters, int covariance_filter, float dist_quantile_q, float* result, float* dbg_Xc,
+                              int max_iters, int covariance_filter, float dist_quantile_q, float* result /* [32] */, float* dbg_Xc,
                               float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, float* dbg_thr /* [max_iters] */)
 {
     const int n = height * width, H = height, W = width;
@@ -156,7 +159,8 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
     for (int i = 0; i < 8; ++i) result[8 + i] = s.T[i];
     result[16] = (float)s.lost; result[17] = (float)s.fail; result[18] = (float)s.iters;
     result[19] = (float)counts[0]; result[20] = (float)counts[1]; result[21] = (float)counts[2];
-    result[23] = (float)s.cost;
+    result[23] = (float)s.cost; result[24] = (float)s.done; result[25] = s.thr;
+    for (int i = 26; i < 32; ++i) result[i] = 0.f;
     return 0;
 }
 

@@ -107,7 +107,7 @@ def run_host(host, sc, cov, thres, cfg=CFG, max_iters=None):
     arrs = dict(K=f(sc["K"]), Xf=f(sc["Xff"]), Cf=f(sc["Cff"]), Qf=f(sc["Qff"]), Xk=f(sc["Xk_canon"]), Ck=f(sc["Ck"]), Qk=f(sc["Qkf"]),
                 idx=np.ascontiguousarray(sc["idx_f2k"]), vm=np.ascontiguousarray(sc["valid_match"].astype(np.uint8)),
                 Tf=f(sc["T_WCf0"]), Tk=f(sc["T_WCk"]))
-    res = np.zeros(24, np.float32)
+    res = np.zeros(32, np.float32)
     mi = int(cfg["max_iters"] if max_iters is None else max_iters)
     dbg = dict(Xc=np.zeros((n, 3), np.float32), var=np.zeros((n, 3), np.float32), valid_opt=np.zeros(n, np.uint8), acc0=np.zeros(36, np.float32),
                thr=np.zeros(max(mi, 1), np.float32))
@@ -122,13 +122,13 @@ def run_host(host, sc, cov, thres, cfg=CFG, max_iters=None):
     return res, dbg
 
 
-def run_hip(dev, sc, cov, thres, cfg=CFG, max_iters=None):
+def run_hip(dev, sc, cov, thres, cfg=CFG, max_iters=None, chunk=None):
     from artdeco_amd import tracker as T
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     cfg = dict(cfg, max_iters=cfg["max_iters"] if max_iters is None else max_iters)
     res, dbg = T.track_frame(sc["height"], sc["width"], t(sc["K"]), t(sc["Xff"]), t(sc["Cff"]), 1, t(sc["Qff"]), t(sc["Xk_canon"]),
                              t(sc["Ck"]), 1, t(sc["Qkf"]), t(sc["idx_f2k"]), t(sc["valid_match"]), t(sc["T_WCf0"]), t(sc["T_WCk"]), cfg,
-                             covariance_filter=cov, thres_keyframe=thres, debug=True)
+                             covariance_filter=cov, thres_keyframe=thres, debug=True, chunk=chunk)
     torch.cuda.synchronize()
     return res.cpu().numpy(), {k: v.cpu().numpy() for k, v in dbg.items()}
 
@@ -275,6 +275,19 @@ def test_hip_tracker_is_bit_reproducible(dev, lib):
     a, _ = run_hip(dev, sc, True, 0.8)
     b, _ = run_hip(dev, sc, True, 0.8)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tracker_far", "tracker_rough", "tracker_lost"])
+def test_hip_tracker_chunked_iterations_are_identical(name, dev, lib):
+    """Enqueueing the iterations in chunks (host reads result[24] in between, resume = 1) is the same computation."""
+    sc, d = load_case(name)
+    cov = bool(d["covariance_filter"])
+    full, _ = run_hip(dev, sc, cov, 0.8)
+    for chunk in (1, 2, 6):
+        part, _ = run_hip(dev, sc, cov, 0.8, chunk=chunk)
+        assert np.array_equal(full, part), chunk
+    assert full[24] == 1.0
 
 
 @pytest.mark.gpu
