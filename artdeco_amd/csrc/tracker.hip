@@ -15,8 +15,8 @@
 //   * the covariance determinant is evaluated in closed form, (fx fy s^3 / Z^3)^2 vx vy vz, instead of an LU of J S J^T;
 //   * torch.quantile's two order statistics come from a three-level (11 + 11 + 10 bit) radix SELECT over order-preserving
 //     keys: exact, no sort.  Histograms are built in LDS per workgroup and written out as per-workgroup partials; NO
-//     global atomics on the data path -- measured on MI355X, a device-scope atomic costs ~3 ns wherever it lands (it is
-//     resolved below the per-XCD L2s), so the first version's 196 608 atomicAdds per pass took 0.5 ms per kernel;
+//     global atomics on the data path -- measured on MI355X, the first version's 196 608 atomicAdds per pass into a
+//     global histogram (most of them on a few hot bins, ~2.7 ns each) took 0.5 ms per kernel;
 //   * "last workgroup to arrive finishes the job": the workgroup that draws the last ticket of a launch reduces the
 //     partials (histogram totals + rank search, or the 36 normal-equation sums + 7x7 Cholesky + retraction +
 //     convergence test), so an iteration is 4 launches (3 select passes + accumulate) and a device flag turns the
