@@ -150,6 +150,15 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profile(args),
                          "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms},
         }
+        valu = _valu_from_profile(args)
+        if valu is not None:
+            # The kernel the metric prices against HBM is bounded by vector-ALU ISSUE: wave64 VALU
+            # instructions per launch from the committed SQ_INSTS_VALU PMC pass of this workload, over the live launch time,
+            # against 1024 SIMDs x 2.4 GHz / 4 cycles per instruction.
+            peak_valu = 1024 * 2.4e9 / 4.0 / 1e9
+            ach = valu / (bwd_ms * 1e-3) / 1e9
+            out["roofline_valu"] = {"bound": "valu-issue", "kernel": "raster_bwd_kernel", "achieved": ach, "peak": peak_valu,
+                                    "unit": "G wave-instr/s", "frac": ach / peak_valu, "wave_insts_per_launch": valu}
         if not args.no_extra_configs and world == 1:
             out["other_configs"] = extra_configs(args, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -211,6 +220,17 @@ def _traffic_from_profile(args):
         t = json.load(open(p))
         if (t.get("gaussians"), t.get("width"), t.get("height")) == (args.gaussians, args.width, args.height):
             return t.get("raster_bwd_hbm_bytes")
+    except Exception:
+        pass
+    return None
+
+
+def _valu_from_profile(args):
+    """Wave64 VALU instructions per raster_bwd launch from the committed PMC pass (same workload only), else None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if (t.get("gaussians"), t.get("width"), t.get("height")) == (args.gaussians, args.width, args.height):
+            return t.get("raster_bwd_valu_wave_insts")
     except Exception:
         pass
     return None
