@@ -299,6 +299,13 @@ __device__ inline void adj_inv_matrix(const Sim3& T, double M[7][7]) {
 
 struct GnSys { double* A; int D, Dp; int* done; int* fail; };
 
+// Zero-fill as a kernel: a hipMemsetAsync node captured into a hipGraph is not ordered before the kernel nodes that
+// follow it (observed on ROCm 7.2 / MI355X), and this entry point should be capturable.
+__global__ __launch_bounds__(256) void gn_clear_kernel(uint4* __restrict__ p, int64_t n16)
+{
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ __launch_bounds__(1024) void gn_assemble_kernel(
     const float* __restrict__ Twc, int num_fix, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int num_edges,
     int num_chunks, const float* __restrict__ partials, GnSys sys, float* __restrict__ Hs_dbg /* [4][E][7][7] or null */,
@@ -535,8 +542,7 @@ extern "C" int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_
     float* partials = (float*)(w + 256);
     double* A = (double*)(w + 256 + gn_align((int64_t)num_edges * chunks * GN_NACC * 4));
     const size_t a_bytes = (size_t)(Dp + GN_TB) * Dp * sizeof(double);
-    hipError_t err = hipMemsetAsync(done, 0, 256, stream);
-    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(adk::gn_clear_kernel, dim3(1), dim3(256), 0, stream, (uint4*)done, (int64_t)16);
     adk::GnArgs a;
     a.Twc = Twc; a.Xs = Xs; a.Cs = Cs; a.K = K; a.ii = ii; a.jj = jj; a.idx = idx_ii2jj; a.valid = valid_match; a.Q = Q;
     a.num_points = num_points;
@@ -557,8 +563,8 @@ extern "C" int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_
             else if (kind == 1) hipLaunchKernelGGL(adk::gn_accumulate_kernel<1>, grid, dim3(256), 0, stream, a);
             else hipLaunchKernelGGL(adk::gn_accumulate_kernel<2>, grid, dim3(256), 0, stream, a);
         }
-        err = hipMemsetAsync(A, 0, a_bytes, stream); // unconditional (cheap); the kernels below are no-ops once `done`
-        if (err != hipSuccess) return (int)err;
+        // unconditional (cheap); the kernels below are no-ops once `done`
+        hipLaunchKernelGGL(adk::gn_clear_kernel, dim3(adk::stream_grid((int64_t)(a_bytes / 16), 256)), dim3(256), 0, stream, (uint4*)A, (int64_t)(a_bytes / 16));
         hipLaunchKernelGGL(adk::gn_assemble_kernel, dim3((unsigned)adk::ceil_div(asm_items > 0 ? asm_items : 1, 256)), dim3(256), 0, stream,
                            (const float*)Twc, num_fix, ii, jj, num_edges, chunks, (const float*)partials, sys, Hs_dbg, gs_dbg);
         for (int kb = 0; kb < nbk; ++kb) {

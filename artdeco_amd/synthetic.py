@@ -155,7 +155,7 @@ def calib_keyframe_graph(num_poses=4, height=48, width=64, seed=0, extra_edges=2
 
 
 def tracker_scene(height=48, width=64, seed=0, fx=70.0, pose_noise=0.03, depth_noise=0.01, outlier_frac=0.03,
-                  kf_pose=None, drop_frac=0.0, rough_cols=0.0):
+                  kf_pose=None, drop_frac=0.0, rough_cols=0.0, kf_N=1, bad_depth_frac=0.0):
     """One frame-to-keyframe tracking problem (VSLAM/CameraTracker.py:53-155): a keyframe (pose 0 of a 2-pose
     `calib_keyframe_graph`, i.e. points on its own pixel rays of one smooth world surface) and a frame (pose 1), with
     what `mast3r_match_asymmetric` hands the tracker (utils_mast3r.py:144-170):
@@ -169,7 +169,9 @@ def tracker_scene(height=48, width=64, seed=0, fx=70.0, pose_noise=0.03, depth_n
     non-trivial (covariance filter); `outlier_frac` of the matches point at random frame pixels; 10 % carry a
     descriptor confidence below the 1.5 threshold; `drop_frac` of the matches are flagged invalid (a frame that
     barely overlaps the keyframe); the right-hand `rough_cols` of the frame's columns get a very noisy depth
-    (local pixel-covariance determinants above 1: the 0.9-quantile branch of the covariance filter).  float32 / int64 / bool numpy arrays."""
+    (local pixel-covariance determinants above 1: the 0.9-quantile branch of the covariance filter).  `kf_N` > 1: the
+    keyframe's stored map is the confidence-weighted mean of kf_N predictions (`Ck` is their SUM, ImageFrame.py:30-52);
+    `bad_depth_frac` of the pixels of both maps get a negative depth (behind the camera: invalid measurements).  float32 / int64 / bool numpy arrays."""
     rng = np.random.default_rng(seed + 1000)
     g = calib_keyframe_graph(num_poses=2, height=height, width=width, seed=seed, extra_edges=0, fx=fx)
     n = height * width
@@ -198,6 +200,15 @@ def tracker_scene(height=48, width=64, seed=0, fx=70.0, pose_noise=0.03, depth_n
     Qff, Qkf = conf(1.6), conf(1.6)
     Qkf[rng.random(n) < 0.1, 0] = 1.0
     T0 = perturb_poses(T, rng, pose_noise)
-    return dict(height=height, width=width, K=g["K"], Xff=Xff, Cff=conf(1.0), Qff=Qff, Xkf=Xkf, Ckf=conf(1.0), Qkf=Qkf,
-                Xk_canon=Xk_canon, Ck=conf(1.0), idx_f2k=idx, valid_match=valid, T_WCk=T[0:1].copy(), T_WCf0=T0[1:2].copy(),
+    Ck = conf(1.0)
+    for _ in range(int(kf_N) - 1):  # further predictions fused into the keyframe (update_pointmap)
+        Xn, Cn = noisy(g["Xs"][0]), conf(1.0)
+        Xk_canon = ((Ck * Xk_canon + Cn * Xn) / (Ck + Cn)).astype(np.float32)
+        Ck = (Ck + Cn).astype(np.float32)
+    if bad_depth_frac > 0:
+        for X in (Xk_canon, Xff):
+            bad = rng.random(n) < bad_depth_frac
+            X[bad, 2] = -np.abs(X[bad, 2])
+    return dict(kf_N=int(kf_N), height=height, width=width, K=g["K"], Xff=Xff, Cff=conf(1.0), Qff=Qff, Xkf=Xkf, Ckf=conf(1.0), Qkf=Qkf,
+                Xk_canon=Xk_canon, Ck=Ck, idx_f2k=idx, valid_match=valid, T_WCk=T[0:1].copy(), T_WCf0=T0[1:2].copy(),
                 T_WCf_gt=T[1:2].copy())

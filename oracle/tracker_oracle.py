@@ -248,10 +248,11 @@ def update_pointmap(X_canon, C, N, X, Cn):
 
 
 def track(sc, cfg=None, covariance_filter=True, min_displacement=30.0, thres_keyframe=0.8, last_dist=0.0, det_mode="lu",
-          kf_N=1, trace=None):
+          kf_N=None, trace=None):
     """CameraTracker.track (:53-155) on a `tracker_scene` dict for a FRESH frame (frame.N == 0) and a keyframe that holds
     (Xk_canon, Ck, kf_N).  Returns a dict with the reference's observable effects."""
     cfg = dict(BASE_CFG, **(cfg or {}))
+    kf_N = int(sc.get("kf_N", 1)) if kf_N is None else kf_N
     H, W, K = sc["height"], sc["width"], sc["K"].astype(F)
     n = H * W
     idx = sc["idx_f2k"]

@@ -50,6 +50,8 @@ CASES = {
                               kf_pose=np.array([0.3, -0.2, 0.1, 0.05, -0.08, 0.03, 0.9949, 1.2])), True, 2.0, 0.5),
     "tracker_ragged": (dict(height=37, width=53, seed=3, fx=55.0, depth_noise=0.03, outlier_frac=0.1), True, 1.0, 0.0),
     "tracker_rough": (dict(height=48, width=64, seed=7, fx=70.0, rough_cols=0.3), True, 30.0, 0.0),
+    "tracker_kfN3": (dict(height=48, width=64, seed=8, fx=70.0, kf_N=3), True, 30.0, 0.0),
+    "tracker_baddepth": (dict(height=48, width=64, seed=9, fx=70.0, bad_depth_frac=0.03), True, 30.0, 0.0),
     "tracker_far": (dict(height=48, width=64, seed=4, fx=70.0, pose_noise=0.12), True, 30.0, 0.0),
     "tracker_newkf": (dict(height=48, width=64, seed=5, fx=70.0, drop_frac=0.75), True, 30.0, 0.0),
     "tracker_lost": (dict(height=48, width=64, seed=6, fx=70.0, drop_frac=0.97), True, 30.0, 0.0),
@@ -74,6 +76,7 @@ def run_case(name, scene_kw, cov_filter, min_disp, last_dist):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     keyframe = ImageFrame(0, 0, 0.0, torch.zeros(3, H, W), pypose_stub.Sim3(t(sc["T_WCk"])))
     keyframe.update_pointmap(t(sc["Xk_canon"]), t(sc["Ck"]))
+    keyframe.N = keyframe.N_updates = sc["kf_N"]  # Xk_canon / Ck already are the fused state of kf_N predictions
     frame = ImageFrame(1, 0, 0.1, torch.zeros(3, H, W), pypose_stub.Sim3(t(sc["T_WCf0"])))
     kfs = Keyframes([keyframe])
     trk = CT.CameraTracker(args, cfg, min_disp, 0.8, None, kfs, H, W, t(sc["K"]), "cpu")

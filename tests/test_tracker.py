@@ -23,8 +23,8 @@ from oracle import tracker_oracle as TO
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-CASES = ["tracker_cov", "tracker_nocov", "tracker_moved_kf", "tracker_ragged", "tracker_rough", "tracker_far", "tracker_newkf",
-         "tracker_lost"]
+CASES = ["tracker_cov", "tracker_nocov", "tracker_moved_kf", "tracker_ragged", "tracker_rough", "tracker_kfN3", "tracker_baddepth",
+         "tracker_far", "tracker_newkf", "tracker_lost"]
 CFG = dict(TO.BASE_CFG)
 
 
@@ -113,7 +113,7 @@ def run_host(host, sc, cov, thres, cfg=CFG, max_iters=None):
                thr=np.zeros(max(mi, 1), np.float32))
     c_f = ctypes.c_float
     rc = host.th_track_frame(sc["height"], sc["width"], _ptr(arrs["K"]), _ptr(arrs["Xf"]), _ptr(arrs["Cf"]), c_f(1.0), _ptr(arrs["Qf"]),
-                             _ptr(arrs["Xk"]), _ptr(arrs["Ck"]), c_f(1.0), _ptr(arrs["Qk"]), _ptr(arrs["idx"]), _ptr(arrs["vm"]),
+                             _ptr(arrs["Xk"]), _ptr(arrs["Ck"]), c_f(1.0 / sc["kf_N"]), _ptr(arrs["Qk"]), _ptr(arrs["idx"]), _ptr(arrs["vm"]),
                              _ptr(arrs["Tf"]), _ptr(arrs["Tk"]), c_f(cfg["sigma_pixel"]), c_f(cfg["sigma_depth"]), c_f(cfg["huber"]),
                              c_f(cfg["C_conf"]), c_f(cfg["Q_conf"]), c_f(cfg["min_match_frac"]), int(cfg["pixel_border"]),
                              c_f(cfg["depth_eps"]), c_f(cfg["rel_error"]), c_f(cfg["delta_norm"]), mi, int(cov), c_f(thres), _ptr(res),
@@ -127,7 +127,7 @@ def run_hip(dev, sc, cov, thres, cfg=CFG, max_iters=None, chunk=None):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     cfg = dict(cfg, max_iters=cfg["max_iters"] if max_iters is None else max_iters)
     res, dbg = T.track_frame(sc["height"], sc["width"], t(sc["K"]), t(sc["Xff"]), t(sc["Cff"]), 1, t(sc["Qff"]), t(sc["Xk_canon"]),
-                             t(sc["Ck"]), 1, t(sc["Qkf"]), t(sc["idx_f2k"]), t(sc["valid_match"]), t(sc["T_WCf0"]), t(sc["T_WCk"]), cfg,
+                             t(sc["Ck"]), sc["kf_N"], t(sc["Qkf"]), t(sc["idx_f2k"]), t(sc["valid_match"]), t(sc["T_WCf0"]), t(sc["T_WCk"]), cfg,
                              covariance_filter=cov, thres_keyframe=thres, debug=True, chunk=chunk)
     torch.cuda.synchronize()
     return res.cpu().numpy(), {k: v.cpu().numpy() for k, v in dbg.items()}
@@ -347,6 +347,7 @@ def test_hip_camera_tracker_class_end_to_end(name, dev, lib):
     H, W = sc["height"], sc["width"]
     keyframe = _Frame(0, _Pose(t(sc["T_WCk"])), dev)
     keyframe.update_pointmap(t(sc["Xk_canon"]), t(sc["Ck"]))
+    keyframe.N = keyframe.N_updates = sc["kf_N"]
     frame = _Frame(1, _Pose(t(sc["T_WCf0"])), dev)
     kfs = _Keyframes([keyframe])
 
