@@ -6,9 +6,13 @@ Hs[4,E,7,7] / gs[2,E,7] (:713-745), the sparse assembly that drops the fixed pos
 `dx = -solve` / zero-on-failure rule, retrSim3 / expSim3 with their series branches (:302-413), and the
 |dx| < delta_thresh stop (:801-806) -- but vectorised over points and in float64 (the reference accumulates in
 float32; the comparison tolerance covers that).  The reference extension cannot be built here (CUDA-only source,
-Eigen submodule absent) and ships no test or golden vector for these entry points: parity unpinned.  What pins the
-restatement instead: tests check it against finite differences of its own residuals and against recovery of known
-ground-truth poses.
+Eigen submodule absent) and ships no test or golden vector for these entry points.  PINNED (rays, calib) on a single
+factor: tests/golden/gn_factor_{rays,calib}.npz hold every iteration's (tau, cost) and the final pose of the (i, j)
+factor of a two-keyframe graph solved by the reference's OWN Python code for the same residuals
+(CameraTracker.opt_pose_ray_dist_sim3 / opt_pose_calib_sim3, VSLAM/CameraTracker.py:242-396, run on CPU by
+tests/golden/make_golden_gn_factor.py), and tests/test_gn.py requires one Gauss-Newton step of this oracle to be that
+step.  The `points` kind and the multi-factor assembly have no Python counterpart in the reference: unpinned; they are
+checked against finite differences of their own residuals and against recovery of known ground-truth poses.
 """
 from __future__ import annotations
 

@@ -5,7 +5,7 @@ so that the REFERENCE's own tracker code can be executed on CPU to produce golde
 
 Semantics restated from pypose's published definitions:
   Sim3 data  [..., 8] = (t xyz, q xyzw, s);   Act(p) = s R(q) p + t;   matrix() = [[s R, t], [0, 1]]
-  A.mul(B) = A o B;   Inv();   quat2unit = quaternion normalised
+  A.mul(B) = A o B;   Inv();   quat2unit = quaternion normalised;   X.add(a) = Exp(a) o X
   sim3 data  [..., 7] = (tau, phi, sigma);    Exp(): q = exp(phi), s = e^sigma, t = W tau with
       W = C I + A [phi]x + B [phi]x^2   (the A, B, C of Sim(3), with their small-angle / small-sigma limits)
 """
@@ -66,6 +66,10 @@ class Sim3:
 
     __mul__ = mul
     __matmul__ = mul
+
+    def add(self, tau):
+        """pypose.add on a Lie group: y = Exp(a) * x (left-multiplicative retraction), a in the tangent space."""
+        return sim3(torch.as_tensor(tau)[..., :7]).Exp().mul(self)
 
     def matrix(self):
         t, q, s = self._parts()

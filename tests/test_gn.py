@@ -29,6 +29,47 @@ def _graph(kind, **kw):
     return S.keyframe_graph(**kw), dict(PRM)
 
 
+# ------------------------------------------------------------------------------------------ CPU: oracle vs the reference's Python
+@pytest.mark.parametrize("kind", ["rays", "calib"])
+def test_oracle_single_factor_matches_reference_tracker_code(kind):
+    """tests/golden/gn_factor_*.npz: the (i, j) factor of a two-keyframe graph solved by the REFERENCE's own
+    CameraTracker.opt_pose_ray_dist_sim3 / opt_pose_calib_sim3 (same residuals, weights, Huber kernel and retraction as
+    gn_kernels.cu; tests/golden/make_golden_gn_factor.py).  One Gauss-Newton step of the oracle on that single factor must
+    be the reference's step, iteration after iteration."""
+    import os
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, f"gn_factor_{kind}.npz"))
+    scenes = {"rays": dict(num_poses=2, n=1500, seed=21, extra_edges=0, noise=0.003),
+              "calib": dict(num_poses=2, height=40, width=56, seed=22, extra_edges=0, fx=60.0)}
+    c, prm = _graph(kind, **scenes[kind])
+    assert float(d["in_sum_Xs"]) == float(c["Xs"].astype(np.float64).sum())
+    e = int(d["edge"])
+    assert (c["ii"][e], c["jj"][e]) == (0, 1)
+    T = d["T0"].astype(np.float32).copy()
+    ie, je = np.array([0]), np.array([1])
+    for it in range(len(d["out_taus"])):
+        Hs, gs = G.factor_blocks(kind, T, c["Xs"], c["Cs"], ie, je, c["idx"][e:e + 1], c["valid"][e:e + 1], c["Q"][e:e + 1], prm)
+        dx = G.solve_step(Hs, gs, ie, je, 2)
+        assert np.abs(dx[0] - d["out_taus"][it]).max() < 2e-4 * max(1.0, np.abs(d["out_taus"][it]).max()), it
+        cost = 0.5 * sum(float((w * err * err).sum()) for _, err, w in _factor_rows(kind, T, c, e, prm))
+        assert abs(cost / d["out_costs"][it] - 1) < 2e-4, it
+        T[1] = G.retr_sim3(dx[0], T[1])
+    Tn = T[1].copy()
+    Tn[3:7] /= np.linalg.norm(Tn[3:7])
+    assert np.abs(Tn - d["out_T_j"][0]).max() < 2e-5
+
+
+def _factor_rows(kind, T, c, e, prm):
+    T = T.astype(np.float64)
+    tij, qij, sij = G.rel_sim3(T[0, 0:3], T[0, 3:7], T[0, 7], T[1, 0:3], T[1, 3:7], T[1, 7])
+    vm = c["valid"][e].reshape(-1).astype(bool)
+    ind = np.where(vm, c["idx"][e], 0)
+    P = G.act_so3(qij, c["Xs"][1].astype(np.float64)) * sij + tij
+    q = c["Q"][e].reshape(-1).astype(np.float64)
+    valid = vm & (q > prm["Q_thresh"]) & (c["Cs"][0].reshape(-1)[ind] > prm["C_thresh"]) & (c["Cs"][1].reshape(-1) > prm["C_thresh"])
+    return G._rows(kind, P, c["Xs"][0][ind].astype(np.float64), ind, valid, q, prm)
+
+
 # ------------------------------------------------------------------------------------------ CPU: the oracle itself
 @pytest.mark.parametrize("kind", KINDS)
 def test_oracle_jacobians_match_finite_differences(kind):
