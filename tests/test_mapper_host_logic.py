@@ -52,6 +52,12 @@ class _TorchNoCuda:
             k.pop("device")
         return torch.tensor(*a, **k)
 
+    @staticmethod
+    def zeros(*a, **k):
+        if k.get("device") == "cuda":
+            k.pop("device")
+        return torch.zeros(*a, **k)
+
 
 def _rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, render_mode, rasterize_mode, absgrad, packed,
                    sh_degree, eps2d):
@@ -207,3 +213,23 @@ def test_weed_out_gaussians_matches_the_reference_method(world):
             assert sa[k].shape == sb[k].shape and torch.equal(sa[k], sb[k]), k
     for k in ("cls_id", "d_max"):
         assert torch.equal(a.gaussian_params[k]["val"], b.gaussian_params[k]["val"]), k
+
+
+def test_rasteriser_oracle_uses_the_references_quaternion_and_covariance_convention():
+    """gsplat itself is not in the reference tree, but ARTDECO's own 3-D covariance helpers are (Reconstruct/utils.py:651-689:
+    build_rotation, build_scaling_rotation, build_covariance_from_scaling_rotation): quaternions are (w, x, y, z), normalised
+    inside, Sigma = R S S^T R^T.  The rasteriser oracle must build the same rotation and covariance from the same parameters."""
+    ns = {"torch": _TorchNoCuda()}
+    build_rotation, build_scaling_rotation, strip_lowerdiag, strip_symmetric, build_cov = _compile_defs(
+        os.path.join(REF, "Reconstruct", "utils.py"),
+        ["build_rotation", "build_scaling_rotation", "strip_lowerdiag", "strip_symmetric", "build_covariance_from_scaling_rotation"], ns)
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(200, 4, generator=g) * torch.rand(200, 1, generator=g) * 3   # un-normalised, like the raw parameter
+    s = torch.exp(torch.randn(200, 3, generator=g))
+    Ro = torch.stack([torch.stack(row, -1) for row in gsplat_oracle._quat_to_rotmat(q)], -2)
+    assert (Ro - build_rotation(q)).abs().max() < 2e-6
+    M = Ro * s[:, None, :]
+    cov = M @ M.transpose(1, 2)
+    ref6 = build_cov(s, 1.0, q)
+    mine6 = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], -1)
+    assert (mine6 - ref6).abs().max() <= 1e-5 * ref6.abs().max()
