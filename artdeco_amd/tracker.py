@@ -19,7 +19,7 @@ from . import _lib
 
 @dataclasses.dataclass
 class TrackOutcome:
-    """Host view of `adk_track_frame`'s 24-float result."""
+    """Host view of `adk_track_frame`'s 32-float result (layout: include/artdeco_hip.h)."""
     T_WCf: torch.Tensor      # [8] device
     T_CkCf: torch.Tensor     # [8] device
     lost: bool
