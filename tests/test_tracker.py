@@ -387,3 +387,37 @@ def test_hip_tracker_full_frame_recovers_pose(dev, lib):
     assert float(res[22]) == np.float32(o["dist_quantile"])
     q = res[3:7] * np.sign(res[6]) - sc["T_WCf_gt"][0, 3:7] * np.sign(sc["T_WCf_gt"][0, 6])
     assert np.abs(q).max() < 3e-3 and np.abs(res[0:3] - sc["T_WCf_gt"][0, 0:3]).max() < 1e-2 and abs(res[7] / sc["T_WCf_gt"][0, 7] - 1) < 3e-3
+
+
+REF_TRACKER = "/root/reference/VSLAM/CameraTracker.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TRACKER), reason="reference tree not mounted")
+def test_keyframe_decisions_follow_the_references_mixed_precision_comparisons():
+    """check_keyframe (CameraTracker.py:159-167) compares a float32 tensor ratio, a python-float ratio and a python-float
+    threshold through python's min(); keyframe_decisions must take the same branch for counts on either side of, and exactly
+    at, the threshold.  The reference method is compiled from its file and run on CPU tensors."""
+    import ast
+    from artdeco_amd.tracker import TrackOutcome, keyframe_decisions
+    tree = ast.parse(open(REF_TRACKER).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CameraTracker")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "check_keyframe")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), REF_TRACKER, "exec"), ns)
+    rng = np.random.default_rng(0)
+    for n, thr in ((3000, 0.333), (3072, 0.333), (1000, 0.25), (999, 1.0 / 3.0), (196608, 0.333)):
+        stub = types.SimpleNamespace(cfg={"match_frac_thresh": thr})
+        edge = int(round(thr * n))
+        trials = [(edge + a, edge + b) for a in (-2, -1, 0, 1, 2) for b in (-2, -1, 0, 1, 2)] + \
+                 [tuple(rng.integers(1, n, 2)) for _ in range(20)]
+        for n_kf, n_unique in trials:
+            n_kf, n_unique = int(np.clip(n_kf, 0, n)), int(np.clip(n_unique, 1, n))
+            valid_kf = torch.zeros(n, 1, dtype=torch.bool)
+            valid_kf[:n_kf] = True
+            valid_match = torch.zeros(n, 1, dtype=torch.bool)
+            valid_match[:n_unique] = True
+            idx = torch.arange(n)                        # n_unique distinct frame pixels among the valid matches
+            ref = bool(ns["check_keyframe"](stub, idx, valid_kf, valid_match))
+            oc = TrackOutcome(None, None, False, False, 3, n_kf, n_kf, n_unique, 0.0, 0.0)
+            mine, _, _ = keyframe_decisions(oc, n, thr, 1e9, 0.0)
+            assert mine == ref, (n, thr, n_kf, n_unique)
