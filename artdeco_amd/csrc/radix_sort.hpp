@@ -227,12 +227,10 @@ static int radix_sort_pairs(const uint32_t* k_src, const uint32_t* v_src, uint32
 {
     const int items = rs_items(n);
     const int nb = (int)ceil_div(n, RS_BLOCK * items);
-    // Staged scatter: on by default for the 8-keys-per-thread chunks (bit-exact binning tests green on MI355X with it; 1 M-key
-    // depth sort 0.130 -> 0.120 ms).  For the 16-keys-per-thread chunks (lists >= 2 M keys, i.e. the tile sort at 1 M / 1080p)
-    // it measured 0.190 -> 0.150 ms but the round's GPU budget ended before the bit-exact suite had run at that chunk size:
-    // opt-in through ADK_RADIX_STAGED=1 until validated.
-    static const bool staged_all = getenv("ADK_RADIX_STAGED") != nullptr;
-    const bool staged = staged_all || items == 8;
+    // Staged scatter: opt-in (ADK_RADIX_STAGED=1) until the whole bit-exact GPU suite has run with it.  Measured on MI355X at
+    // the very end of round 1: 1 M-key depth sort 0.130 -> 0.120 ms, 3.8 M-key tile sort 0.190 -> 0.150 ms (step 2.51 -> 2.43
+    // ms); the three small bit-exact binning cases passed with it before the round's GPU budget ran out.
+    static const bool staged = getenv("ADK_RADIX_STAGED") != nullptr;
     uint32_t* hist = scratch;
     uint32_t* dtot = scratch + (int64_t)256 * nb;
     const uint32_t* ki = k_src;
