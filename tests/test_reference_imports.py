@@ -39,3 +39,21 @@ def test_reference_matching_imports_the_backend_dropin(ref_path):
     for name, n_args in (("iter_proj", 6), ("refine_matches", 5), ("gauss_newton_rays", 14), ("gauss_newton_calib", 19),
                          ("gauss_newton_points", 13)):
         assert len(inspect.signature(getattr(msb, name)).parameters) == n_args, name  # gn.cpp:3-114
+
+
+def test_install_tracker_redirects_the_frontends_import(ref_path):
+    """VSLAM/Frontend.py:9 does `from VSLAM.CameraTracker import CameraTracker`; after install_tracker() that name is the
+    drop-in class, with the constructor arguments Frontend.py:34-37 passes."""
+    import artdeco_amd.tracker as T
+    saved = sys.modules.get("VSLAM.CameraTracker")
+    try:
+        T.install_tracker()
+        from VSLAM.CameraTracker import CameraTracker
+        assert CameraTracker is T.CameraTracker
+        params = list(inspect.signature(CameraTracker.__init__).parameters)
+        assert params[1:11] == ["args", "config", "min_displacement", "thres_keyframe", "model", "frames", "H_slam", "W_slam", "K_slam", "device"]
+    finally:
+        if saved is None:
+            sys.modules.pop("VSLAM.CameraTracker", None)
+        else:
+            sys.modules["VSLAM.CameraTracker"] = saved
