@@ -421,3 +421,57 @@ def test_keyframe_decisions_follow_the_references_mixed_precision_comparisons():
             oc = TrackOutcome(None, None, False, False, 3, n_kf, n_kf, n_unique, 0.0, 0.0)
             mine, _, _ = keyframe_decisions(oc, n, thr, 1e9, 0.0)
             assert mine == ref, (n, thr, n_kf, n_unique)
+
+
+# ---------------------------------------------------------------------------------- CPU: edge cases of the shared arithmetic
+def _oracle_vs_host(host, sc, cfg=None, cov=True, thres=0.8):
+    cfg = dict(CFG, **(cfg or {}))
+    res, dbg = run_host(host, sc, cov, thres, cfg=cfg)
+    tr = []
+    o = TO.track(sc, cfg, cov, thres_keyframe=thres, det_mode="analytic", trace=tr)
+    assert bool(res[16]) == o["lost"]
+    assert int(res[19]) == int(o["valid_opt"].sum()) and int(res[20]) == int(o["valid_kf"].sum())
+    assert np.array_equal(dbg["valid_opt"].astype(bool), o["valid_opt"])
+    if not o["lost"]:
+        assert int(res[18]) == o["iterations"]
+        assert np.abs(res[0:8] - o["T_WCf"]).max() < 5e-5
+    return res, o
+
+
+def test_host_confidence_threshold_uses_the_average_over_updates(host):
+    """ImageFrame.get_average_conf (ImageFrame.py:51-52): C / N, compared with C_conf (CameraTracker.py:83-84)."""
+    sc = S.tracker_scene(height=24, width=32, seed=16, kf_N=3)   # seed chosen so that no stopping test sits within 30 % of its threshold
+    for c_conf in (0.0, 1.4, 1.6, 5.0):   # the summed keyframe confidence is ~3 x (1..2): its average straddles 1.4 / 1.6
+        res, o = _oracle_vs_host(host, sc, dict(C_conf=c_conf))
+    assert o["lost"] and bool(res[16])       # C_conf = 5: nothing is confident enough -> insufficient match
+
+
+def test_host_lost_threshold_boundary(host):
+    """valid_opt.sum() / numel < min_match_frac in float32 (CameraTracker.py:90-91), on either side of the boundary."""
+    sc = S.tracker_scene(height=24, width=32, seed=14, drop_frac=0.5)
+    n = 24 * 32
+    n_opt = int(TO.track(sc, None, True, det_mode="analytic")["valid_opt"].sum())
+    for frac in (np.float32(n_opt) / np.float32(n), np.nextafter(np.float32(n_opt) / np.float32(n), np.float32(1)),
+                 np.float32(n_opt - 1) / np.float32(n)):
+        _oracle_vs_host(host, sc, dict(min_match_frac=float(frac)))
+
+
+def test_host_displacement_quantile_with_heavy_ties(host):
+    """Every match displaced by the same integer offset: all order statistics tie (torch.quantile returns that value)."""
+    sc = S.tracker_scene(height=24, width=32, seed=15, outlier_frac=0.0)
+    H, W = 24, 32
+    k = np.arange(H * W)
+    u, v = np.clip(k % W + 3, 0, W - 1), np.clip(k // W + 4, 0, H - 1)
+    sc["idx_f2k"] = (v * W + u).astype(np.int64)
+    res, o = _oracle_vs_host(host, sc)
+    assert float(res[22]) == np.float32(o["dist_quantile"])
+    inner = (k % W + 3 < W) & (k // W + 4 < H)
+    if o["valid_opt"][inner].mean() > 0.85:
+        assert float(res[22]) == 5.0
+
+
+def test_host_all_matches_invalid_is_lost_and_returns_the_input_pose(host):
+    sc = S.tracker_scene(height=24, width=32, seed=16)
+    sc["valid_match"][:] = False
+    res, o = _oracle_vs_host(host, sc)
+    assert bool(res[16]) and int(res[19]) == 0 and int(res[21]) == 0 and np.array_equal(res[0:8], sc["T_WCf0"][0])
