@@ -227,10 +227,10 @@ static int radix_sort_pairs(const uint32_t* k_src, const uint32_t* v_src, uint32
 {
     const int items = rs_items(n);
     const int nb = (int)ceil_div(n, RS_BLOCK * items);
-    // Staged scatter: opt-in (ADK_RADIX_STAGED=1) until the whole bit-exact GPU suite has run with it.  Measured on MI355X at
-    // the very end of round 1: 1 M-key depth sort 0.130 -> 0.120 ms, 3.8 M-key tile sort 0.190 -> 0.150 ms (step 2.51 -> 2.43
-    // ms); the three small bit-exact binning cases passed with it before the round's GPU budget ran out.
-    static const bool staged = getenv("ADK_RADIX_STAGED") != nullptr;
+    // Staged scatter is the default since round 2: the whole bit-exact GPU suite (binning cases, KNN Morton sort, 1 M / 1080p
+    // properties; 228 tests) passed with it on MI355X (gpurun_out/r02_staged_suite.log).  1 M-key depth sort 0.130 -> 0.120 ms,
+    // 3.8 M-key tile sort 0.190 -> 0.150 ms.  ADK_RADIX_STAGED=0 selects the direct scatter (kept for A/B measurements).
+    static const bool staged = [] { const char* e = getenv("ADK_RADIX_STAGED"); return !(e && e[0] == '0'); }();
     uint32_t* hist = scratch;
     uint32_t* dtot = scratch + (int64_t)256 * nb;
     const uint32_t* ki = k_src;
