@@ -271,11 +271,37 @@ def isect_tiles(means2d, radii, depths, width, height, tile=TILE):
 
 
 # ----------------------------------------------------------------------------- compositing
-def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isects, backgrounds=None):
+KNIFE_EPS = 5e-4
+
+
+class _one_thread:
+    """The per-tile tensors ([n,256]) are far too small for OpenMP: with 8+ threads torch spends its time in fork/join
+    (measured here: 0.8 s single-threaded vs 5-30 s with 4-8 threads for one 256x192 frame)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
+def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isects, backgrounds=None, tile_window=None,
+                        extras=None):
     """Per-tile vectorised, autograd-capable restatement of rasterize_to_pixels_fwd (App. A item 4).
 
     colors [N,CDIM].  Returns render_colors [H,W,CDIM], render_alphas [H,W,1], last_ids int32 [H,W]
     (index into the sorted intersection list of the last splat that contributed; 0 if none).
+
+    tile_window = (tx0, ty0, tx1, ty1): only tiles with tx0 <= tx < tx1, ty0 <= ty < ty1 are composited (the rest of the
+    image stays empty) -- keeps the fp64 autograd reference tractable at the BASELINE sizes.
+    extras: a dict that receives
+      "knife"   bool [H,W]: the pixel has a reached splat sitting on one of the rasteriser's DISCONTINUITIES within a
+                relative KNIFE_EPS -- alpha vs 1/255 (skip), alpha vs 0.999 (clamp: gradient switches off), sigma vs 0,
+                or T(1-alpha) vs 1e-4 (terminate).  fp32 and fp64 evaluations may legitimately decide such a pixel
+                differently, so tolerance tests exclude exactly these pixels instead of allowing a blanket outlier fraction.
+      "main_ids" int32 [H,W]: Gaussian with the largest alpha*T (first in list order on exact ties), -1 if none;
+      "main_w", "second_w" [H,W]: the two largest alpha*T values of the pixel.
     """
     dt = means2d.dtype
     cdim = colors.shape[1]
@@ -289,12 +315,21 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isect
     last = torch.zeros(Hp, Wp, dtype=torch.int32)
     ys, xs = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
     thr_alpha = torch.tensor(ALPHA_THRESHOLD, dtype=torch.float32).to(dt)
+    if extras is not None:
+        ex_knife = torch.zeros(Hp, Wp, dtype=torch.bool)
+        ex_main = torch.full((Hp, Wp), -1, dtype=torch.int32)
+        ex_w1 = torch.zeros(Hp, Wp, dtype=dt)
+        ex_w2 = torch.zeros(Hp, Wp, dtype=dt)
+    threads = _one_thread()
+    threads.__enter__()
     for tid in range(tile_w * tile_h):
         s = int(offsets[tid])
         e = int(offsets[tid + 1]) if tid + 1 < tile_w * tile_h else I
         if e <= s:
             continue
         ty, tx = divmod(tid, tile_w)
+        if tile_window is not None and not (tile_window[0] <= tx < tile_window[2] and tile_window[1] <= ty < tile_window[3]):
+            continue
         g = flat[s:e]
         px = (tx * TILE + xs).reshape(-1).to(dt) + 0.5  # [256]
         py = (ty * TILE + ys).reshape(-1).to(dt) + 0.5
@@ -320,7 +355,29 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isect
         out_c[sl] = col.reshape(TILE, TILE, cdim)
         out_T[sl] = T_final.reshape(TILE, TILE)
         last[sl] = lastk.reshape(TILE, TILE)
+        if extras is not None:
+            with torch.no_grad():
+                ov = (opacities[g][:, None] * torch.exp(-sigma)).detach()
+                Ti, Te = T_incl.detach(), T_excl.detach()
+                reached = Te > TRANSMITTANCE_EPS * (1.0 - KNIFE_EPS)
+                near = ((ov * 255.0 - 1.0).abs() <= KNIFE_EPS) | ((ov - MAX_ALPHA).abs() <= KNIFE_EPS * MAX_ALPHA) \
+                    | (sigma.detach().abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= KNIFE_EPS * TRANSMITTANCE_EPS))
+                ex_knife[sl] = (near & reached).any(0).reshape(TILE, TILE)
+                wd = w.detach()
+                k = min(2, wd.shape[0])
+                top = torch.topk(wd, k, dim=0)
+                w1 = top.values[0]
+                w2 = top.values[1] if k > 1 else torch.zeros_like(w1)
+                first = (wd == w1[None, :]).to(torch.int8).argmax(0)  # first list position holding the maximum
+                mid = torch.where(w1 > 0, g[first].to(torch.int32), torch.full_like(first, -1, dtype=torch.int32))
+                ex_main[sl] = mid.reshape(TILE, TILE)
+                ex_w1[sl] = w1.reshape(TILE, TILE)
+                ex_w2[sl] = w2.reshape(TILE, TILE)
+    threads.__exit__()
     out_c, out_T, last = out_c[:height, :width], out_T[:height, :width], last[:height, :width]
+    if extras is not None:
+        extras.update(knife=ex_knife[:height, :width], main_ids=ex_main[:height, :width], main_w=ex_w1[:height, :width],
+                      second_w=ex_w2[:height, :width])
     if backgrounds is not None:
         out_c = out_c + out_T[..., None] * backgrounds.to(dt)[None, None, :]
     return out_c, (1.0 - out_T)[..., None], last
@@ -367,7 +424,7 @@ def rasterize_to_pixels_loop(means2d, conics, colors, opacities, width, height, 
 # ----------------------------------------------------------------------------- full pipeline
 def rasterization(means, quats, scales, opacities, colors, viewmat, K, width, height,
                   sh_degree=3, eps2d=0.3, render_mode="RGB+D", near_plane=0.01, far_plane=1e10,
-                  radius_clip=0.0, backgrounds=None, grad_dtype=None):
+                  radius_clip=0.0, backgrounds=None, grad_dtype=None, tile_window=None, extras=None):
     """One-camera restatement of gsplat.rendering.rasterization as ARTDECO calls it.
 
     Integer decisions always come from an fp32 pass.  With grad_dtype=torch.float64 the
@@ -406,10 +463,52 @@ def rasterization(means, quats, scales, opacities, colors, viewmat, K, width, he
         feat = rgb
     else:
         raise ValueError(render_mode)
-    render, alphas, last = rasterize_to_pixels(p["means2d"], p["conics"], feat, op, width, height, isects, backgrounds)
+    render, alphas, last = rasterize_to_pixels(p["means2d"], p["conics"], feat, op, width, height, isects, backgrounds,
+                                               tile_window=tile_window, extras=extras)
     meta = {"radii": p32["radii"], "means2d": p["means2d"], "depths": p["depths"], "conics": p["conics"],
             "colors": feat, "isects": isects, "last_ids": last, "p32": p32}
     return render, alphas, meta
+
+
+def rasterization_window(sc, tile_window, eps2d=0.01, sh_degree=3, dtype=torch.float64):
+    """The gradient reference at the BASELINE sizes (1 M / 1080p, 4 M / 2592x1944): fp32 projection and binning of
+    the WHOLE scene (vectorised, seconds), then high-precision autograd restricted to the tiles of `tile_window`
+    and to the Gaussians on those tiles' lists (every other Gaussian has an exactly zero gradient for a loss supported
+    on the window).  sc: dict from synthetic_scene() (fp32; "viewmat" may be replaced).
+
+    Returns dict: ids (int64 [M], Gaussians in the window, ascending), leaves (means/quats/scales/opacities/colors of those
+    + the full viewmat, `dtype`, requires_grad), render [H,W,4], alphas [H,W,1], extras (see rasterize_to_pixels), p32,
+    isects (of the whole scene, fp32 integer pass).
+    """
+    W, H = sc["width"], sc["height"]
+    p32 = project(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["viewmat"], sc["K"], W, H, eps2d)
+    isects = isect_tiles(p32["means2d"], p32["radii"], p32["depths"], W, H)
+    tile_w, tile_h, I = isects["tile_w"], isects["tile_h"], isects["n_isects"]
+    off = isects["offsets"].reshape(-1)
+    tx0, ty0, tx1, ty1 = tile_window
+    spans = []
+    for ty in range(ty0, ty1):
+        for tx in range(tx0, tx1):
+            tid = ty * tile_w + tx
+            spans.append((int(off[tid]), int(off[tid + 1]) if tid + 1 < tile_w * tile_h else I))
+    ids = np.unique(np.concatenate([isects["flatten_ids"][s:e] for s, e in spans] or [np.zeros(0, np.int32)])).astype(np.int64)
+    sub = dict(isects)
+    sub["flatten_ids"] = np.searchsorted(ids, isects["flatten_ids"]).astype(np.int32)  # only window entries are ever read
+    tid_ = torch.from_numpy(ids)
+    leaves = {k: sc[k][tid_].to(dtype).clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    leaves["viewmat"] = sc["viewmat"].to(dtype).clone().requires_grad_(True)
+    p = project(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["viewmat"], sc["K"].to(dtype),
+                W, H, eps2d)
+    vis = p32["valid"][tid_]
+    dirs = leaves["means"] - camera_position(leaves["viewmat"])[None, :]
+    dirs = torch.where(vis[:, None], dirs, torch.ones_like(dirs))
+    rgb = sh_to_rgb(sh_degree, dirs, leaves["colors"])
+    feat = torch.cat([rgb, p["depths"][:, None]], -1)
+    extras = {}
+    render, alphas, last = rasterize_to_pixels(p["means2d"], p["conics"], feat, leaves["opacities"], W, H, sub,
+                                               tile_window=tile_window, extras=extras)
+    return {"ids": tid_, "leaves": leaves, "render": render, "alphas": alphas, "extras": extras, "p32": p32, "isects": isects,
+            "last_ids": last}
 
 
 # ----------------------------------------------------------------------------- synthetic scenes (SURVEY.md 8d)

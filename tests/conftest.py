@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import torch  # noqa: E402
+
+# The oracles work on many small tensors; OpenMP fork/join dominates them with the default thread count (measured in the
+# build container: one 256x192 oracle frame 0.8 s single-threaded, 5-30 s with 4-8 threads).
+torch.set_num_threads(int(os.environ.get("ADK_TEST_THREADS", "1")))
+
 import artdeco_amd  # noqa: E402
 
 artdeco_amd.install_dropins()

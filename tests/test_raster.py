@@ -3,8 +3,11 @@
 Bit-exact: radii, tiles-per-Gaussian, sorted intersection keys (tile | depth bits), flatten ids,
 tile offsets.  fp32 tolerance (north star: 1e-4 relative): rendered RGB+D / alpha and every
 per-attribute gradient, with the gradient reference obtained by fp64 autograd over the oracle.
-Splat-skip decisions (alpha < 1/255) can flip on an ulp of exp(); such flips are bounded by
-1/255 of one splat's colour, so pixel/gradient comparisons allow a tiny outlier fraction.
+The rasteriser has four discontinuities per (splat, pixel): alpha vs 1/255 (skip), alpha vs 0.999 (clamp),
+sigma vs 0, T(1-alpha) vs 1e-4 (terminate).  An fp32 and an fp64 evaluation may decide a pixel sitting on one of them
+differently, so the gradient tests IDENTIFY those pixels (oracle `extras["knife"]`, relative margin 5e-4, a few percent of the
+pixels) and take them out of the loss on both sides; on everything else the north-star criterion is asserted as is:
+rel_l2 <= 1e-4 per attribute and max |error| <= 1e-4 max |gradient|, no outlier allowance.
 """
 import numpy as np
 import pytest
@@ -121,14 +124,17 @@ def test_binning_is_bit_exact(N, W, H, seed, tilt, dev):
                                                        (200000, 512, 384, 0, 3, "RGB+D")])
 def test_forward_render_matches_oracle(N, W, H, seed, sh_degree, mode, dev):
     sc = dict(_scene(N, W, H, seed), viewmat=_tilted_viewmat(seed))
-    ro, ao, ometa = go.rasterization(**sc, eps2d=0.01, sh_degree=sh_degree, render_mode=mode)
+    ex = {}
+    ro, ao, ometa = go.rasterization(**sc, eps2d=0.01, sh_degree=sh_degree, render_mode=mode, extras=ex)
     r, a, meta, _ = _run_hip(sc, dev, sh_degree=sh_degree, render_mode=mode)
     r, a = r[0].cpu(), a[0].cpu()
     assert r.shape == ro.shape and a.shape == ao.shape
-    assert _close_frac(r, ro, 1e-4) >= 0.9995 and float((r - ro).abs().max()) <= 2e-2 * float(ro.abs().max())
-    assert _close_frac(a, ao, 1e-4) >= 0.9995
-    # last contributing index agrees wherever the pixel is not on a skip/terminate knife edge
-    # (exposed through the C ABI only; checked via the ED normalisation path instead)
+    keep = (~ex["knife"])[..., None]   # every pixel that is not ON a skip / clamp / terminate threshold: 1e-4, no allowance
+    assert float(keep.float().mean()) > 0.9
+    assert float(((r - ro).abs() * keep).max()) <= 1e-4 * float(ro.abs().max())
+    assert float(((a - ao).abs() * keep).max()) <= 1e-4
+    # knife-edge pixels: a flipped decision moves the pixel by at most one splat's contribution
+    assert float((r - ro).abs().max()) <= 2e-2 * float(ro.abs().max())
 
 
 @pytest.mark.gpu
@@ -144,6 +150,16 @@ def test_forward_backgrounds_and_expected_depth(dev):
     assert _close_frac(re[0, ..., 3:4].cpu(), exp_depth, 1e-4) >= 0.999
 
 
+def _assert_grad(name, gh, gref, rel=1e-4):
+    """north-star criterion, no outlier allowance: rel_l2 and max error relative to the largest entry."""
+    gh, gref = gh.double(), gref.double()
+    nrm = float(gref.norm())
+    rel_l2 = float((gh - gref).norm()) / max(nrm, 1e-300)
+    rel_max = float((gh - gref).abs().max()) / max(float(gref.abs().max()), 1e-300)
+    assert rel_l2 <= rel and rel_max <= rel, (name, "rel_l2", rel_l2, "rel_max", rel_max)
+    return rel_l2, rel_max
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,W,H,seed", [(1500, 96, 80, 0), (6000, 160, 128, 1), (40000, 256, 192, 2)])
 def test_backward_matches_fp64_autograd_oracle(N, W, H, seed, dev):
@@ -153,19 +169,79 @@ def test_backward_matches_fp64_autograd_oracle(N, W, H, seed, dev):
     v_a = torch.randn(H, W, 1, generator=g)
     # fp64 autograd over the oracle, on the fp32 tile lists
     leaves = {k: sc[k].double().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors", "viewmat")}
+    ex = {}
     ro, ao, _ = go.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
-                                 leaves["viewmat"], sc["K"], W, H, eps2d=0.01, grad_dtype=torch.float64)
+                                 leaves["viewmat"], sc["K"], W, H, eps2d=0.01, grad_dtype=torch.float64, extras=ex)
+    keep = (~ex["knife"])[..., None]
+    assert float(keep.double().mean()) > 0.8
+    v_r, v_a = v_r * keep, v_a * keep          # knife-edge pixels leave the loss on both sides
     ((ro * v_r.double()).sum() + (ao * v_a.double()).sum()).backward()
     # HIP
     r, a, meta, hl = _run_hip(sc, dev, requires_grad=True)
     ((r[0] * v_r.to(dev)).sum() + (a[0] * v_a.to(dev)).sum()).backward()
+    scale = float(ro.detach().abs().max())
+    assert float(((r[0].cpu().double() - ro.detach()).abs() * keep).max()) <= 1e-4 * scale
+    assert float(((a[0].cpu().double() - ao.detach()).abs() * keep).max()) <= 1e-4
     for k in ("means", "quats", "scales", "opacities", "colors"):
-        gh, go_ = hl[k].grad.cpu().double(), leaves[k].grad
-        frac = _close_frac(gh, go_, 1e-4)
-        rel_l2 = float((gh - go_).norm() / go_.norm())
-        assert frac >= 0.999 and rel_l2 <= 2e-3, (k, frac, rel_l2)
-    gv, gvo = hl["viewmat"].grad.cpu().double()[:3], leaves["viewmat"].grad[:3]
-    assert float((gv - gvo).abs().max()) <= 2e-3 * float(gvo.abs().max()), (gv, gvo)
+        _assert_grad(k, hl[k].grad.cpu(), leaves[k].grad)
+    _assert_grad("viewmat", hl["viewmat"].grad.cpu()[:3], leaves["viewmat"].grad[:3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,W,H", [(1_000_000, 1920, 1080), (4_000_000, 2592, 1944)])
+def test_binning_is_bit_exact_at_baseline_sizes(N, W, H, dev):
+    """BASELINE configs[2] and configs[3] at FULL size: radii, tiles per Gaussian, the sorted 64-bit (tile | depth-bits)
+    keys, the sorted Gaussian ids and the tile offsets, bit for bit against the vectorised oracle (projection + isect only;
+    the oracle's compositing is not needed for the integer outputs)."""
+    sc = dict(_scene(N, W, H, 0), viewmat=_tilted_viewmat(1))
+    p = go.project(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["viewmat"], sc["K"], W, H, 0.01)
+    oi = go.isect_tiles(p["means2d"], p["radii"], p["depths"], W, H)
+    r, a, meta, _ = _run_hip(sc, dev)
+    assert torch.equal(meta["radii"][0].cpu(), p["radii"])
+    assert np.array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), oi["tiles_per_gauss"])
+    assert meta["isect_ids"].numel() == oi["n_isects"] and oi["n_isects"] > 3 * N
+    assert np.array_equal(meta["isect_ids"].cpu().numpy(), oi["isect_ids"])
+    assert np.array_equal(meta["flatten_ids"].cpu().numpy(), oi["flatten_ids"])
+    assert np.array_equal(meta["isect_offsets"][0].cpu().numpy(), oi["offsets"])
+    vis = p["valid"]
+    assert torch.equal(meta["means2d"][0].cpu()[vis], p["means2d"][vis])
+    assert torch.equal(meta["depths"][0].cpu()[vis], p["depths"][vis])
+    assert torch.equal(meta["conics"][0].cpu()[vis], p["conics"][vis])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,W,H,window", [(200_000, 512, 384, (10, 8, 18, 14)), (1_000_000, 1920, 1080, (50, 30, 56, 34)),
+                                          (1_000_000, 1920, 1080, (0, 0, 4, 3)), (4_000_000, 2592, 1944, (158, 118, 162, 122))])
+def test_render_and_backward_at_baseline_sizes(N, W, H, window, dev):
+    """Forward render and every per-attribute gradient at the BASELINE sizes (configs[1] 200 k / 512x384, configs[2]
+    1 M / 1080p, configs[3] 4 M / 2592x1944; interior, corner and ragged-edge windows) against fp64 autograd over the oracle.
+    The HIP path renders and back-propagates the WHOLE frame; the loss is supported on a window of tiles so that the fp64
+    reference (restricted to the Gaussians on those tiles' lists; everything else has an exactly zero gradient) stays
+    tractable."""
+    sc = dict(_scene(N, W, H, 0), viewmat=_tilted_viewmat(2))
+    o = go.rasterization_window(sc, window)
+    tx0, ty0, tx1, ty1 = window
+    ys, xs = slice(ty0 * 16, min(ty1 * 16, H)), slice(tx0 * 16, min(tx1 * 16, W))
+    g = torch.Generator().manual_seed(5)
+    keep = torch.zeros(H, W, 1, dtype=torch.bool)
+    keep[ys, xs] = ~o["extras"]["knife"][ys, xs, None]
+    assert float(keep[ys, xs].double().mean()) > 0.7
+    v_r = torch.randn(H, W, 4, generator=g) * keep
+    v_a = torch.randn(H, W, 1, generator=g) * keep
+    ((o["render"] * v_r.double()).sum() + (o["alphas"] * v_a.double()).sum()).backward()
+    r, a, meta, hl = _run_hip(sc, dev, requires_grad=True)
+    ((r[0] * v_r.to(dev)).sum() + (a[0] * v_a.to(dev)).sum()).backward()
+    # forward: every pixel of the window that is not on a knife edge
+    ro = o["render"].detach()
+    assert float(((r[0].cpu().double() - ro).abs() * keep).max()) <= 1e-4 * float(ro.abs().max())
+    assert float(((a[0].cpu().double() - o["alphas"].detach()).abs() * keep).max()) <= 1e-4
+    ids = o["ids"]
+    rest = torch.ones(N, dtype=torch.bool); rest[ids] = False
+    for k in ("means", "quats", "scales", "opacities", "colors"):
+        gh = hl[k].grad.cpu()
+        _assert_grad(k, gh[ids], o["leaves"][k].grad)
+        assert float(gh[rest].abs().max()) == 0.0, k   # Gaussians off the window's lists: exactly zero
+    _assert_grad("viewmat", hl["viewmat"].grad.cpu()[:3], o["leaves"]["viewmat"].grad[:3])
 
 
 @pytest.mark.gpu
@@ -238,9 +314,15 @@ def test_gaussian_rasterizer_adapter(dev):
     inv = torch.where(p["valid"], 1.0 / p["depths"].clamp(min=1e-9), torch.zeros_like(p["depths"]))
     rid, _, _ = go.rasterize_to_pixels(p["means2d"], p["conics"], inv[:, None], sc["opacities"], W, H, ometa["isects"])
     assert _close_frac(invdepth.detach().cpu()[0], rid[..., 0], 1e-4) >= 0.999
-    # mainGaussID: -1 exactly where nothing was composited; otherwise a Gaussian covering that pixel's tile
+    # mainGaussID == argmax over the pixel's list of alpha*T (the oracle's compositing weights), -1 where nothing was
+    # composited; pixels whose two largest weights agree to 1e-5 relative (an fp32 tie) are the only ones left out
+    ex = {}
+    go.rasterize_to_pixels(p["means2d"], p["conics"], inv[:, None], sc["opacities"], W, H, ometa["isects"], extras=ex)
     mid = main_id[0].cpu()
     assert bool(((mid == -1) == (ao[..., 0] == 0)).all())
-    assert int(mid.max()) < N
+    clear = (ex["main_w"] - ex["second_w"]) > 1e-5 * ex["main_w"]
+    assert float(clear.float().mean()) > 0.99
+    assert bool((mid[clear] == ex["main_ids"][clear]).all())
+    assert bool((mid[ao[..., 0] == 0] == -1).all()) and int(mid.max()) < N
     (color.sum() + invdepth.sum()).backward()
     assert bool(torch.isfinite(means.grad).all()) and float(means.grad.abs().max()) > 0
