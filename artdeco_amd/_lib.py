@@ -14,7 +14,9 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "artdeco_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libartdeco_hip.so")
+# ARTDECO_HIP_LIB: developer override used for A/B measurements of differently-compiled builds of the SAME sources
+# (python -m artdeco_amd.build --variant NAME --extra-flags ...); the default is the in-tree library.
+LIB_PATH = os.environ.get("ARTDECO_HIP_LIB") or os.path.join(_HERE, "lib", "libartdeco_hip.so")
 
 _CTYPE = {
     "int": ctypes.c_int,

@@ -19,8 +19,13 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIBNAME = "libartdeco_hip.so"
 
 ARCH = "gfx950"
+# -fno-slp-vectorize: measured on MI355X (round 2, gpurun_out/r02_ab_*.json): hipcc's SLP vectoriser turns adjacent scalar
+# fp32 adds/muls/fmas into v_pk_add/mul/fma_f32, and on gfx950 a packed-fp32 VALU op costs MORE than the two scalar ops
+# it replaces.  Whole step 2.44 -> 2.21 ms with it off: raster bwd 0.73 -> 0.62, raster fwd 0.35 -> 0.29, projection
+# bwd 0.345 -> 0.29, SSIM fwd 0.060 -> 0.052, LoD fwd 0.070 -> 0.060 ms; nothing got slower.  Results are unchanged
+# where they are compared bit-exactly (packed ops are the same IEEE operations per element).
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-                "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
+                "-fno-slp-vectorize", "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
 # Per-file extra flags.  IEEE-unfused arithmetic wherever the result feeds an
 # integer decision (radii, tile ids, sort keys) or is compared bit-exactly
@@ -54,12 +59,13 @@ def _headers_mtime() -> float:
     return m
 
 
-def _compile_one(hipcc: str, src: str, hdr_m: float, force: bool, verbose: bool) -> str:
-    obj = os.path.join(OBJDIR, src[:-4] + ".o")
+def _compile_one(hipcc: str, src: str, hdr_m: float, force: bool, verbose: bool, objdir: str = OBJDIR,
+                 extra: tuple = ()) -> str:
+    obj = os.path.join(objdir, src[:-4] + ".o")
     sp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_m):
         return obj
-    cmd = [hipcc, *COMMON_FLAGS, *EXTRA_FLAGS.get(src, []), "-c", sp, "-o", obj]
+    cmd = [hipcc, *COMMON_FLAGS, *EXTRA_FLAGS.get(src, []), *extra, "-c", sp, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,14 +80,16 @@ def lib_path() -> str:
     return os.path.join(LIBDIR, LIBNAME)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, variant: str | None = None, extra_flags: tuple = ()) -> str:
+    """variant/extra_flags: developer A/B builds (lib/libartdeco_hip.<variant>.so, selected with ARTDECO_HIP_LIB)."""
+    objdir = OBJDIR if variant is None else OBJDIR + "_" + variant
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdr_m = _headers_mtime()
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs) or 1)) as ex:
-        objs = list(ex.map(lambda s: _compile_one(hipcc, s, hdr_m, force, verbose), srcs))
-    out = lib_path()
+        objs = list(ex.map(lambda s: _compile_one(hipcc, s, hdr_m, force, verbose, objdir, tuple(extra_flags)), srcs))
+    out = lib_path() if variant is None else os.path.join(LIBDIR, f"libartdeco_hip.{variant}.so")
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out, *objs]
@@ -94,4 +102,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    _extra = tuple(a.split("=", 1)[1] for a in sys.argv if a.startswith("--extra-flags="))
+    print(build(force="--force" in sys.argv, verbose=True, variant=_variant, extra_flags=_extra))

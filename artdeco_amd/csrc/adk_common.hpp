@@ -45,6 +45,28 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return base + k;
 }
 
+// Zero-fill as a KERNEL.  A hipMemsetAsync node captured into a hipGraph is not ordered before the kernel nodes that
+// follow it on this stack (measured while building the tracker: replay 0 correct, later replays read half-cleared state),
+// so nothing that may end up inside a captured step uses hipMemsetAsync.  Any size / alignment (tail bytes one by one).
+static __global__ __launch_bounds__(256) void clear_bytes_kernel(unsigned char* __restrict__ p, int64_t nbytes) {
+    const int64_t n4 = nbytes >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool aligned = (((uintptr_t)p) & 3) == 0;
+    if (aligned) {
+        uint32_t* q = reinterpret_cast<uint32_t*>(p);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) q[i] = 0u;
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) p[i] = 0;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) p[i] = 0;
+    }
+}
+static inline int clear_bytes(void* p, int64_t nbytes, hipStream_t stream) {
+    if (nbytes <= 0) return 0;
+    hipLaunchKernelGGL(clear_bytes_kernel, dim3(stream_grid(ceil_div(nbytes, 4), 256)), dim3(256), 0, stream,
+                       static_cast<unsigned char*>(p), nbytes);
+    return (int)hipGetLastError();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

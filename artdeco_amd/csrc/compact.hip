@@ -119,7 +119,7 @@ extern "C" int adk_compact_plan(int64_t N, const uint8_t* keep, int64_t* n_keep,
 {
     if (N < 0 || !n_keep) return ADK_EINVAL;
     if (N >= ((int64_t)1 << 31)) return ADK_EUNSUPPORTED;
-    if (N == 0) return (int)hipMemsetAsync(n_keep, 0, sizeof(int64_t), stream);
+    if (N == 0) return adk::clear_bytes(n_keep, sizeof(int64_t), stream);
     if (!keep || !workspace) return ADK_EINVAL;
     if (workspace_bytes < adk_compact_workspace_bytes(N)) return ADK_EWORKSPACE;
     const int nb = (int)cmp_blocks(N);

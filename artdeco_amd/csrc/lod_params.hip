@@ -509,7 +509,7 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     if (N < 0) return ADK_EINVAL;
     if (local_dim != LOD_L || global_dim != LOD_G || hidden_dim != LOD_HID) return ADK_EUNSUPPORTED;
     if (!v_mlp) return ADK_EINVAL;
-    if (N == 0) return (int)hipMemsetAsync(v_mlp, 0, LOD_NW * sizeof(float), stream);
+    if (N == 0) return adk::clear_bytes(v_mlp, LOD_NW * sizeof(float), stream);
     if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 || !viewmat) return ADK_EINVAL;
     if (!v_opac_eff || !v_scale_eff || !v_quat_eff || !v_xyz_add || !v_opacity_raw || !v_scaling_raw || !v_rotation || !v_local_feat || !v_global_feat || !workspace) return ADK_EINVAL;
     if (workspace_bytes < adk_lod_params_bwd_workspace_bytes(N)) return ADK_EWORKSPACE;

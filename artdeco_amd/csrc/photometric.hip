@@ -320,8 +320,8 @@ extern "C" int adk_photometric_bwd(int W, int H, const float* colors4, const flo
     if (W < 0 || H < 0) return ADK_EINVAL;
     const int64_t P = (int64_t)W * H;
     if (!v_exposure) return ADK_EINVAL;
-    hipError_t e = hipMemsetAsync(v_exposure, 0, 12 * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
+    int e = adk::clear_bytes(v_exposure, 12 * sizeof(float), stream); // a kernel, not hipMemsetAsync: hipGraph-safe
+    if (e != 0) return e;
     if (P == 0) return 0;
     if (!colors4 || !alphas || !bg || !exposure || !gt_image || !mono_idepth || !rdk || !v_image_ssim || !v_loss || !v_colors4 || !v_alphas) return ADK_EINVAL;
     if (((uintptr_t)colors4 | (uintptr_t)v_colors4) & 15) return ADK_EINVAL;
@@ -351,8 +351,8 @@ extern "C" int adk_visibility_masks(int N, const int* radii, const int64_t* cls_
 {
     if (N < 0 || V < 0) return ADK_EINVAL;
     if (gvis && V > 0) {
-        hipError_t e = hipMemsetAsync(gvis, 0, (size_t)V, stream);
-        if (e != hipSuccess) return (int)e;
+        int e = adk::clear_bytes(gvis, V, stream);
+        if (e != 0) return e;
     }
     if (N == 0) return 0;
     if (!radii || !vis || (gvis && !cls_id)) return ADK_EINVAL;

@@ -172,7 +172,7 @@ extern "C" int adk_bin_depth_order(int N, const uint32_t* depth_keys, const uint
 {
     if (N < 0) return ADK_EINVAL;
     if (!n_isects) return ADK_EINVAL;
-    if (N == 0) { return (int)hipMemsetAsync(n_isects, 0, sizeof(int64_t), stream); }
+    if (N == 0) { return adk::clear_bytes(n_isects, sizeof(int64_t), stream); }
     if (!depth_keys || !gauss_ids || !tiles_per_gauss || !sorted_ids || !block_offs || !workspace) return ADK_EINVAL;
     if (workspace_bytes < adk_bin_depth_workspace_bytes(N) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
     char* w = (char*)workspace;
@@ -198,8 +198,8 @@ extern "C" int adk_bin_depth_order(int N, const uint32_t* depth_keys, const uint
 extern "C" int adk_bin_count_isects(int N, const int32_t* tiles_per_gauss, int64_t* n_isects, hipStream_t stream)
 {
     if (N < 0 || !n_isects) return ADK_EINVAL;
-    hipError_t e = hipMemsetAsync(n_isects, 0, sizeof(int64_t), stream);
-    if (e != hipSuccess) return (int)e;
+    int e = adk::clear_bytes(n_isects, sizeof(int64_t), stream); // a kernel, not hipMemsetAsync: hipGraph-safe
+    if (e != 0) return e;
     if (N == 0) return 0;
     if (!tiles_per_gauss) return ADK_EINVAL;
     int nb = (int)adk::ceil_div(N, 2048);

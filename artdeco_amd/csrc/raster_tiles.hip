@@ -17,9 +17,10 @@
 //     SGPRs and the wave then walks only the set bits (s_ff1 / s_flbit), in order.  64 cull
 //     tests cost what one used to, and culled splats cost nothing in the compositing loop.
 //     The test is conservative w.r.t. the alpha>=1/255 rule (the radii bound exactly that).
-//   * backward: per-splat gradients are reduced across the 64 lanes, accumulated per staged
-//     splat in LDS across the 4 quadrant waves, and flushed once per (splat, tile) with
-//     hardware fp32 atomics into the packed 48 B gradient record.
+//   * backward: the same one-wave-per-tile layout; per splat only the quadrants whose cull bit is set are
+//     evaluated, their contributions summed in 10 registers, reduced ONCE per (splat, tile) across the 64 lanes
+//     (transposing DPP butterfly) and published by 10 lanes with one hardware fp32 atomic instruction into the
+//     packed 48 B gradient record (no LDS accumulators, no flush phase).
 //   * tiles are mapped to workgroups through an XCD-aware bijection so that neighbouring tiles
 //     (which share Gaussians) run on the same XCD and hit the same 4 MiB L2.
 #include "adk_common.hpp"
@@ -82,8 +83,8 @@ template <bool MAIN_ID>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void raster_fwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids,
-    int32_t* __restrict__ main_ids)
+    float* __restrict__ render_colors, float* __restrict__ render_alphas, float* __restrict__ final_T,
+    int32_t* __restrict__ last_ids, int32_t* __restrict__ main_ids)
 {
     __shared__ float4 srec[64][3];
     const int n_tiles = tile_w * tile_h;
@@ -181,6 +182,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int pxi = tx * TILE + (q & 1) * 8 + (lane & 7), pyi = ty * TILE + (q >> 1) * 8 + (lane >> 3);
             const int64_t pix = (int64_t)pyi * W + pxi;
             render_alphas[pix] = 1.0f - P.T;
+            // The backward restarts its transmittance recurrence from T_final.  Recovering it as 1 - alpha (what upstream
+            // does) loses up to 1e-4 RELATIVE when alpha is close to 1 (dense scenes: T_final ~ 1e-3, ulp(alpha) = 6e-8);
+            // measured: every raster gradient was off by 1.3-1.5e-4 rel_l2 against the fp64 oracle because of it.
+            final_T[pix] = P.T;
             float o0 = P.o0, o1 = P.o1, o2 = P.o2, o3 = P.o3;
             if (backgrounds) {
                 o0 += P.T * backgrounds[0]; o1 += P.T * backgrounds[1]; o2 += P.T * backgrounds[2]; o3 += P.T * backgrounds[3];
@@ -219,7 +224,7 @@ struct PixBwd {
 __global__ __launch_bounds__(64) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
-    const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ final_T, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_rec)
 {
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         P.vr0 = P.vr1 = P.vr2 = P.vr3 = 0.f; P.T = 1.f; P.bdot = 0.f; P.C0 = 0.f; P.bin_final = -1;
         if (pxi < W && pyi < H) {
             const int64_t pix = (int64_t)pyi * W + pxi;
-            const float T_final = 1.0f - render_alphas[pix];
+            const float T_final = final_T[pix];
             const float4 v = reinterpret_cast<const float4*>(v_render_colors)[pix];
             P.vr0 = v.x; P.vr1 = v.y; P.vr2 = v.z; P.vr3 = v.w;
             const float bg_dot = bgc[0] * v.x + bgc[1] * v.y + bgc[2] * v.z + bgc[3] * v.w;
@@ -348,40 +353,40 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 
 } // namespace adk
 
-// render_colors [H,W,4], render_alphas [H,W], last_ids [H,W]; backgrounds [4] or NULL; main_ids [H,W]
-// (Gaussian id with the largest alpha*T per pixel, -1 if none) or NULL.
+// render_colors [H,W,4], render_alphas [H,W], final_T [H,W] (exact final transmittance, consumed by adk_raster_bwd),
+// last_ids [H,W]; backgrounds [4] or NULL; main_ids [H,W] (Gaussian id with the largest alpha*T per pixel, -1 if none) or NULL.
 extern "C" int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
                               const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                              float* render_colors, float* render_alphas, int32_t* last_ids, int32_t* main_ids,
-                              hipStream_t stream)
+                              float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
+                              int32_t* main_ids, hipStream_t stream)
 {
     if (width <= 0 || height <= 0 || n_isects < 0 || n_isects >= ((int64_t)1 << 31)) return ADK_EINVAL;
-    if (!offsets || !render_colors || !render_alphas || !last_ids) return ADK_EINVAL;
+    if (!offsets || !render_colors || !render_alphas || !final_T || !last_ids) return ADK_EINVAL;
     if (n_isects > 0 && (!rec || !flatten_ids)) return ADK_EINVAL;
     if (((uintptr_t)rec & 15) || ((uintptr_t)render_colors & 15)) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
     if (main_ids)
         hipLaunchKernelGGL(adk::raster_fwd_kernel<true>, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
-                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids, main_ids);
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, main_ids);
     else
         hipLaunchKernelGGL(adk::raster_fwd_kernel<false>, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
-                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, last_ids, nullptr);
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, nullptr);
     ADK_RETURN_LAST_ERROR();
 }
 
 // v_rec [N,12] must be zero-initialised by the caller; gradients are accumulated into it.
 extern "C" int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,
                               const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                              const float* render_alphas, const int32_t* last_ids, const float* v_render_colors,
+                              const float* final_T, const int32_t* last_ids, const float* v_render_colors,
                               const float* v_render_alphas, float* v_rec, hipStream_t stream)
 {
     if (width <= 0 || height <= 0 || n_isects < 0 || n_isects >= ((int64_t)1 << 31)) return ADK_EINVAL;
     if (n_isects == 0) return 0;
-    if (!rec || !flatten_ids || !offsets || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas || !v_rec) return ADK_EINVAL;
+    if (!rec || !flatten_ids || !offsets || !final_T || !last_ids || !v_render_colors || !v_render_alphas || !v_rec) return ADK_EINVAL;
     if (((uintptr_t)rec & 15) || ((uintptr_t)v_render_colors & 15)) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
     hipLaunchKernelGGL(adk::raster_bwd_kernel, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
-                       rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_alphas, last_ids, v_render_colors,
+                       rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors,
                        v_render_alphas, v_rec);
     ADK_RETURN_LAST_ERROR();
 }

@@ -228,11 +228,12 @@ class RasterizeGaussians(torch.autograd.Function):
 
             render_colors = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
             render_alphas = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
+            final_T = torch.empty(H, W, dtype=torch.float32, device=dev)   # exact T_final for the backward
             last_ids = torch.empty(H, W, **i32)
             main_ids = torch.empty(H, W, **i32) if cfg.want_main_ids else None
             with _stage("raster_fwd"):
               rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
-                                    _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(),
+                                    _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(), final_T.data_ptr(),
                                     last_ids.data_ptr(), _lib.ptr(main_ids), stream)
             _lib.check(rc, "adk_raster_fwd")
 
@@ -250,9 +251,9 @@ class RasterizeGaussians(torch.autograd.Function):
         ctx.has_rest = rest_c is not None
         ctx.save_for_backward(means, quats, scales, colors_c if colors_c is not None else means.new_empty(0),
                               rest_c if rest_c is not None else means.new_empty(0), viewmat, K, bg if bg is not None else means.new_empty(0), rec, radii, flatten_ids,
-                              offsets, render_alphas, last_ids)
+                              offsets, final_T, last_ids)
         aux = (radii, rec, tiles_per_gauss, flatten_ids, offsets, isect_ids, last_ids,
-               main_ids if main_ids is not None else torch.empty(0, **i32))
+               main_ids if main_ids is not None else torch.empty(0, **i32), final_T)
         ctx.mark_non_differentiable(*aux)
         return (render_colors, render_alphas) + aux
 
@@ -260,7 +261,7 @@ class RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, v_colors, v_alphas, *unused):
         lib = _lib.load()
         cfg: RasterConfig = ctx.cfg
-        (means, quats, scales, colors, rest, viewmat, K, bg, rec, radii, flatten_ids, offsets, render_alphas,
+        (means, quats, scales, colors, rest, viewmat, K, bg, rec, radii, flatten_ids, offsets, final_T,
          last_ids) = ctx.saved_tensors
         dev = means.device
         N = means.shape[0]
@@ -273,7 +274,7 @@ class RasterizeGaussians(torch.autograd.Function):
             v_rec = torch.zeros(N, 12, dtype=torch.float32, device=dev)
             with _stage("raster_bwd"):
               rc = lib.adk_raster_bwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), ctx.n_isects,
-                                    bg.data_ptr() if ctx.has_bg else None, render_alphas.data_ptr(),
+                                    bg.data_ptr() if ctx.has_bg else None, final_T.data_ptr(),
                                     last_ids.data_ptr(), v_colors.data_ptr(), v_alphas.data_ptr(), v_rec.data_ptr(),
                                     stream)
             _lib.check(rc, "adk_raster_bwd")

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 3
+#define ADK_ABI_VERSION 4
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -169,17 +169,19 @@ int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int
                            const uint32_t* depth_keys, int64_t* isect_ids, adk_stream_t stream);
 
 /* Replaces rasterize_to_pixels fwd: render_colors [H,W,4], render_alphas [H,W], last_ids [H,W];
+ * final_T [H,W] = the exact final transmittance of each pixel, saved for the backward (upstream
+ * recovers it as 1 - render_alphas, which loses up to 1e-4 relative where alpha ~ 1);
  * backgrounds [4] or NULL; main_ids [H,W] or NULL = id of the Gaussian with the largest alpha*T per
  * pixel, -1 if none (mainGaussID of the on-the-fly-nvs GaussianRasterizer). */
 int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
                    const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                   float* render_colors, float* render_alphas, int32_t* last_ids, int32_t* main_ids,
-                   adk_stream_t stream);
+                   float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
+                   int32_t* main_ids, adk_stream_t stream);
 
 /* Replaces rasterize_to_pixels bwd: accumulates into v_rec [N,12] (caller zero-fills it). */
 int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,
                    const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                   const float* render_alphas, const int32_t* last_ids, const float* v_render_colors,
+                   const float* final_T, const int32_t* last_ids, const float* v_render_colors,
                    const float* v_render_alphas, float* v_rec, adk_stream_t stream);
 
 /* -------------------------------------------------------------- mast3r_slam_backends

@@ -199,7 +199,7 @@ def test_binning_is_bit_exact_at_baseline_sizes(N, W, H, dev):
     r, a, meta, _ = _run_hip(sc, dev)
     assert torch.equal(meta["radii"][0].cpu(), p["radii"])
     assert np.array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), oi["tiles_per_gauss"])
-    assert meta["isect_ids"].numel() == oi["n_isects"] and oi["n_isects"] > 3 * N
+    assert meta["isect_ids"].numel() == oi["n_isects"] and oi["n_isects"] > 2 * N
     assert np.array_equal(meta["isect_ids"].cpu().numpy(), oi["isect_ids"])
     assert np.array_equal(meta["flatten_ids"].cpu().numpy(), oi["flatten_ids"])
     assert np.array_equal(meta["isect_offsets"][0].cpu().numpy(), oi["offsets"])
@@ -210,16 +210,21 @@ def test_binning_is_bit_exact_at_baseline_sizes(N, W, H, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,W,H,window", [(200_000, 512, 384, (10, 8, 18, 14)), (1_000_000, 1920, 1080, (50, 30, 56, 34)),
-                                          (1_000_000, 1920, 1080, (0, 0, 4, 3)), (4_000_000, 2592, 1944, (158, 118, 162, 122))])
-def test_render_and_backward_at_baseline_sizes(N, W, H, window, dev):
+@pytest.mark.parametrize("N,W,H,window,tilt", [(200_000, 512, 384, (10, 8, 18, 14), 2), (1_000_000, 1920, 1080, (50, 30, 56, 34), 2),
+                                               (1_000_000, 1920, 1080, (0, 0, 4, 3), 2),
+                                               (4_000_000, 2592, 1944, (80, 119, 84, 122), None),   # ragged bottom row of tiles
+                                               (4_000_000, 2592, 1944, (40, 50, 43, 53), 2)])
+def test_render_and_backward_at_baseline_sizes(N, W, H, window, tilt, dev):
     """Forward render and every per-attribute gradient at the BASELINE sizes (configs[1] 200 k / 512x384, configs[2]
     1 M / 1080p, configs[3] 4 M / 2592x1944; interior, corner and ragged-edge windows) against fp64 autograd over the oracle.
     The HIP path renders and back-propagates the WHOLE frame; the loss is supported on a window of tiles so that the fp64
     reference (restricted to the Gaussians on those tiles' lists; everything else has an exactly zero gradient) stays
     tractable."""
-    sc = dict(_scene(N, W, H, 0), viewmat=_tilted_viewmat(2))
+    sc = _scene(N, W, H, 0)
+    if tilt is not None:
+        sc = dict(sc, viewmat=_tilted_viewmat(tilt))
     o = go.rasterization_window(sc, window)
+    assert len(o["ids"]) > 500
     tx0, ty0, tx1, ty1 = window
     ys, xs = slice(ty0 * 16, min(ty1 * 16, H)), slice(tx0 * 16, min(tx1 * 16, W))
     g = torch.Generator().manual_seed(5)
