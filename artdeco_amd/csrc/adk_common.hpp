@@ -108,7 +108,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // 16-lane row: at every stage a lane keeps one half of its values and ships the other half to its partner
 // (row_mirror, row_half_mirror, quad mirror, quad xor-1), 5 + 3 + 2 + 1 = 11 DPP ops + ~20 selects.
 // Afterwards lane `owner lanes` {0,1,2,4,6} (+8 for values 5..9) of each row hold the row sums of values
-// {0,1,2,3,4} (+5); two ds_bpermute adds (xor 16, xor 32) finish the 4 rows.
+// {0,1,2,3,4} (+5); two permlane-swap adds finish the 4 rows.
 // Returns the total of value `slot` (valid in every row's owner lanes); is_owner is true for the 10 lanes
 // of row 0 that should publish it.
 struct Reduce10 { float value; int slot; bool is_owner; };
@@ -135,9 +135,14 @@ __device__ __forceinline__ Reduce10 wave_reduce10(const float (&a)[10], int lane
     const float k4 = (two && b0) ? w1 : w0;
     const float s4 = two ? (b0 ? w0 : w1) : w0;
     float f = k4 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s4), 0xB1, 0xf, 0xf, false));
-    // the 4 rows
-    f += __shfl_xor(f, 16, 64);
-    f += __shfl_xor(f, 32, 64);
+    // the 4 rows, in registers: swap(x = f, y = f) leaves (lo, lo) / (hi, hi) resp. (even rows) / (odd rows) in x / y, so
+    // x + y is the pairwise sum in every lane (gfx950 v_permlane32_swap / v_permlane16_swap: 7.2 cycles each against ~21
+    // for a ds_bpermute + its lgkmcnt wait, tools/dpp_bench.hip)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f), __float_as_uint(f), false, false);
+    f = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+    sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(f), __float_as_uint(f), false, false);
+    f = __uint_as_float(sw.x) + __uint_as_float(sw.y);
     Reduce10 o;
     o.slot = (b3 ? 5 : 0) + (b2 ? (b1 ? 4 : 3) : (b1 ? 2 : (b0 ? 1 : 0)));
     o.is_owner = (lane < 16) && (two || !b0);

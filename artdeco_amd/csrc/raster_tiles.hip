@@ -66,6 +66,24 @@ __device__ __forceinline__ bool splat_reaches_rect(float mx, float my, float a, 
     return best <= tau;
 }
 
+// What both tile kernels stage in LDS per splat (three float4): the compositing loop evaluates
+//     alpha = opacity * exp(-sigma) = exp2(e),   e = dx (A dx + B dy) + C dy^2 + log2(opacity),
+// with A = -log2(e)/2 a, B = -log2(e) b, C = -log2(e)/2 c pre-multiplied ONCE per (splat, tile) by the lane that stages the
+// splat: v_exp_f32 is a base-2 exponential, so the per-pixel multiply by -log2(e) and the multiply by the opacity both
+// disappear (2 of ~25 / ~45 VALU instructions per evaluated pixel quadrant in fwd / bwd).  Forward and backward use the
+// SAME explicit fma sequence (splat_exponent) so that they take identical skip / terminate decisions on every pixel.
+struct StagedSplat { float4 a, cn, col; }; // a = (mean2d.x, mean2d.y, log2 opacity, opacity), cn = (A, B, C, unused)
+__device__ __forceinline__ void stage_splat(float4 (&dst)[3], const float4& r0, const float4& r1, const float4& r2) {
+    const float L2E = 1.4426950408889634f;
+    dst[0] = make_float4(r0.x, r0.y, __log2f(r0.z), r0.z);
+    dst[1] = make_float4(-0.5f * L2E * r1.x, -L2E * r1.y, -0.5f * L2E * r1.z, 0.f);
+    dst[2] = r2;
+}
+// log2(opacity * exp(-sigma)) at offset (dx, dy) from the splat centre
+__device__ __forceinline__ float splat_exponent(const float4& a, const float4& cn, float dx, float dy) {
+    return fmaf(dx, fmaf(cn.x, dx, cn.y * dy), fmaf(cn.z * dy, dy, a.z));
+}
+
 // ---------------------------------------------------------------------------------- forward
 // One wavefront per 16x16 tile; lane l owns pixel l (8x8 raster order) of EACH of the four 8x8 quadrants,
 // exactly like the backward below.  Against the earlier 4-waves-per-tile version this removes every
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (have) {
             const int64_t g = flatten_ids[batch_start + lane];
             r0 = rec4[3 * g]; r1 = rec4[3 * g + 1];
-            srec[lane][0] = r0; srec[lane][1] = r1; srec[lane][2] = rec4[3 * g + 2];
+            stage_splat(srec[lane], r0, r1, rec4[3 * g + 2]);
         }
         __syncthreads();
         // splat-parallel culling: this lane's splat against each live quadrant
@@ -152,9 +170,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 if (mq[q] & bit) { // wave-uniform
                     PixFwd& P = px[q];
                     const float dx = a.x - (fx0 + (float)((q & 1) * 8)), dy = a.y - (fy0 + (float)((q >> 1) * 8));
-                    const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
-                    const float alpha = fminf(MAX_ALPHA, a.z * __expf(-sigma));
-                    const bool valid = !((done >> q) & 1u) && !(sigma < 0.f || alpha < ALPHA_THR);
+                    const float e = splat_exponent(a, cn, dx, dy);
+                    const float alpha = fminf(MAX_ALPHA, __builtin_amdgcn_exp2f(e));
+                    const bool valid = !((done >> q) & 1u) && !(e > a.z || alpha < ALPHA_THR); // e > log2(opacity) <=> sigma < 0
                     const float next_T = P.T * (1.0f - alpha);
                     const bool term = valid && (next_T <= T_EPS); // terminate BEFORE adding this splat
                     const bool contrib = valid && !term;
@@ -218,9 +236,14 @@ struct PixBwd {
 //   * splat-parallel culling produces four 64-bit hit masks (one per quadrant) per group of 64 staged
 //     splats; the wave walks the union and, per splat, evaluates only the quadrants whose bit is set
 //     (wave-uniform branches), summing their contributions in the same 10 registers;
-//   * the 10 sums are reduced once (4 DPP row steps + 2 row_bcast steps) and lanes 63 issue the 10 global
-//     fp32 atomics directly -- no LDS accumulators, no cross-wave merge, no flush phase, no block barrier
-//     besides the (single-wave, free) staging barrier.
+//   * the 10 sums are reduced once per (splat, tile): transposing DPP butterfly inside each 16-lane row (11 DPP), the
+//     4 rows combined with v_permlane32_swap / v_permlane16_swap, and the 10 totals PARKED in an LDS table
+//     sacc[staged splat][gradient-record dword]; after the batch of 64 staged splats the table is flushed with 16
+//     wave instructions whose lanes cover 4 whole 48 B gradient records each.  Measured on MI355X (tools/lab, round 2):
+//     one 10-lane atomic instruction per splat 0.716 ms -> parked + flushed 0.650 ms; a flush whose 64 lanes hit 64
+//     DIFFERENT records was 2x SLOWER (1.55 ms: the memory side pays per cache line touched by an instruction, not per
+//     lane), LDS ds_add_f32 for the row combine 0.85 ms.  Where the time goes (same measurements, ablations): cull test +
+//     exponent + validity 0.22, gradient arithmetic 0.21, cross-lane reduction 0.18, atomics 0.09 ms.
 __global__ __launch_bounds__(64) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
@@ -230,6 +253,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 {
     __shared__ float4 srec[64][3];
     __shared__ int sid[64];
+    __shared__ float sacc[64][12]; // [staged splat][dword of its gradient record]: totals parked until the batch is flushed
     const int n_tiles = tile_w * tile_h;
     const int tile = xcd_remap(blockIdx.x, n_tiles);
     const int tx = tile % tile_w, ty = tile / tile_w;
@@ -280,9 +304,11 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         if (have) {
             g = flatten_ids[batch_end - lane];
             r0 = rec4[3 * (int64_t)g]; r1 = rec4[3 * (int64_t)g + 1]; r2 = rec4[3 * (int64_t)g + 2];
-            sid[lane] = g; srec[lane][0] = r0; srec[lane][1] = r1; srec[lane][2] = r2;
+            sid[lane] = g;
+            stage_splat(srec[lane], r0, r1, r2);
         }
         __syncthreads();
+        unsigned long long touched_mask = 0ull; // staged splats whose totals were parked in sacc
         // splat-parallel culling: this lane's splat against each quadrant
         unsigned long long mq[4];
 #pragma unroll
@@ -299,7 +325,6 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             const unsigned long long bit = 1ull << t;
             any &= any - 1;
             const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
-            const float opac = a.z;
             const int idx = batch_end - t;
             float acc[NACC];
 #pragma unroll
@@ -309,16 +334,15 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             for (int q = 0; q < 4; ++q) {
                 if (mq[q] & bit) { // wave-uniform
                     PixBwd& P = px[q];
-                    // Branch-free body: an invalid lane gets vis = 0 => alpha = 0, ra = 1, fac = 0 and every
+                    // Branch-free body: an invalid lane gets ov = 0 => alpha = 0, ra = 1, fac = 0 and every
                     // gradient term vanishes on its own.
                     const float dx = a.x - P.fx, dy = a.y - P.fy;
-                    const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
-                    float vis = __expf(-sigma);
-                    const bool valid = (idx <= P.bin_final) && !(sigma < 0.f) && !(opac * vis < ALPHA_THR);
+                    const float e = splat_exponent(a, cn, dx, dy);
+                    float ov = __builtin_amdgcn_exp2f(e); // opacity * exp(-sigma)
+                    const bool valid = (idx <= P.bin_final) && !(e > a.z) && !(ov < ALPHA_THR);
                     if (__ballot(valid) == 0ull) continue; // nobody in this quadrant blended it (all finished earlier / below 1/255)
                     touched = true;
-                    vis = valid ? vis : 0.f;
-                    const float ov = opac * vis;
+                    ov = valid ? ov : 0.f;
                     const float alpha = fminf(MAX_ALPHA, ov);
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha); // 1 ulp v_rcp_f32; alpha <= 0.999
                     P.T *= ra;
@@ -326,27 +350,43 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     const float S1 = col.x * P.vr0 + col.y * P.vr1 + col.z * P.vr2 + col.w * P.vr3;
                     const float v_alpha = P.T * S1 + ra * (P.C0 - P.bdot);
                     P.bdot += fac * S1;
-                    const float gop = (ov <= MAX_ALPHA) ? vis * v_alpha : 0.f; // clamped alpha passes no gradient
-                    const float t1 = gop * dx, t2 = gop * dy; // v_sigma = -opac * gop: the factor -opac is applied after the reduction
+                    // gq = opacity * vis * v_alpha = -v_sigma (clamped alpha passes no gradient); the opacity gradient is
+                    // vis * v_alpha = gq / opacity, divided once per splat at the flush
+                    const float gq = (ov <= MAX_ALPHA) ? ov * v_alpha : 0.f;
+                    const float t1 = gq * dx, t2 = gq * dy;
                     acc[0] += t1;                      // v_mean2d = conic (acc[0], acc[1])^T is formed by project_bwd,
                     acc[1] += t2;                      //   once per Gaussian instead of once per (splat, pixel)
-                    acc[2] += gop;                     // v_opacity
-                    acc[3] += t1 * dx;                 // 2 * v_conic.a
-                    acc[4] += t1 * dy;                 // v_conic.b
-                    acc[5] += t2 * dy;                 // 2 * v_conic.c
+                    acc[2] += gq;                      // opacity * v_opacity
+                    acc[3] += t1 * dx;                 // -2 * v_conic.a
+                    acc[4] += t1 * dy;                 // -v_conic.b
+                    acc[5] += t2 * dy;                 // -2 * v_conic.c
                     acc[6] += fac * P.vr0; acc[7] += fac * P.vr1; acc[8] += fac * P.vr2; acc[9] += fac * P.vr3;
                 }
             }
-            // ONE 64-lane reduction per (splat, tile): transposing butterfly (11 DPP ops instead of 60), after
-            // which 10 lanes of row 0 each own one total and publish it with a single atomic instruction
-            if (!touched) continue; // every sum is zero: no reduction, no atomics
+            if (!touched) continue; // every sum is zero: no reduction, nothing parked
+            // ONE 64-lane reduction per (splat, tile); the 10 lanes of row 0 that own a total park it in the LDS table
             const Reduce10 red = wave_reduce10(acc, lane);
-            // per-splat factors of the sums, applied once by the owner lane: -opac on the v_sigma-weighted slots
-            // (0,1,3,4,5), and the 1/2 of the symmetric conic entries (3,5)
-            const float scale = (red.slot == 2 || red.slot >= 6) ? 1.0f : ((red.slot == 3 || red.slot == 5) ? -0.5f * opac : -opac);
-            const float total = red.value * scale;
-            if (red.is_owner && total != 0.f)
-                unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[t] + acc_to_rec(red.slot), total);
+            touched_mask |= bit;
+            if (red.is_owner) sacc[t][acc_to_rec(red.slot)] = red.value;
+        }
+        // Flush the batch: one instruction = 4 staged splats x the 12 dwords of their gradient records (10 live), so its
+        // atomics fall into 4 records.  Per-splat factors applied here: -1 on the v_sigma-weighted dwords (0,1,5), -1/2 on
+        // the symmetric conic entries (4,6), 1/opacity on the opacity gradient (2).
+        if (touched_mask) {
+            __syncthreads();
+            const int d = lane & 15;
+            const bool live_d = d < 12 && d != 3 && d != 7;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                if (!((touched_mask >> (4 * j)) & 0xFull)) continue; // wave-uniform: none of these 4 splats was touched
+                const int sp = 4 * j + (lane >> 4);
+                if (live_d && ((touched_mask >> sp) & 1ull)) {
+                    const float opac = srec[sp][0].w;
+                    const float scale = d >= 8 ? 1.0f : (d == 2 ? __builtin_amdgcn_rcpf(opac) : ((d == 4 || d == 6) ? -0.5f : -1.0f));
+                    const float total = sacc[sp][d] * scale;
+                    if (total != 0.f) unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[sp] + d, total);
+                }
+            }
         }
     }
 }

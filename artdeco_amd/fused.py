@@ -467,7 +467,7 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
 
 
 def fused_optimization_step_mirror(self, keyframe_id=-1, is_important=True):
-    """artdeco_amd.mapper.MapperScene.optimization_step with the fused chain."""
+    """harness.mapper.MapperScene.optimization_step with the fused chain."""
     if len(self.xyz) == 0:
         return None
     return fused_train_on_keyframe(self, keyframe_id, is_important)
@@ -596,7 +596,7 @@ def fused_weed_out_gaussians(self):
 
 
 def patch_scene_model(scene) -> bool:
-    """Install fused_render on this scene-model instance (ARTDECO's SceneModel or artdeco_amd.mapper.MapperScene).
+    """Install fused_render on this scene-model instance (ARTDECO's SceneModel or harness.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
     if not supported(scene):
         return False

@@ -4,7 +4,7 @@
 (`mast3r_slam_backends.gauss_newton_*`, VSLAM/mast3r_slam/global_opt.py:138-231): per-keyframe canonical pointmaps
 `Xs [P,n,3]`, confidences `Cs [P,n,1]`, a two-way factor list `ii/jj [E]` (prep_two_way_edges, global_opt.py:131-138),
 matches `idx [E,n]`, `valid [E,n,1]`, match scores `Q [E,n,1]`, and the ground-truth poses `T_gt [P,8]` = (t, q xyzw, s).
-The Gaussian-cloud workload of the mapper lives in `artdeco_amd.mapper.synthetic_cloud`.
+The Gaussian-cloud workload of the mapper lives in `harness.mapper.synthetic_cloud`.
 """
 from __future__ import annotations
 

@@ -2,7 +2,9 @@
 """bench.py -- mapper hot path on MI355X (see DESIGN.md "Measurement").
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, one independent scene per rank)
+    (N > 1: one rank per GPU, one independent scene per rank.  Under torch.distributed.run the ranks are already there;
+    a bare `python bench.py --gpus N` re-executes itself under torch.distributed.run with N local ranks on 127.0.0.1.
+    `--backend gloo --cpu-dry-run` drives the same launch / barrier / all-reduce / report path on CPU for the tests.)
 
 Workload (BASELINE.json metric "on-the-fly frames/sec + raster fwd+bwd ms @1M Gaussians 1080p"):
 config[2] -- 1 M Gaussians, 1920x1080, SH degree 3, RGB+D, L1 + fused-SSIM + inverse-depth loss,
@@ -14,8 +16,10 @@ frames/s = steps/s / steps_per_frame with steps_per_frame = 10 (run.sh --num_com
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -42,7 +46,70 @@ def parse():
                     help="skip the secondary measurements (other BASELINE configs, unfused glue) reported next to `value`")
     ap.add_argument("--unfused-glue", action="store_true",
                     help="time ARTDECO's render() glue as stock torch ops instead of artdeco_amd.fused (SURVEY 8 f-1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no GPU work: a constant CPU step through the same launch / barrier / all-reduce / report code "
+                         "(tests/test_multigpu.py runs `bench.py --gpus 2 --backend gloo --cpu-dry-run`)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    (one process per GPU, rendezvous on 127.0.0.1, a free port).  Never returns."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def cpu_dry_run(args, rank, world):
+    """The N > 1 control path on CPU (gloo): rendezvous, barrier, K timed `steps`, MAX / SUM all-reduce, one JSON line."""
+    from artdeco_amd import multigpu
+    dev = torch.device("cpu")
+    multigpu.init(args.backend, None)
+    x = torch.ones(1 << 16)
+    step = lambda: float((x * 1.0001).sum())
+    for _ in range(args.warmup):
+        step()
+    multigpu.barrier(None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    multigpu.barrier(None)
+    elapsed = time.perf_counter() - t0
+    elapsed_max, sums = multigpu.aggregate(elapsed, {"steps": float(args.steps)}, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "cpu-dry-run steps/sec (control path only)", "value": sums["steps"] / elapsed_max, "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "cpu-dry-run",
+                          "config": {"workload": "constant CPU step (no kernels): launch + barrier + metric all-reduce path",
+                                     "parallelism": f"scene-per-rank x{world}", "backend": args.backend}}))
+    multigpu.shutdown()
+
+
+def measure_hbm_copy_gbs(lib, dev):
+    """Achievable HBM bandwidth of THIS box: adk_stream_copy (float4 grid-stride copy) of 1 GiB, read + write bytes over the
+    best of 5 launches.  BASELINE.md asks for the roofline denominator to be re-measured next to the 8 TB/s spec."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    best = float("inf")
+    for i in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.adk_stream_copy(dst.data_ptr(), src.data_ptr(), n, stream)
+        e1.record()
+        assert rc == 0, rc
+        torch.cuda.synchronize(dev)
+        if i >= 2:
+            best = min(best, e0.elapsed_time(e1))
+    return 2.0 * n / (best * 1e-3) / 1e9
 
 
 def cpu_baseline(args):
@@ -81,15 +148,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                     # one rank per GPU; this process is replaced
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
         sys.exit(2)
+    if args.cpu_dry_run:
+        return cpu_dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    from artdeco_amd import _lib, mapper, multigpu, rasterizer
-    multigpu.init("nccl", dev)  # RCCL over xGMI; used for the barrier + the metric all-reduce only
-    _lib.load()
+    from artdeco_amd import _lib, multigpu, rasterizer
+    from harness import mapper
+    multigpu.init(args.backend, dev)  # nccl = RCCL over xGMI; used for the barrier + the metric all-reduce only
+    lib = _lib.load()
     torch.manual_seed(rank)
     scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=rank, targets="render")
     nkf = len(scene.keyframes)
@@ -136,6 +208,8 @@ def main():
         bwd_ms = stages["raster_bwd"]["mean_ms"]
         alg_bytes_bwd = 44.0 * I + 28.0 * P + 40.0 * V  # raster bwd
         achieved = alg_bytes_bwd / (bwd_ms * 1e-3) / 1e9
+        hbm_measured = measure_hbm_copy_gbs(lib, dev)
+        prof = _profile_counters(args)
         out = {
             "metric": "on-the-fly frames/sec (mapper hot path; raster fwd+bwd + L1 + fused-SSIM + sparse Adam) @1M Gaussians 1080p",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,18 +222,27 @@ def main():
             "raster_fwd_ms": stages["raster_fwd"]["mean_ms"], "raster_bwd_ms": bwd_ms,
             "stage_ms": {k: round(v["mean_ms"], 4) for k, v in stages.items()},
             "roofline": {"bound": "hbm", "kernel": "raster_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profile(args),
-                         "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("raster_bwd_hbm_bytes"),
+                         "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms,
+                         "peak_measured_stream_copy": hbm_measured, "frac_of_measured_peak": achieved / hbm_measured,
+                         "traffic_source": prof.get("source")},
         }
-        valu = _valu_from_profile(args)
-        if valu is not None:
-            # The kernel the metric prices against HBM is bounded by vector-ALU ISSUE: wave64 VALU
-            # instructions per launch from the committed SQ_INSTS_VALU PMC pass of this workload, over the live launch time,
-            # against 1024 SIMDs x 2.4 GHz / 4 cycles per instruction.
-            peak_valu = 1024 * 2.4e9 / 4.0 / 1e9
+        if prof.get("raster_bwd_valu_wave_insts"):
+            # What actually bounds the kernel the metric prices against HBM is vector-ALU time.  Two
+            # numbers, both from the committed PMC pass of THIS kernel source (null when the source changed since):
+            #  * issue fraction: wave64 VALU instructions per launch / launch time against the guide's issue rate, 1024 SIMDs
+            #    x 2.4 GHz / 2 cycles per instruction (MI355X_MICROARCH.md "issues each VALU instruction over 2 cycles");
+            #  * VALU-busy: SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x launch cycles at 2.4 GHz).
+            # busy / issue = average cycles per VALU instruction / 2: DPP, transcendental and packed ops cost more than 2.
+            valu = prof["raster_bwd_valu_wave_insts"]
+            peak_valu = 1024 * 2.4e9 / 2.0 / 1e9
             ach = valu / (bwd_ms * 1e-3) / 1e9
-            out["roofline_valu"] = {"bound": "valu-issue", "kernel": "raster_bwd_kernel", "achieved": ach, "peak": peak_valu,
+            out["roofline_valu"] = {"bound": "valu", "kernel": "raster_bwd_kernel", "achieved": ach, "peak": peak_valu,
                                     "unit": "G wave-instr/s", "frac": ach / peak_valu, "wave_insts_per_launch": valu}
+            if prof.get("raster_bwd_active_inst_valu_quadcycles"):
+                busy = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / (1024 * bwd_ms * 1e-3 * 2.4e9)
+                out["roofline_valu"]["valu_busy"] = busy
+                out["roofline_valu"]["cycles_per_valu_inst"] = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / valu
         if not args.no_extra_configs and world == 1:
             out["other_configs"] = extra_configs(args, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -191,21 +274,30 @@ def extra_configs(args, dev):
     """Secondary single-GPU measurements, OUTSIDE the timed region of `value` (10 steps each): the other
     BASELINE.json configs that fit one GPU, and the headline config with ARTDECO's render() glue left as stock
     torch ops (what an unchanged run_system.py gets without the one-line artdeco_amd.fused patch)."""
-    from artdeco_amd import fused, mapper
+    from artdeco_amd import fused
+    from harness import mapper
     res = {}
-    cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True),
-             ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True),
-             ("run.sh training resolution (map 1296x972, pyr_lvl 1): 1M Gaussians 648x486", 1_000_000, 648, 486, True),
-             ("configs[3] 4M Gaussians 2592x1944", 4_000_000, 2592, 1944, True),
-             (f"headline config, unfused torch glue ({args.gaussians} Gaussians {args.width}x{args.height})",
-              args.gaussians, args.width, args.height, False)]
-    for name, n, w, h, use_fused in cases:
+    cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True, False),
+             ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True, False),
+             ("run.sh training resolution (map 1296x972, pyr_lvl 1): 1M Gaussians 648x486", 1_000_000, 648, 486, True, False),
+             ("configs[3] 4M Gaussians 2592x1944, d_max = creation depth x LoD level (LoD culling and fading active)",
+              4_000_000, 2592, 1944, True, True),
+             ("configs[3] 4M Gaussians 2592x1944, no LoD culling (d_max = inf)", 4_000_000, 2592, 1944, True, False),
+             (f"headline config, UNCHANGED host code: ARTDECO's torch glue, natives swapped only ({args.gaussians} Gaussians {args.width}x{args.height})",
+              args.gaussians, args.width, args.height, False, False),
+             ("north-star target 1M Gaussians 512x384, UNCHANGED host code", 1_000_000, 512, 384, False, False)]
+    for name, n, w, h, use_fused, lod in cases:
         try:
-            scene = mapper.build_synthetic_mapper(n, w, h, dev, seed=0, targets="render")
+            scene = mapper.build_synthetic_mapper(n, w, h, dev, seed=0, targets="render", lod=lod)
             if use_fused:
                 fused.patch_scene_model(scene)
             dt = _time_steps(scene)
             res[name] = {"ms_per_step": dt * 1e3, "frames_per_s": 1.0 / (dt * STEPS_PER_FRAME)}
+            if lod:
+                with torch.no_grad():
+                    pkg = scene.render_from_id(0)
+                res[name]["lod_selected_frac"] = float(scene.last_selected_frac) if hasattr(scene, "last_selected_frac") else None
+                res[name]["visible_frac"] = float(pkg["visibility_filter"].float().mean())
             del scene
             torch.cuda.empty_cache()
         except Exception as e:  # report, never hide
@@ -213,28 +305,28 @@ def extra_configs(args, dev):
     return res
 
 
-def _traffic_from_profile(args):
-    """HBM bytes per raster_bwd launch from the committed rocprofv3 PMC pass (profiles/), when it was
-    taken on this exact workload; otherwise null."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        t = json.load(open(p))
-        if (t.get("gaussians"), t.get("width"), t.get("height")) == (args.gaussians, args.width, args.height):
-            return t.get("raster_bwd_hbm_bytes")
-    except Exception:
-        pass
-    return None
+def kernel_source_sha():
+    """Hash of the sources raster_bwd_kernel is compiled from: profiles/traffic.json is only valid for the kernel it profiled."""
+    h = hashlib.sha256()
+    for f in ("raster_tiles.hip", "adk_common.hpp"):
+        h.update(open(os.path.join(ROOT, "artdeco_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def _valu_from_profile(args):
-    """Wave64 VALU instructions per raster_bwd launch from the committed PMC pass (same workload only), else None."""
+def _profile_counters(args):
+    """Per-launch PMC figures of raster_bwd_kernel from the committed rocprofv3 passes (profiles/traffic.json, written by
+    tools/profile_round.sh on this exact workload).  Stamped with the hash of the kernel's sources: after any edit of
+    raster_tiles.hip the old counters are NOT reported (traffic: null) until the profile is re-taken."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if (t.get("gaussians"), t.get("width"), t.get("height")) == (args.gaussians, args.width, args.height):
-            return t.get("raster_bwd_valu_wave_insts")
     except Exception:
-        pass
-    return None
+        return {}
+    if (t.get("gaussians"), t.get("width"), t.get("height")) != (args.gaussians, args.width, args.height):
+        return {}
+    if t.get("kernel_source_sha") != kernel_source_sha():
+        return {"source": f"profiles/traffic.json is stale (kernel sources changed since {t.get('tag')}): re-run tools/profile_round.sh"}
+    t["source"] = f"profiles/traffic.json ({t.get('tag')}; rocprofv3 --pmc passes, per launch)"
+    return t
 
 
 if __name__ == "__main__":

@@ -386,13 +386,18 @@ def synthetic_cloud(N, width, height, seed=0, sh_k=16, z_range=(2.0, 6.0), sigma
     return dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, fx=fx)
 
 
-def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random"):
+def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random", lod=False):
     """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height).
     targets: "random" = uniform-noise keyframe images (every parameter gets a large gradient: what the parity tests
     want); "render" = each keyframe observes the cloud itself (its own render and inverse depth), i.e. a converged map,
     so the cloud keeps the SURVEY 8(d) statistics while it is optimised.  With noise targets the optimiser dissolves
     the cloud within ~30 steps (opacities and radii shrink, intersections 3.7 M -> 2.3 M at 1 M Gaussians / 1080p,
-    raster backward 1.0 -> 0.5 ms): a benchmark on them times a workload that gets lighter every step."""
+    raster backward 1.0 -> 0.5 ms): a benchmark on them times a workload that gets lighter every step.
+    lod: give every Gaussian the d_max the reference would have given it, creation depth x LoD level (h3dgsv3.py:891 with
+    self.lods = [1, 2, 4, 8], :222): levels drawn 55/25/13/7 %, creation depth = distance to the camera x U(0.35, 1.5) (the map
+    was built from keyframes nearer and farther than the one rendering it).  About 8 % of the cloud then fails
+    `dist < 2 d_max` and is culled, another ~25 % is faded by the alpha ratio (h3dgsv3.py:628-639); with lod=False d_max is
+    1e3 and the LoD logic never triggers (the SURVEY 8(d) statistics, used for the headline)."""
     c = synthetic_cloud(N, width, height, seed)
     torch.manual_seed(seed)  # nn.Linear's default init draws from the global generator
     scene = MapperScene(width, height, c["fx"], device)
@@ -405,6 +410,11 @@ def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targ
         last.bias.copy_(torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0]))
     op = c["opacities"].clamp(1e-4, 1 - 1e-4)
     scene.set_gaussians(c["means"], c["quats"], torch.log(2.0 * c["scales"]), torch.log(op / (1 - op)), c["sh"], seed=seed)
+    if lod:
+        gl = torch.Generator().manual_seed(seed + 7)
+        level = torch.tensor([1.0, 2.0, 4.0, 8.0])[torch.multinomial(torch.tensor([0.55, 0.25, 0.13, 0.07]), N, True, generator=gl)]
+        z_create = c["means"].norm(dim=1) * (0.35 + 1.15 * torch.rand(N, generator=gl))
+        scene.gaussian_params["d_max"]["val"] = (z_create * level).reshape(N, 1).to(device)
     g = torch.Generator().manual_seed(seed + 1)
     for i in range(n_keyframes):
         Rt = torch.eye(4)

@@ -48,7 +48,8 @@ ALL = ("id", "cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,E,keep_frac", [(10_000, 3_000, 0.8), (777, 0, 0.5), (5_000, 1_234, 1.0), (300, 50, 0.0), (1, 1, 1.0)])
 def test_fused_add_and_prune_matches_torch(N, E, keep_frac, dev):
-    from artdeco_amd import fused, mapper
+    from artdeco_amd import fused
+    from harness import mapper
     ref = _optimizer(dev, N, 64, seed=N)
     got = _clone(ref)
     g = torch.Generator().manual_seed(E + 1)

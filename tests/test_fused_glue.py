@@ -5,7 +5,7 @@ import torch
 
 
 def _scene(dev, N=20000, W=160, H=112, seed=0, lod=True):
-    from artdeco_amd import mapper
+    from harness import mapper
     sc = mapper.build_synthetic_mapper(N, W, H, dev, seed=seed, n_keyframes=2)
     g = torch.Generator().manual_seed(seed + 5)
     with torch.no_grad():
@@ -86,7 +86,7 @@ def test_fused_optimization_step_tracks_unfused(dev):
 def test_pose_rt_matches_sixd_autograd(dev):
     """PoseRt (one kernel each way) vs Keyframe.get_Rt's torch chain (keyframe.py:150-154, utils.py:223-229)."""
     from artdeco_amd.fused import PoseRt
-    from artdeco_amd.mapper import sixD2mtx
+    from harness.mapper import sixD2mtx
     g = torch.Generator().manual_seed(1)
     for trial in range(4):
         r6 = (torch.eye(3)[:, :2] + 0.4 * torch.randn(3, 2, generator=g)).to(dev).requires_grad_(True)
@@ -111,7 +111,7 @@ def test_fused_mapper_loss_matches_torch_chain(important, dev):
     """FusedMapperLoss vs the reference's image-space chain written in torch (h3dgsv3.py:690-694, 611-614,
     430-448) on the same rasteriser-shaped inputs: loss, by-products and all three gradients."""
     from artdeco_amd.fused import FusedMapperLoss
-    from artdeco_amd.mapper import radial_decay_kernel
+    from harness.mapper import radial_decay_kernel
     from fused_ssim import fused_ssim
     H, W = 75, 133
     g = torch.Generator().manual_seed(7)
@@ -242,7 +242,8 @@ def test_colour_adam_inside_backward_is_bit_identical(N, deg, dev):
     import artdeco_amd
     artdeco_amd.install_dropins()
     from diff_gaussian_rasterization import adamUpdate
-    from artdeco_amd import _lib, mapper
+    from artdeco_amd import _lib
+    from harness import mapper
     lib = _lib.load()
     W, H, K = 160, 112, 16
     c = mapper.synthetic_cloud(N, W, H, seed=4)

@@ -1,4 +1,4 @@
-"""The mirror of ARTDECO's mapper host code (artdeco_amd/mapper.py: MapperScene.render / render_from_id /
+"""The mirror of ARTDECO's mapper host code (harness/mapper.py: MapperScene.render / render_from_id /
 optimization_step, Keyframe, sixD2mtx, radial_decay_kernel) against the REFERENCE's own source, executed on CPU.
 
 `SceneModel.render`, `render_from_id`, `optimization_step` (Reconstruct/scene/scene_models/h3dgsv3.py:401-469, 595-700) and
@@ -85,7 +85,7 @@ def _adam_update_basic(param, grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
 
 @pytest.fixture()
 def world(monkeypatch):
-    from artdeco_amd import mapper
+    from harness import mapper
     fake_gsplat = types.SimpleNamespace(rendering=types.SimpleNamespace(rasterization=_rasterization))
     monkeypatch.setattr(mapper, "gsplat", fake_gsplat)
     monkeypatch.setattr(mapper, "fused_ssim", _fused_ssim)

@@ -46,3 +46,23 @@ def test_single_process_is_a_noop():
     assert topo.world == 1
     e, s = multigpu.aggregate(3.0, {"steps": 7.0}, torch.device("cpu"))
     assert e == 3.0 and s == {"steps": 7.0}
+
+
+def test_bench_entry_self_launches_two_ranks_on_gloo():
+    """The driver's own invocation, `python bench.py --gpus N` with no launcher in front of it: bench.py re-executes itself
+    under torch.distributed.run with N local ranks (127.0.0.1), every rank joins the process group, the barrier / MAX / SUM
+    all-reduce path runs, and rank 0 prints exactly one JSON line with n_gpus = N.  (--cpu-dry-run replaces the GPU step by
+    a constant CPU step; everything around it is the code the 8-GPU run executes.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cpu-dry-run",
+                        "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "scene-per-rank x2"

@@ -1,4 +1,4 @@
-"""The mirror of ARTDECO's optimiser host logic (artdeco_amd/mapper.py: BaseAdam, SparseGaussianAdam.step / add_and_prune)
+"""The mirror of ARTDECO's optimiser host logic (harness/mapper.py: BaseAdam, SparseGaussianAdam.step / add_and_prune)
 against the REFERENCE's own classes (Reconstruct/scene/optimizers.py), run side by side on CPU.
 
 The reference's classes are imported from /root/reference and executed unmodified; only the two native entry points they
@@ -39,7 +39,7 @@ def both(monkeypatch):
     artdeco_amd.install_dropins()
     sys.path.insert(0, REF)
     ref = __import__("Reconstruct.scene.optimizers", fromlist=["SparseGaussianAdam"])
-    from artdeco_amd import mapper
+    from harness import mapper
     for mod in (ref, mapper):
         monkeypatch.setattr(mod, "adamUpdate", _adam_update)
         monkeypatch.setattr(mod, "adamUpdateBasic", _adam_update_basic)

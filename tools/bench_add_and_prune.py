@@ -1,5 +1,5 @@
 """Time SparseGaussianAdam.add_and_prune (optimizers.py:163-219) at 1 M Gaussians + 50 k new ones, 95 % kept:
-the torch restatement (artdeco_amd.mapper._add_and_prune) vs artdeco_amd.fused.fused_add_and_prune.
+the torch restatement (harness.mapper._add_and_prune) vs artdeco_amd.fused.fused_add_and_prune.
 usage (GPU box, repo root): python tools/bench_add_and_prune.py"""
 import os
 import sys
@@ -8,7 +8,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from artdeco_amd import fused, mapper  # noqa: E402
+from artdeco_amd import fused
+from harness import mapper  # noqa: E402
 from tests.test_add_and_prune import ALL, _clone, _extension, _optimizer  # noqa: E402
 
 dev = torch.device("cuda:0")

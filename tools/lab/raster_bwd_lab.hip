@@ -6,6 +6,11 @@
 //   2  no reduction, no atomics (the 10 per-lane sums go to the sink)
 //   3  cull test + sigma/exp/validity only (no gradient math, no reduction)
 //   4  reduction through LDS (transpose: 10 ds_write_b32 per lane, 10 lanes x 4 partial columns, DPP finish)
+//   5  row butterfly (11 DPP) then the 4 row sums of every slot go to an LDS table sacc[64 splats][10] with ds_add_f32;
+//      after the batch of 64 staged splats the table is flushed with 10 FULL-WAVE atomic instructions (lane = splat)
+//      instead of one 10-lane atomic instruction per splat
+//   6  as 5 but the 4 rows are combined in registers with v_permlane32_swap / v_permlane16_swap and 10 lanes ds_write
+//   7  as 6 + hand-scheduled body (exp2 with folded log2 constants, opacity folded into the exponent)
 // The answer to "where do the 0.73 ms go" is the difference between consecutive variants.
 #include "adk_common.hpp"
 
@@ -42,7 +47,12 @@ struct PixBwd {
     int bin_final;
 };
 
-__global__ __launch_bounds__(64) void lab_bwd_kernel(
+#if LAB_VARIANT == 8
+#define LAB_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define LAB_OCC
+#endif
+__global__ __launch_bounds__(64) LAB_OCC void lab_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     const float* __restrict__ final_T, const int32_t* __restrict__ last_ids,
@@ -53,6 +63,9 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
     __shared__ int sid[64];
 #if LAB_VARIANT == 4
     __shared__ float sred[NACC][65];
+#endif
+#if LAB_VARIANT >= 5
+    __shared__ float sacc[64][12]; // [staged splat][gradient-record dword]: a flush instruction covers 4 whole records
 #endif
     const int n_tiles = tile_w * tile_h;
     const int tile = xcd_remap(blockIdx.x, n_tiles);
@@ -103,8 +116,25 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
         if (have) {
             g = flatten_ids[batch_end - lane];
             r0 = rec4[3 * (int64_t)g]; r1 = rec4[3 * (int64_t)g + 1]; r2 = rec4[3 * (int64_t)g + 2];
+#if LAB_VARIANT >= 7 || defined(LAB_EXP2)
+            {   // pre-scaled per-splat constants: exponent of 2 instead of e, opacity folded in as log2(opacity)
+                const float L2E = 1.4426950408889634f;
+                sid[lane] = g;
+                srec[lane][0] = make_float4(r0.x, r0.y, __log2f(r0.z), r0.z);
+                srec[lane][1] = make_float4(-0.5f * L2E * r1.x, -L2E * r1.y, -0.5f * L2E * r1.z, 0.f);
+                srec[lane][2] = r2;
+            }
+#else
             sid[lane] = g; srec[lane][0] = r0; srec[lane][1] = r1; srec[lane][2] = r2;
+#endif
         }
+#if LAB_VARIANT >= 5
+#if LAB_VARIANT == 5
+#pragma unroll
+        for (int k = 0; k < 12; ++k) (&sacc[0][0])[k * 64 + lane] = 0.f;
+#endif
+        unsigned long long touched_mask = 0ull;
+#endif
         __syncthreads();
         unsigned long long mq[4];
 #pragma unroll
@@ -121,7 +151,11 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
             const unsigned long long bit = 1ull << t;
             any &= any - 1;
             const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
+#if LAB_VARIANT >= 7 || defined(LAB_EXP2)
+            const float opac = a.w;
+#else
             const float opac = a.z;
+#endif
             const int idx = batch_end - t;
             float acc[NACC];
 #pragma unroll
@@ -132,6 +166,26 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
                 if (mq[q] & bit) {
                     PixBwd& P = px[q];
                     const float dx = a.x - P.fx, dy = a.y - P.fy;
+#if LAB_VARIANT >= 7 || defined(LAB_EXP2)
+                    const float e = fmaf(dx, fmaf(cn.x, dx, cn.y * dy), fmaf(cn.z * dy, dy, a.z)); // log2(opacity * exp(-sigma))
+                    float ov = __builtin_amdgcn_exp2f(e);
+                    const bool valid = (idx <= P.bin_final) && !(e > a.z) && !(ov < ALPHA_THR);
+                    if (__ballot(valid) == 0ull) continue;
+                    touched = true;
+                    ov = valid ? ov : 0.f;
+                    const float alpha = fminf(MAX_ALPHA, ov);
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    P.T *= ra;
+                    const float fac = alpha * P.T;
+                    const float S1 = col.x * P.vr0 + col.y * P.vr1 + col.z * P.vr2 + col.w * P.vr3;
+                    const float v_alpha = P.T * S1 + ra * (P.C0 - P.bdot);
+                    P.bdot += fac * S1;
+                    const float gq = (ov <= MAX_ALPHA) ? ov * v_alpha : 0.f; // = opacity * vis * v_alpha
+                    const float t1 = gq * dx, t2 = gq * dy;
+                    acc[0] += t1; acc[1] += t2; acc[2] += gq;
+                    acc[3] += t1 * dx; acc[4] += t1 * dy; acc[5] += t2 * dy;
+                    acc[6] += fac * P.vr0; acc[7] += fac * P.vr1; acc[8] += fac * P.vr2; acc[9] += fac * P.vr3;
+#else
                     const float sigma = 0.5f * (cn.x * dx * dx + cn.z * dy * dy) + cn.y * dx * dy;
                     float vis = __expf(-sigma);
                     const bool valid = (idx <= P.bin_final) && !(sigma < 0.f) && !(opac * vis < ALPHA_THR);
@@ -155,6 +209,7 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
                     acc[3] += t1 * dx; acc[4] += t1 * dy; acc[5] += t2 * dy;
                     acc[6] += fac * P.vr0; acc[7] += fac * P.vr1; acc[8] += fac * P.vr2; acc[9] += fac * P.vr3;
 #endif
+#endif
                 }
             }
             if (!touched) continue;
@@ -163,6 +218,45 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
 #elif LAB_VARIANT == 2
 #pragma unroll
             for (int k = 0; k < NACC; ++k) sink += acc[k];
+#elif LAB_VARIANT >= 5
+            {
+                touched_mask |= bit;
+                // intra-row transposing butterfly only (11 DPP): afterwards the 10 owner lanes of EACH 16-lane row hold
+                // that row's sum of slot o.slot
+                const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+                float r[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const float keep = b3 ? acc[j + 5] : acc[j], send = b3 ? acc[j] : acc[j + 5];
+                    r[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x140, 0xf, 0xf, false));
+                }
+                const float k0 = b2 ? r[3] : r[0], k1 = b2 ? r[4] : r[1], s0 = b2 ? r[0] : r[3], s1 = b2 ? r[1] : r[4];
+                const float u0 = k0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x141, 0xf, 0xf, false));
+                const float u1 = k1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x141, 0xf, 0xf, false));
+                const float u2 = r[2] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r[2]), 0x141, 0xf, 0xf, false));
+                const float k30 = b2 ? (b1 ? u1 : u0) : (b1 ? u2 : u0);
+                const float s30 = b2 ? (b1 ? u0 : u1) : (b1 ? u0 : u2);
+                const float w0 = k30 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s30), 0x1B, 0xf, 0xf, false));
+                const float w1 = u1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u1), 0x1B, 0xf, 0xf, false));
+                const bool two = !b2 && !b1;
+                const float k4 = (two && b0) ? w1 : w0;
+                const float s4 = two ? (b0 ? w0 : w1) : w0;
+                float f = k4 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s4), 0xB1, 0xf, 0xf, false));
+                const int slot = (b3 ? 5 : 0) + (b2 ? (b1 ? 4 : 3) : (b1 ? 2 : (b0 ? 1 : 0)));
+                const bool row_owner = two || !b0;
+#if LAB_VARIANT == 5
+                if (row_owner) atomicAdd(&sacc[t][acc_to_rec(slot)], f);   // ds_add_f32, 40 lanes, 4 rows per address
+#else
+                {   // the 4 rows in registers: x = f, y = f; permlane32_swap -> (lo,lo),(hi,hi); permlane16_swap -> even/odd rows
+                    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                    u2v p = __builtin_amdgcn_permlane32_swap(__float_as_uint(f), __float_as_uint(f), false, false);
+                    f = __uint_as_float(p.x) + __uint_as_float(p.y);
+                    p = __builtin_amdgcn_permlane16_swap(__float_as_uint(f), __float_as_uint(f), false, false);
+                    f = __uint_as_float(p.x) + __uint_as_float(p.y);
+                    if (row_owner && lane < 16) sacc[t][acc_to_rec(slot)] = f;
+                }
+#endif
+            }
 #elif LAB_VARIANT == 4
             // LDS transpose: lane l writes its 10 sums to column l; then lane (k, part) = (l % 10, l / 10), l < 60,
             // adds 64/6 ~ 11 entries of row k; 6 partials per slot are combined with 3 DPP-free LDS reads by the owner.
@@ -189,9 +283,16 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
             }
 #else
             const Reduce10 red = wave_reduce10(acc, lane);
+#ifdef LAB_EXP2
+            const float scale = red.slot >= 6 ? 1.0f : (red.slot == 2 ? __builtin_amdgcn_rcpf(opac) : ((red.slot == 3 || red.slot == 5) ? -0.5f : -1.0f));
+#else
             const float scale = (red.slot == 2 || red.slot >= 6) ? 1.0f : ((red.slot == 3 || red.slot == 5) ? -0.5f * opac : -opac);
+#endif
             const float total = red.value * scale;
-#if LAB_VARIANT == 1
+#if LAB_VARIANT == 1 && defined(LAB_COUNT)
+            sink += (red.is_owner && total != 0.f) ? 1.f : 0.f;      // how many lane-atomics would have been issued
+            if (lane == 63) sink += 1024.f;                           // ... and how many (splat, tile) pairs reduced
+#elif LAB_VARIANT == 1
             sink += red.is_owner ? total : 0.f;
 #else
             if (red.is_owner && total != 0.f)
@@ -199,8 +300,34 @@ __global__ __launch_bounds__(64) void lab_bwd_kernel(
 #endif
 #endif
         }
+#if LAB_VARIANT >= 5
+        // flush: one instruction = 4 staged splats x their 12-dword gradient records (10 live dwords each), so the
+        // atomics of an instruction fall into 4 records (full-wave instructions over 64 DIFFERENT records were measured
+        // 2x slower than the per-splat 10-lane form: the memory side pays per cache line touched, not per lane)
+        __syncthreads();
+        {
+            const int d = lane & 15;
+            const bool live_d = d < 12 && d != 3 && d != 7;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int sp = 4 * j + (lane >> 4);
+                if (!((touched_mask >> (4 * j)) & 0xFull)) continue; // wave-uniform: none of these 4 splats was touched
+                if (live_d && ((touched_mask >> sp) & 1ull)) {
+#if LAB_VARIANT >= 7
+                    const float opac = srec[sp][0].w; // sums carry opacity already: v_opacity = sum / opacity
+                    const float scale = d >= 8 ? 1.0f : (d == 2 ? __builtin_amdgcn_rcpf(opac) : ((d == 4 || d == 6) ? -0.5f : -1.0f));
+#else
+                    const float opac = srec[sp][0].z;
+                    const float scale = (d == 2 || d >= 8) ? 1.0f : ((d == 4 || d == 6) ? -0.5f * opac : -opac);
+#endif
+                    const float tot = sacc[sp][d] * scale;
+                    if (tot != 0.f) unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[sp] + d, tot);
+                }
+            }
+        }
+#endif
     }
-    if (LAB_VARIANT != 0 && LAB_VARIANT != 4) sink_out[(int64_t)tile * 64 + lane] = sink;
+    if (LAB_VARIANT != 0 && LAB_VARIANT < 4) sink_out[(int64_t)tile * 64 + lane] = sink;
 }
 
 } // namespace adk

@@ -16,8 +16,9 @@ def agg(path):
     return {k: {n: v / c[k][n] for n, v in d.items()} for k, d in a.items()}
 
 
-f, w, s = (agg(p + "/b_counter_collection.csv") for p in sys.argv[1:4])
-print("# per-launch means; FETCH_SIZE/WRITE_SIZE in KB (separate --pmc passes), SQ/GRBM counters in millions")
-for k in sorted(s):
+if __name__ == "__main__":
+  f, w, s = (agg(p + "/b_counter_collection.csv") for p in sys.argv[1:4])
+  print("# per-launch means; FETCH_SIZE/WRITE_SIZE in KB (separate --pmc passes), SQ/GRBM counters in millions")
+  for k in sorted(s):
     sq = "  ".join("%s=%.1f" % (n.replace("SQ_", ""), v / 1e6) for n, v in sorted(s[k].items()))
     print("%-44s FETCH_KB=%9.0f WRITE_KB=%9.0f  %s" % (k, f.get(k, {}).get("FETCH_SIZE", 0), w.get(k, {}).get("WRITE_SIZE", 0), sq))
