@@ -213,6 +213,14 @@ static __global__ __launch_bounds__(RS_BLOCK) void radix_scatter_staged_kernel(
     }
 }
 
+// MEASURED DEAD END (round 2, MI355X): a ONESWEEP form of the pass -- one upfront histogram kernel for the digit totals of all
+// passes, then ONE launch per pass in which every workgroup takes a ticket, publishes its 256 digit counts and obtains its
+// per-digit prefix by decoupled look-back over its predecessors' status words (agent-scope atomics, one thread per digit) --
+// was bit-identical and much slower: 1 M-key depth sort 0.12 -> 1.97 ms with a one-word-at-a-time walk, 0.42 ms with 8 words
+// in flight per round; 3.8 M-key tile sort 0.15 -> 0.46 ms.  The lists are small (512-928 co-resident workgroups that all
+// start together), so nothing hides the chain of cross-XCD round trips (~1 us each) the look-back needs before the first
+// inclusive prefixes exist; three dependent launches (~3-5 us gaps) cost less.  Removed again; see git history.
+
 // Scratch needed by one radix sort over n items: histogram table + digit totals.
 static inline int64_t radix_scratch_bytes(int64_t n) {
     const int64_t nb = ceil_div(n > 0 ? n : 1, RS_BLOCK * 8); // the smaller chunk bounds the table size
