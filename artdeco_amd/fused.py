@@ -153,7 +153,7 @@ def _render_raw(self, width: int, height: int, view_matrix: torch.Tensor):
                         sh_degree=self.active_sh_degree, eps2d=eps2d, sh_rest=P["f_rest"]["val"])
     col4, alphas, radii = out[0], out[1], out[2]
     vis, gvis = visibility_masks(radii, P["cls_id"]["val"], P["global_feat"]["val"].shape[0])
-    return col4, alphas, scaling, vis, gvis
+    return col4, alphas, scaling, vis, gvis, sel
 
 
 def fused_render(self, width: int, height: int, view_matrix: torch.Tensor, bg: torch.Tensor | None = None):
@@ -164,7 +164,11 @@ def fused_render(self, width: int, height: int, view_matrix: torch.Tensor, bg: t
     if lock is not None:
         lock.acquire()
     try:
-        col4, alphas, scaling, visible_mask, global_visible_mask = _render_raw(self, width, height, view_matrix)
+        col4, alphas, scaling, visible_mask, global_visible_mask, sel = _render_raw(self, width, height, view_matrix)
+        if getattr(self, "scaling_reg_factor", 0) != 0:
+            # the reference's "scale" has one row per LoD-SELECTED Gaussian (h3dgsv3.py:660,699) and its regulariser
+            # averages over exactly those (:443); only materialised when the regulariser is on (boolean index = host sync)
+            scaling = scaling[sel.bool()]
         rendered_alpha = alphas.permute(2, 0, 1)
         rendered_color = col4[..., 0:3].permute(2, 0, 1) + (1.0 - rendered_alpha) * bg[:, None, None]
         invdepth = 1.0 / col4[..., 3:4].permute(2, 0, 1)
@@ -222,7 +226,10 @@ def fused_render_from_id(self, keyframe_id, pyr_lvl=0, bg=None):
 
 def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
     """Drop-in body for SparseGaussianAdam.step (Reconstruct/scene/optimizers.py:77-161): the same updates, the
-    same learning-rate decay, one kernel launch (adk_adam_update_multi) and no boolean-index host sync."""
+    same learning-rate decay, one kernel launch (adk_adam_update_multi) and no boolean-index host sync.
+    One documented difference: the floor of a per-element learning rate (`clamp_min_(lr_init * 0.1)`, optimizers.py:134)
+    is applied to the rows that were decayed (the visible ones); the reference clamps every row, which is a no-op on rows
+    that were never decayed below the floor -- i.e. identical unless a caller pre-loads rates below the floor."""
     import ctypes
     lib = _lib.load()
     skip = ("id", "cls_id", "d_max")
@@ -244,6 +251,20 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
             continue
         vis, n = (global_visibility, N_global) if key == "global_feat" else (visibility, N)
         lr = pd["lr"]
+        # the same normalisation dropin.adamUpdate applies: the kernel reads raw pointers
+        _lib.require_cuda(vis, lr)
+        if vis.dtype != torch.bool or not vis.is_contiguous():
+            vis = vis.bool().contiguous()
+            keep.append(vis)
+        if vis.numel() != int(n):
+            raise _lib.AdkError(f"fused optimizer step: visibility mask of {key} has {vis.numel()} entries, expected {int(n)}")
+        if lr.dtype != torch.float32 or not lr.is_contiguous():
+            if lr.numel() != 1 and key in self.lr_dict:
+                raise _lib.AdkError(f"fused optimizer step: per-element learning rate of {key} must be contiguous float32 (it is updated in place)")
+            lr = lr.float().contiguous()
+            keep.append(lr)
+        if lr.numel() not in (1, int(n), val.numel()):
+            raise _lib.AdkError(f"fused optimizer step: learning rate of {key} has {lr.numel()} elements")
         decay, lr_min = 1.0, 0.0
         if key in self.lr_dict:
             decay, lr_min = float(self.lr_dict[key]["lr_decay"]), float(self.lr_dict[key]["lr_init"] * 0.1)
@@ -443,7 +464,7 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     if lock is not None:
         lock.acquire()
     try:
-        col4, alphas, scaling, vis, gvis = _render_raw(self, width, height, view_matrix)
+        col4, alphas, scaling, vis, gvis, sel = _render_raw(self, width, height, view_matrix)
     finally:
         if lock is not None:
             lock.release()
@@ -453,7 +474,10 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     loss, _image, invdepth, _parts = FusedMapperLoss.apply(col4, alphas, keyframe.exposure, bg, gt_image, mono_idepth, rdk,
                                                            self.lambda_dssim, keyframe.depth_loss_weight, not is_important)
     if self.scaling_reg_factor != 0:
-        loss = loss + self.scaling_reg_factor * scaling.prod(dim=1).mean()
+        # mean over the LoD-selected rows only, as the reference's scale.prod(dim=1).mean() over scaling[selection_mask]
+        # (h3dgsv3.py:443,660); unselected rows of the fused [N,3] tensor hold 1 and must not enter the average
+        selw = sel.to(scaling.dtype)
+        loss = loss + self.scaling_reg_factor * (scaling.prod(dim=1) * selw).sum() / selw.sum().clamp_min(1.0)
     # the SH colours (48 of the 75 floats of a Gaussian) take their Adam step inside the projection backward, on
     # exactly the rows optimizer.step would touch (radii > 0); their .grad stays None and the step below skips them
     with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
@@ -513,25 +537,25 @@ def fused_add_and_prune(self, extension_tensors, valid_mask):
     if mask.dtype != torch.bool or mask.numel() != N:
         raise ValueError("valid_mask must be a bool tensor with one entry per Gaussian")
     E = None
-    jobs = []  # (dict to store into, key in that dict, src tensor, ext tensor or None, fill bits, requires_grad)
+    jobs = []  # (dict to store into, key in that dict, src tensor, ext tensor or None, fill bits, requires_grad, rows appended)
     for key in keys:
         param, ext = self.params[key], extension_tensors[key]
         has_ext = not (ext.numel() == 0 or ext.dim() == 0)
+        e_key = ext.shape[0] if has_ext else 0   # a key's moments / lr grow by ITS OWN extension rows (optimizers.py:205-219)
         if has_ext:
             if E is None:
-                E = ext.shape[0]
-            elif ext.shape[0] != E:
+                E = e_key
+            elif e_key != E:
                 raise ValueError("extension tensors must all add the same number of rows")
         meta_only = key in ("id", "cls_id", "d_max")
-        jobs.append((param, "val", param["val"].detach(), ext if has_ext else None, 0, not meta_only))
+        jobs.append((param, "val", param["val"].detach(), ext if has_ext else None, 0, not meta_only, e_key))
         if meta_only:
             continue
-        jobs.append((param, "exp_avg", param["exp_avg"], None, 0, False))
-        jobs.append((param, "exp_avg_sq", param["exp_avg_sq"], None, 0, False))
+        jobs.append((param, "exp_avg", param["exp_avg"], None, 0, False, e_key))
+        jobs.append((param, "exp_avg_sq", param["exp_avg_sq"], None, 0, False, e_key))
         if key in self.lr_dict:
             bits = struct.unpack("<I", struct.pack("<f", float(self.lr_dict[key]["lr_init"])))[0]
-            jobs.append((param, "lr", param["lr"], None, bits, False))
-    E = E or 0
+            jobs.append((param, "lr", param["lr"], None, bits, False, e_key))
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream(dev).cuda_stream
         ws = torch.empty(int(lib.adk_compact_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -539,7 +563,7 @@ def fused_add_and_prune(self, extension_tensors, valid_mask):
         _lib.check(lib.adk_compact_plan(N, mask.data_ptr(), n_keep_dev.data_ptr(), ws.data_ptr(), ws.numel(), st), "adk_compact_plan")
         K = int(n_keep_dev.item())  # the one host read: sizes every output
         srcs, exts, dsts, fills, words, outs = [], [], [], [], [], []
-        for store, name, src, ext, bits, _rg in jobs:
+        for store, name, src, ext, bits, _rg, n_app in jobs:
             src = src.contiguous()
             if src.shape[0] != N or src.element_size() not in (4, 8):
                 raise ValueError(f"add_and_prune: unexpected tensor for {name}: shape {tuple(src.shape)}, dtype {src.dtype}")
@@ -549,11 +573,9 @@ def fused_add_and_prune(self, extension_tensors, valid_mask):
                 e = ext.to(device=dev, dtype=src.dtype).contiguous()
                 if e.shape[1:] != src.shape[1:]:
                     raise ValueError("extension tensor does not match the parameter's row shape")
-            # appended rows of a tensor without an extension (moments, lr) exist only when some parameter is extended
-            n_app = E if (e is not None or name != "val") else 0
             out = torch.empty((K + n_app,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
             srcs.append(src); exts.append(e); dsts.append(out); fills.append(bits); words.append(max(row_words, 1)); outs.append((store, name, out, _rg, n_app))
-        # tensors that append nothing take part with E = 0 in a second call; the common case is a single call
+        # keys with an empty extension take part with 0 appended rows in a second call; the common case is a single call
         for group_E in sorted({o[4] for o in outs}, reverse=True):
             idx = [i for i, o in enumerate(outs) if o[4] == group_E]
             n = len(idx)
@@ -595,6 +617,16 @@ def fused_weed_out_gaussians(self):
     self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
 
 
+def _patch_optimizer(opt) -> None:
+    if opt is None or not (hasattr(opt, "lr_dict") and hasattr(opt, "params")) or hasattr(opt, "_unfused_step"):
+        return
+    opt._unfused_step = opt.step
+    opt.step = types.MethodType(fused_optimizer_step, opt)
+    if hasattr(opt, "add_and_prune"):
+        opt._unfused_add_and_prune = opt.add_and_prune
+        opt.add_and_prune = types.MethodType(fused_add_and_prune, opt)
+
+
 def patch_scene_model(scene) -> bool:
     """Install fused_render on this scene-model instance (ARTDECO's SceneModel or harness.mapper.MapperScene).
     Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
@@ -605,13 +637,17 @@ def patch_scene_model(scene) -> bool:
     if hasattr(scene, "render_from_id"):
         scene._unfused_render_from_id = scene.render_from_id
         scene.render_from_id = types.MethodType(fused_render_from_id, scene)
-    opt = getattr(scene, "optimizer", None)
-    if opt is not None and hasattr(opt, "lr_dict") and hasattr(opt, "params"):
-        opt._unfused_step = opt.step
-        opt.step = types.MethodType(fused_optimizer_step, opt)
-        if hasattr(opt, "add_and_prune"):
-            opt._unfused_add_and_prune = opt.add_and_prune
-            opt.add_and_prune = types.MethodType(fused_add_and_prune, opt)
+    _patch_optimizer(getattr(scene, "optimizer", None))
+    if hasattr(scene, "reset_optimizer") and not hasattr(scene, "_unfused_reset_optimizer"):
+        # SceneModel.reset_optimizer builds a NEW SparseGaussianAdam (h3dgsv3.py:317-330, called at the start of every
+        # finetune epoch, :1234): patch the replacement as well, or the fused step silently disappears
+        scene._unfused_reset_optimizer = scene.reset_optimizer
+
+        def _reset_and_repatch(self, *a, **kw):
+            r = self._unfused_reset_optimizer(*a, **kw)
+            _patch_optimizer(getattr(self, "optimizer", None))
+            return r
+        scene.reset_optimizer = types.MethodType(_reset_and_repatch, scene)
     if hasattr(scene, "optimization_step") and hasattr(scene, "lambda_dssim") and hasattr(scene, "rad_decay"):
         scene._unfused_optimization_step = scene.optimization_step
         body = fused_optimization_step if hasattr(scene, "get_training_id") else fused_optimization_step_mirror

@@ -242,6 +242,16 @@ class MapperScene:
     def add_keyframe(self, kf: Keyframe):
         self.keyframes.append(kf)
 
+    def reset_optimizer(self):
+        """h3dgsv3.py:317-330: a NEW SparseGaussianAdam over the current parameters (called at the start of every finetune epoch)."""
+        for key, pd in self.gaussian_params.items():
+            if key in _NO_OPT:
+                continue
+            if not pd["val"].requires_grad:
+                pd["val"].requires_grad = True
+        self.optimizer = SparseGaussianAdam({**self.gaussian_params, **self.mlp_params}, (0.5, 0.99), lr_dict=self.lr_dict,
+                                            device=self.device)
+
     # -- reference-named accessors (h3dgsv3.py:332-372) --------------------------------------------
     xyz = property(lambda s: s.gaussian_params["xyz"]["val"])
     f_dc = property(lambda s: s.gaussian_params["f_dc"]["val"])

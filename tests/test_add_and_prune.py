@@ -71,6 +71,28 @@ def test_fused_add_and_prune_matches_torch(N, E, keep_frac, dev):
 
 
 @pytest.mark.gpu
+def test_fused_add_and_prune_with_one_empty_extension(dev):
+    """A key whose extension is empty while the others add rows: its moments must grow by ITS OWN (zero) rows, exactly as
+    optimizers.py:205-219 (`zeros_like(extension_tensors[key])`) does -- not by the rows of the first non-empty key."""
+    from artdeco_amd import fused
+    from harness import mapper
+    N, E = 2_000, 300
+    ref = _optimizer(dev, N, 64, seed=5)
+    got = _clone(ref)
+    mask = (torch.rand(N, generator=torch.Generator().manual_seed(9)) < 0.7).to(dev)
+    ext = _extension(dev, E, 0, seed=3, keys=tuple(k for k in ALL if k != "global_feat"))
+    ext["local_feat"] = ext["local_feat"][:0]   # this key adds nothing
+    with torch.no_grad():
+        mapper._add_and_prune(ref, ext, mask)
+        fused.fused_add_and_prune(got, ext, mask)
+    for k in ref.params:
+        for n, t in ref.params[k].items():
+            if torch.is_tensor(t):
+                assert got.params[k][n].shape == t.shape and torch.equal(got.params[k][n], t), (k, n)
+    assert got.params["local_feat"]["exp_avg"].shape[0] == got.params["local_feat"]["val"].shape[0] == int(mask.sum())
+
+
+@pytest.mark.gpu
 def test_patch_installs_add_and_prune(dev):
     from artdeco_amd import fused
     from tests.test_fused_glue import _scene

@@ -142,3 +142,22 @@ def test_base_adam_matches_the_reference_class(both):
         _same(Pa, Pb)
     A.zero_grad(); B.zero_grad()
     assert all(p["val"].grad is None for p in Pa.values()) and all(p["val"].grad is None for p in Pb.values())
+
+
+def test_patch_survives_reset_optimizer():
+    """SceneModel.reset_optimizer (h3dgsv3.py:317-330, start of every finetune epoch) REPLACES the optimiser object; the fused
+    step / add_and_prune installed by patch_scene_model must be installed on the replacement too (method swaps only: no GPU)."""
+    import types
+    from artdeco_amd import fused
+    from harness import mapper
+    sc = mapper.MapperScene(64, 48, 50.0, "cpu")
+    c = mapper.synthetic_cloud(50, 64, 48, 0)
+    sc.set_gaussians(c["means"], c["quats"], torch.log(c["scales"]), torch.zeros(50), c["sh"])
+    assert fused.patch_scene_model(sc)
+    first = sc.optimizer
+    assert first.step.__func__ is fused.fused_optimizer_step
+    sc.reset_optimizer()
+    assert sc.optimizer is not first
+    assert sc.optimizer.step.__func__ is fused.fused_optimizer_step
+    assert sc.optimizer.add_and_prune.__func__ is fused.fused_add_and_prune
+    assert isinstance(sc.reset_optimizer, types.MethodType)
