@@ -12,6 +12,9 @@ from __future__ import annotations
 import torch
 
 from artdeco_amd import _lib
+from artdeco_amd import autoinstall as _autoinstall
+
+_autoinstall.on_dropin_import()  # post-import hook: fused mapper paths on every SceneModel (ARTDECO_AMD_AUTOFUSE=0 disables)
 
 from ._rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401
 

@@ -13,6 +13,9 @@ from __future__ import annotations
 import torch
 
 from artdeco_amd import _lib
+from artdeco_amd import autoinstall as _autoinstall
+
+_autoinstall.on_dropin_import()  # post-import hook: fused mapper paths on every SceneModel (ARTDECO_AMD_AUTOFUSE=0 disables)
 
 allowed_padding = ["same", "valid"]
 _C1, _C2 = 0.01 ** 2, 0.03 ** 2   # (k1 L)^2, (k2 L)^2 with L = 1, the constants the reference passes

@@ -10,6 +10,9 @@ Only what the reference uses is implemented: 1-D `src`/`index`, no preallocated 
 import torch
 
 from artdeco_amd import _lib
+from artdeco_amd import autoinstall as _autoinstall
+
+_autoinstall.on_dropin_import()  # post-import hook: fused mapper paths on every SceneModel (ARTDECO_AMD_AUTOFUSE=0 disables)
 
 _DTYPES = {torch.float32: 0, torch.int32: 1, torch.int64: 2}
 
