@@ -35,7 +35,8 @@ EXTRA_FLAGS = {
     "raster_project.hip": ["-ffp-contract=off"],
     "matching.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],
-    "tracker.hip": ["-ffp-contract=off"],  # same arithmetic as the host-compiled test harness (tests/host/)
+    "tracker.hip": ["-ffp-contract=off"],
+    "voxel.hip": ["-ffp-contract=off"],    # voxel indices are floor((p - min) / size): integer-deciding fp32 chain  # same arithmetic as the host-compiled test harness (tests/host/)
 }
 
 

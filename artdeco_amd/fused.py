@@ -617,6 +617,49 @@ def fused_weed_out_gaussians(self):
     self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
 
 
+def update_voxel_device(new_xyz: torch.Tensor, xyz: torch.Tensor, cls_id: torch.Tensor, voxel_size: float = 0.1, reciprocal: bool = True):
+    """SceneModel.update_voxel (h3dgsv3.py:227-316) on the device: the same three results -- (updated_orig_cls_id [N,1] int64,
+    updated_new_cls_id [M,1] int64, new_voxel_count: int) -- or, with no old points (the cold start, :244-255),
+    (new_cls_id [M,1] int64, voxel_count: int).  Two small host reads (grid extents, the count) instead of the
+    reference's six-plus synchronising torch.unique / .item() / boolean-mask operations.
+    reciprocal: round `(p - min) / voxel_size` the way torch's GPU kernel does (multiply by the fp32 reciprocal; default, it is
+    GPU code that is being replaced) or with a true division like torch's CPU kernel (what the CPU-generated goldens used)."""
+    lib = _lib.load()
+    _lib.require_cuda(new_xyz)
+    dev = new_xyz.device
+    M, N = new_xyz.shape[0], (xyz.shape[0] if xyz is not None else 0)
+    if M == 0 and N == 0:
+        raise ValueError("update_voxel needs at least one point")
+    f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+    nx_, ox_ = f(new_xyz), (f(xyz) if N else None)
+    cls = cls_id.detach().reshape(-1).to(dev, torch.int64).contiguous() if N else None
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        minc = torch.empty(3, dtype=torch.float32, device=dev)
+        info = torch.empty(4, dtype=torch.int64, device=dev)
+        small = torch.empty(64, dtype=torch.uint8, device=dev)
+        _lib.check(lib.adk_voxel_bounds(_lib.ptr(ox_), N, nx_.data_ptr() if M else None, M, _lib.ptr(cls), float(voxel_size), int(bool(reciprocal)), minc.data_ptr(),
+                                        info.data_ptr(), small.data_ptr(), small.numel(), st), "adk_voxel_bounds")
+        gx, gy, gz, max_cls = (int(v) for v in info.tolist())      # host read 1: decides the number of radix passes
+        upd_o = torch.empty(N, dtype=torch.int64, device=dev)
+        upd_n = torch.empty(M, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        ws = _WS.get(dev, int(lib.adk_voxel_workspace_bytes(N, M)) + 256)
+        base = (ws.data_ptr() + 255) & ~255
+        _lib.check(lib.adk_voxel_assign(_lib.ptr(ox_), N, nx_.data_ptr() if M else None, M, _lib.ptr(cls), float(voxel_size), int(bool(reciprocal)), minc.data_ptr(),
+                                        gx, gy, gz, max_cls, upd_o.data_ptr() if N else None, upd_n.data_ptr() if M else None,
+                                        count.data_ptr(), base, ws.numel() - (base - ws.data_ptr()), st), "adk_voxel_assign")
+        n_new = int(count.item())                                    # host read 2: sizes global_feat (h3dgsv3.py:888)
+    if N == 0:
+        return upd_n.unsqueeze(-1), n_new
+    return upd_o.unsqueeze(-1), upd_n.unsqueeze(-1), n_new
+
+
+def fused_update_voxel(self, new_xyz, xyz, cls_id, voxel_size=0.1):
+    """Drop-in body for SceneModel.update_voxel."""
+    return update_voxel_device(new_xyz, xyz, cls_id, voxel_size)
+
+
 def _patch_optimizer(opt) -> None:
     if opt is None or not (hasattr(opt, "lr_dict") and hasattr(opt, "params")) or hasattr(opt, "_unfused_step"):
         return
@@ -652,6 +695,9 @@ def patch_scene_model(scene) -> bool:
         scene._unfused_optimization_step = scene.optimization_step
         body = fused_optimization_step if hasattr(scene, "get_training_id") else fused_optimization_step_mirror
         scene.optimization_step = types.MethodType(body, scene)
+    if hasattr(scene, "update_voxel"):
+        scene._unfused_update_voxel = scene.update_voxel
+        scene.update_voxel = types.MethodType(fused_update_voxel, scene)
     if hasattr(scene, "weed_out_gaussians") and hasattr(scene, "make_dummy_ext_tensor"):
         scene._unfused_weed_out_gaussians = scene.weed_out_gaussians
         scene.weed_out_gaussians = types.MethodType(fused_weed_out_gaussians, scene)

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 4
+#define ADK_ABI_VERSION 5
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -323,6 +323,26 @@ int adk_visibility_masks(int N, const int* radii, const int64_t* cls_id, int64_t
  * arg = n.  dtype 0 = float32, 1 = int32, 2 = int64 (src and out); index int64; arg int64. */
 int adk_scatter_argmax(int64_t n, const void* src, int dtype, const int64_t* index, int64_t dim_size,
                        int is_min, void* out, int64_t* arg, adk_stream_t stream);
+
+/* ------------------------------------------------ SceneModel.update_voxel
+ * Replaces the torch chain of Reconstruct/scene/scene_models/h3dgsv3.py:227-316 (voxel hash, 3x torch.unique,
+ * scatter_max majority vote, searchsorted, boolean-mask writes), called per LoD level at :884-887.
+ * Stage 1 -- adk_voxel_bounds: minc [3] float = componentwise minimum of old ++ new points (:262-263), info [4] int64 =
+ * grid extents nx, ny, nz (:267) and max(cls_id) (:258; -1 when N = 0); workspace >= 64 bytes.  The caller reads `info`
+ * (it decides the number of radix passes) and passes it back to
+ * Stage 2 -- adk_voxel_assign: updated_orig [N] / updated_new [M] int64 and *new_voxel_count (int64, device), exactly the
+ * method's three results (two with N = 0, the cold start of :244-255).  xyz [N,3], new_xyz [M,3] float, cls_id [N] int64.
+ * use_reciprocal selects how `(p - min) / voxel_size` (:266) is rounded: 0 = true fp32 division (torch's CPU kernel), 1 =
+ * multiplication by the fp32 reciprocal (torch's GPU kernel for tensor / python-float, i.e. what the reference computes
+ * where it actually runs); the two differ in the last bit for ~1e-7 of the coordinates. */
+int adk_voxel_bounds(const float* xyz, int64_t N, const float* new_xyz, int64_t M, const int64_t* cls_id,
+                     float voxel_size, int use_reciprocal, float* minc, int64_t* info, void* workspace, int64_t workspace_bytes,
+                     adk_stream_t stream);
+int64_t adk_voxel_workspace_bytes(int64_t N, int64_t M);
+int adk_voxel_assign(const float* xyz, int64_t N, const float* new_xyz, int64_t M, const int64_t* cls_id,
+                     float voxel_size, int use_reciprocal, const float* minc, int64_t nx, int64_t ny, int64_t nz, int64_t max_cls,
+                     int64_t* updated_orig, int64_t* updated_new, int64_t* new_voxel_count, void* workspace,
+                     int64_t workspace_bytes, adk_stream_t stream);
 
 /* ------------------------------------------- mast3r_slam_backends: Gauss-Newton
  * Replaces gauss_newton_points / gauss_newton_rays / gauss_newton_calib --

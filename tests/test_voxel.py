@@ -1,6 +1,6 @@
 """SceneModel.update_voxel (densification path): the numpy oracle against goldens produced by the REFERENCE's
-own method source executed on CPU (tests/golden/make_golden_voxel.py).  The device path for this function is not built yet;
-this pins the restatement it will be checked against."""
+own method source executed on CPU (tests/golden/make_golden_voxel.py), and the DEVICE path (artdeco_amd/csrc/voxel.hip through
+artdeco_amd.fused.update_voxel_device) against the same goldens and, at 1 M + 50 k points, against the oracle -- bit for bit."""
 import importlib.util
 import os
 
@@ -33,3 +33,58 @@ def test_majority_vote_ties_take_the_smallest_class():
     new = np.array([[0.05, 0.05, 0.05], [5.0, 5.0, 5.0]], np.float32)
     orig, upd, count = voxel_oracle.update_voxel(new, xyz, cls, 0.1)
     assert (orig == 3).all() and upd[0, 0] == 3 and upd[1, 0] == 8 and count == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_update_voxel_matches_reference_goldens(name, dev):
+    import torch
+    from artdeco_amd import fused
+    new, xyz, cls, vs = CASES[name]
+    d = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    res = fused.update_voxel_device(torch.from_numpy(new).to(dev), torch.from_numpy(xyz).to(dev), torch.from_numpy(cls).to(dev), vs,
+                                    reciprocal=False)   # the goldens are the reference's CPU execution: true division
+    assert len(res) == sum(1 for k in d.files if k.startswith("out"))
+    for i, r in enumerate(res):
+        got = r.cpu().numpy() if hasattr(r, "cpu") else np.int64(r)
+        assert np.array_equal(got, d[f"out{i}"]), (name, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("recip", [False, True])
+@pytest.mark.parametrize("N,M,vs,wide", [(1_000_000, 50_000, 0.1, False), (300_000, 20_000, 0.004, True), (5_000, 0, 0.2, False)])
+def test_device_update_voxel_matches_oracle_at_map_size(N, M, vs, wide, recip, dev):
+    """Map-sized inputs (1 M Gaussians + 50 k new points per LoD level) and a grid fine enough for hashes above 2^32 (two-word
+    radix sort), against the golden-pinned oracle."""
+    import torch
+    from artdeco_amd import fused
+    rng = np.random.default_rng(N + M)
+    span = 40.0 if wide else 6.0
+    centres = rng.uniform(-span, span, (400, 3))
+    pts = lambda k: (centres[rng.integers(0, 400, k)] + 0.4 * rng.standard_normal((k, 3))).astype(np.float32)
+    xyz, new = pts(N), pts(M) + np.float32(0.05)
+    cls = rng.integers(0, max(N // 10, 1), (N, 1)).astype(np.int64)
+    ro, rn, rc = voxel_oracle.update_voxel(new, xyz, cls, vs, reciprocal=recip)
+    go, gn, gc = fused.update_voxel_device(torch.from_numpy(new).to(dev), torch.from_numpy(xyz).to(dev), torch.from_numpy(cls).to(dev), vs,
+                                           reciprocal=recip)
+    assert gc == rc
+    assert np.array_equal(go.cpu().numpy(), ro) and np.array_equal(gn.cpu().numpy(), rn)
+
+
+@pytest.mark.gpu
+def test_device_update_voxel_equals_the_torch_chain_on_the_gpu(dev):
+    """The reference's own sequence of torch operations (h3dgsv3.py:227-316, restated in tools/bench_update_voxel.py) executed
+    by torch ON THE GPU -- division by the voxel size as torch's GPU kernel rounds it -- gives the device path's results."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from bench_update_voxel import torch_chain
+    from artdeco_amd import fused
+    new, xyz, cls, vs = CASES["voxel_mixed"]
+    rng = np.random.default_rng(5)
+    xyz = np.concatenate([xyz, (rng.uniform(-3, 3, (200_000, 3))).astype(np.float32)])
+    cls = np.concatenate([cls, rng.integers(0, 5000, (200_000, 1)).astype(np.int64)])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    a = torch_chain(t(new), t(xyz), t(cls), vs)
+    b = fused.update_voxel_device(t(new), t(xyz), t(cls), vs)
+    assert a[2] == b[2] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
