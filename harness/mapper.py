@@ -222,7 +222,9 @@ class MapperScene:
         N = means.shape[0]
         n_vox = n_voxels or max(1, N // 8)
         g = torch.Generator().manual_seed(seed)
-        val = lambda t: t.to(dev).contiguous().requires_grad_(True)
+        # detach + clone: a caller's tensor must never BECOME the parameter (on the same device .to() returns the tensor
+        # itself, so two scenes built from one cloud would share -- and the second would get a non-leaf -- parameters)
+        val = lambda t: t.detach().clone().to(dev).contiguous().requires_grad_(True)
         P = self.gaussian_params = {
             "cls_id": {"val": torch.randint(0, n_vox, (N, 1), generator=g).to(dev)},
             "d_max": {"val": torch.full((N, 1), float(d_max), device=dev)},
