@@ -85,7 +85,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        return self.fc2(self.act(self.fc1(x.to(self.fc1.weight.dtype))))
 
 
 class Attention(nn.Module):
@@ -98,7 +98,7 @@ class Attention(nn.Module):
 
     def forward(self, x, xpos):
         B, N, C = x.shape
-        qkv5 = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
+        qkv5 = self.qkv(x.to(self.qkv.weight.dtype)).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         # q and k are adjacent [H,D] slabs of every token: rotate both with ONE in-place rope launch over 2H "heads"
         if not self.rope.rotate_qk_inplace(qkv5, xpos):
             qkv = qkv5.transpose(1, 3)
@@ -123,6 +123,8 @@ class CrossAttention(nn.Module):
     def forward(self, query, key, value, qpos, kpos):
         B, Nq, C = query.shape
         H, D = self.num_heads, C // self.num_heads
+        wd = self.projq.weight.dtype
+        query, key, value = query.to(wd), key.to(wd), value.to(wd)
         q = self.projq(query).reshape(B, Nq, H, D).permute(0, 2, 1, 3)
         k = self.projk(key).reshape(B, key.shape[1], H, D).permute(0, 2, 1, 3)
         v = self.projv(value).reshape(B, value.shape[1], H, D).permute(0, 2, 1, 3)
@@ -170,11 +172,18 @@ class PatchEmbed(nn.Module):
         self.norm = nn.Identity()
 
     def forward(self, x, true_shape=None):
-        x = self.proj(x)
-        B, _, h, w = x.shape
+        # A stride-P PxP convolution IS a GEMM over non-overlapping patches: [B h w, 3 P P] x [3 P P, D].  As a Conv2d in
+        # fp16 MIOpen's immediate mode fell back to `naive_conv_ab_nonpacked_fwd_nchw_half_double_half`, 1.07 ms per image
+        # (profiles/r02_frontend_kernel_stats_tf32eq.csv); as a Linear it is one hipBLASLt call.  Same parameters
+        # (proj.weight [D,3,P,P], proj.bias), same arithmetic.
+        B, C, H, W = x.shape
+        P = self.patch_size[0]
+        h, w = H // P, W // P
+        patches = x.reshape(B, C, h, P, w, P).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, C * P * P)
+        tokens = F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
         ys, xs = torch.arange(h, device=x.device), torch.arange(w, device=x.device)
         pos = torch.cartesian_prod(ys, xs).view(1, h * w, 2).expand(B, -1, 2).clone()
-        return x.flatten(2).transpose(1, 2), pos
+        return tokens, pos
 
 
 # ------------------------------------------------------------------------------------------ DPT head
@@ -245,7 +254,8 @@ class DPTOutputAdapter(nn.Module):
     def forward(self, tokens: List[torch.Tensor], image_size):
         H, W = image_size
         nh, nw = H // self.P, W // self.P
-        layers = [tokens[h] for h in self.hooks]
+        wd = self.head[0].weight.dtype
+        layers = [tokens[h].to(wd) for h in self.hooks]
         layers = [l.transpose(1, 2).reshape(l.shape[0], l.shape[2], nh, nw) for l in layers]
         layers = [self.act_postprocess[i](l) for i, l in enumerate(layers)]
         layers = [self.scratch.layer_rn[i](l) for i, l in enumerate(layers)]
@@ -294,10 +304,10 @@ class CatMlpDptHead(nn.Module):
 
     def forward(self, decout, img_shape):
         H, W = int(img_shape[0]), int(img_shape[1])
-        pts3d = self.dpt(decout, (H, W))
+        pts3d = self.dpt(decout, (H, W)).float()
         cat = torch.cat([decout[0], decout[-1]], dim=-1)
         B = cat.shape[0]
-        lf = self.head_local_features(cat).transpose(-1, -2).reshape(B, -1, H // self.patch_size, W // self.patch_size)
+        lf = self.head_local_features(cat).float().transpose(-1, -2).reshape(B, -1, H // self.patch_size, W // self.patch_size)
         lf = F.pixel_shuffle(lf, self.patch_size)
         fmap = torch.cat([pts3d, lf], dim=1).permute(0, 2, 3, 1)
         res = {"pts3d": reg_dense_depth(fmap[..., 0:3], self.depth_mode)}
@@ -350,35 +360,100 @@ class AsymmetricMASt3R(nn.Module):
         return super().load_state_dict(ckpt, **kw)
 
     def _encode_image(self, image, true_shape=None):
-        x, pos = self.patch_embed(image, true_shape)
+        x, pos = self.patch_embed(image.to(self.patch_embed.proj.weight.dtype), true_shape)
+        if getattr(self, "_fp32_stream", False):
+            x = x.float()   # the residual stream, the LayerNorms and the softmax stay fp32; only GEMM operands are narrow
         for blk in self.enc_blocks:
             x = blk(x, pos)
         return self.enc_norm(x), pos, None
 
     def _decoder(self, f1, pos1, f2, pos2):
         final = [(f1, f2)]
-        f1, f2 = self.decoder_embed(f1), self.decoder_embed(f2)
+        wd = self.decoder_embed.weight.dtype
+        f1, f2 = self.decoder_embed(f1.to(wd)), self.decoder_embed(f2.to(wd))
+        if getattr(self, "_fp32_stream", False):
+            f1, f2 = f1.float(), f2.float()
         final.append((f1, f2))
+        side = self._side_stream(f1)
         for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
             a, b = final[-1]
-            n1, _ = blk1(a, b, pos1, pos2)
-            n2, _ = blk2(b, a, pos2, pos1)
+            if side is None:
+                n1, _ = blk1(a, b, pos1, pos2)
+                n2, _ = blk2(b, a, pos2, pos1)
+            else:
+                # the two branches of a decoder level are independent (dust3r/model.py:181-186) and each is a chain of small
+                # launches at 768 tokens that leaves most of the chip idle: run them on two HIP streams
+                main = torch.cuda.current_stream(a.device)
+                side.wait_stream(main)
+                n1, _ = blk1(a, b, pos1, pos2)
+                with torch.cuda.stream(side):
+                    n2, _ = blk2(b, a, pos2, pos1)
+                main.wait_stream(side)
+                n2.record_stream(main)
             final.append((n1, n2))
         del final[1]
         final[-1] = (self.dec_norm(final[-1][0]), self.dec_norm(final[-1][1]))
         return zip(*final)
+
+    def _side_stream(self, t):
+        """Second HIP stream for the independent halves of the decoder / the two heads (GPU only; ADK_MAST3R_STREAMS=0 disables)."""
+        import os
+        if not t.is_cuda or os.environ.get("ADK_MAST3R_STREAMS", "1") == "0":
+            return None
+        st = getattr(self, "_side", None)
+        if st is None or st.device != t.device:
+            st = self._side = torch.cuda.Stream(device=t.device)
+        return st
 
     def _downstream_head(self, head_num, decout, img_shape):
         head = self.downstream_head1 if head_num == 1 else self.downstream_head2
         shp = img_shape[0] if torch.is_tensor(img_shape) and img_shape.dim() == 2 else img_shape
         return head(decout, shp)
 
-    def to_inference_dtype(self, dtype):
+    def both_heads(self, dec1, dec2, shape1, shape2):
+        """head 1 on view 1's decoder tokens, head 2 on view 2's (dust3r/model.py:205-208): independent, so on the GPU they run
+        on two HIP streams."""
+        dec1, dec2 = [t.float() for t in dec1], [t.float() for t in dec2]
+        side = self._side_stream(dec1[0])
+        if side is None:
+            return self._downstream_head(1, dec1, shape1), self._downstream_head(2, dec2, shape2)
+        main = torch.cuda.current_stream(dec1[0].device)
+        side.wait_stream(main)
+        res1 = self._downstream_head(1, dec1, shape1)
+        with torch.cuda.stream(side):
+            res2 = self._downstream_head(2, dec2, shape2)
+        main.wait_stream(side)
+        for v in res2.values():
+            v.record_stream(main)
+        return res1, res2
+
+    def to_inference_dtype(self, dtype, fp32_stream=False, heads=False):
         """Cast encoder + decoders ONCE to bf16/fp16 (autocast would re-cast every weight on every call);
-        the heads stay fp32 like the reference (dust3r/model.py:205)."""
-        for m in (self.patch_embed, self.enc_blocks, self.enc_norm, self.decoder_embed, self.dec_blocks, self.dec_blocks2, self.dec_norm):
-            m.to(dtype)
-        self._trunk_dtype = dtype
+        the heads stay fp32 like the reference (dust3r/model.py:205).
+
+        fp32_stream=True is the TF32-CLASS mode: only the GEMM operands (Linear / patch-embedding weights and the
+        activations entering them) are narrowed -- fp16 has TF32's 10-bit mantissa -- while products accumulate in
+        fp32 on the matrix cores and the residual stream, every LayerNorm and the attention softmax stay fp32.  The
+        reference runs the model under `torch.backends.cuda.matmul.allow_tf32 = True` (run_system.py:73), i.e. with
+        10-bit GEMM operands; tools/frontend_precision.py measures this mode against an emulated TF32 forward."""
+        trunk = (self.patch_embed, self.enc_blocks, self.enc_norm, self.decoder_embed, self.dec_blocks, self.dec_blocks2, self.dec_norm)
+        if not fp32_stream:
+            for m in trunk:
+                m.to(dtype)
+            self._trunk_dtype = dtype
+            return self
+        for root in trunk:
+            for m in root.modules():
+                if isinstance(m, (nn.Linear, nn.Conv2d)):
+                    m.to(dtype)
+        self._trunk_dtype, self._fp32_stream = None, True
+        if heads:
+            # the reference's heads run "in fp32" (dust3r/model.py:205) -- under the same allow_tf32 setting, which applies to
+            # their convolutions and Linear layers as well (cudnn.allow_tf32 defaults to True): the same operand narrowing
+            for head in (self.downstream_head1, self.downstream_head2):
+                for m in head.modules():
+                    if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+                        m.to(dtype)
         return self
 
     @torch.inference_mode()
@@ -393,8 +468,7 @@ class AsymmetricMASt3R(nn.Module):
         feat2, pos2, _ = self._encode_image(img2, shape2)
         dec1, dec2 = self._decoder(feat1, pos1, feat2, pos2)
         with torch.autocast(device_type=img1.device.type, enabled=False):
-            res1 = self._downstream_head(1, [t.float() for t in dec1], shape1)
-            res2 = self._downstream_head(2, [t.float() for t in dec2], shape2)
+            res1, res2 = self.both_heads(dec1, dec2, shape1, shape2)
         res2["pts3d_in_other_view"] = res2.pop("pts3d")
         return res1, res2
 

@@ -3,7 +3,16 @@
 + iter_proj + refine_matches, on one MI355X (random-init weights: checkpoints are download-only), next to the
 PyTorch-CPU path of the same module on the host cores.  Prints one JSON line.
 
-    python bench_frontend.py [--iters 10] [--dtype bf16|fp32] [--cpu-baseline]
+    python bench_frontend.py [--iters 10] [--dtype tf32eq|fp32|bf16|fp16] [--cpu-baseline]
+
+Precision modes (tools/frontend_precision.py measures each against the fp32 CPU forward, profiles/r02_frontend_precision.txt):
+  tf32eq (default)  what the reference's own precision setting amounts to: it runs fp32 with TF32 GEMMs allowed
+                    (run_system.py:73), i.e. 10-bit GEMM operands, fp32 accumulation.  gfx950 has no TF32 MFMA; fp16 operands have
+                    the same 10-bit mantissa, so this mode narrows ONLY the GEMM operands to fp16 and keeps the accumulation, the
+                    residual stream, every LayerNorm and the softmax in fp32.  Output error vs fp32: 1.3e-3 max / 7.8e-4 rel_l2,
+                    the same as an emulated TF32 forward (1.3e-3 / 8.0e-4).
+  fp32              everything fp32 (error 4e-6)
+  bf16 / fp16       whole trunk cast (bf16: 2e-2 / 1.2e-2 -- narrower than the reference's TF32, reported for comparison only)
 """
 import argparse
 import json
@@ -67,8 +76,7 @@ def tracking_frame_match(net, img_f, kf_feat, kf_pos):
         shape = torch.tensor(x.shape[-2:])[None]
         feat1, pos1, _ = net._encode_image(x, shape)
         dec1, dec2 = net._decoder(feat1, pos1, kf_feat, kf_pos)
-        r1 = net._downstream_head(1, [t.float() for t in dec1], shape)
-        r2 = net._downstream_head(2, [t.float() for t in dec2], shape)
+        r1, r2 = net.both_heads(list(dec1), list(dec2), shape, shape)
         X11, X21, D11, D21 = r1["pts3d"], r2["pts3d"], r1["desc"], r2["desc"]
         b, h, w, _ = X11.shape
         rays = F.normalize(X11, dim=-1).permute(0, 3, 1, 2)
@@ -82,7 +90,7 @@ def tracking_frame_match(net, img_f, kf_feat, kf_pos):
     return p1, valid
 
 
-def tracking_frame_bench(net, img_f, img_k, iters):
+def tracking_frame_bench(net, img_f, img_k, iters, use_graph=True):
     with torch.inference_mode():
         td = getattr(net, "_trunk_dtype", None)
         xk = img_k.to(td) if td is not None else img_k
@@ -90,13 +98,66 @@ def tracking_frame_bench(net, img_f, img_k, iters):
     for _ in range(3):
         tracking_frame_match(net, img_f, kf_feat, kf_pos)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        tracking_frame_match(net, img_f, kf_feat, kf_pos)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
-    return {"ms_per_frame": dt * 1e3, "frames_per_s": 1.0 / dt, "launch": "eager",
-            "workload": "one tracked frame: 1 encode (keyframe embedding cached) + decoder + 2 heads + iter_proj + refine_matches"}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    dt_eager = timed(lambda: tracking_frame_match(net, img_f, kf_feat, kf_pos))
+    out = {"ms_per_frame_eager": dt_eager * 1e3,
+           "workload": "one tracked frame: 1 encode (keyframe embedding cached) + decoder + 2 heads + iter_proj + refine_matches"}
+    dt = dt_eager
+    if use_graph:
+        # ~700 launches of microseconds each: Python cannot issue them as fast as the GPU retires them; shapes are static
+        # for a given camera, so the whole frame is captured once into a hipGraph (the two decoder branches and the two heads
+        # become parallel branches of the graph) and replayed per frame
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                tracking_frame_match(net, img_f, kf_feat, kf_pos)
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(graph):
+                captured = tracking_frame_match(net, img_f, kf_feat, kf_pos)
+            ref = tracking_frame_match(net, img_f, kf_feat, kf_pos)
+            ref2 = tracking_frame_match(net, img_f, kf_feat, kf_pos)
+            graph.replay()
+            torch.cuda.synchronize()
+            same = lambda a, b: float((a[0] == b[0]).all(-1).float().mean())
+            dt = timed(graph.replay)
+            # random-init weights give near-random descriptors, so the match argmax amplifies the run-to-run rounding differences
+            # of hipBLASLt's split-K kernels: the replay must agree with eager as well as eager agrees with itself
+            out.update(ms_per_frame_graph=dt * 1e3, graph_matches_identical_to_eager=same(captured, ref), eager_matches_identical_to_eager=same(ref, ref2))
+        except Exception as e:
+            out["graph_error"] = repr(e)[:200]
+    out.update(ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, launch="hipGraph replay" if "ms_per_frame_graph" in out else "eager")
+    return out
+
+
+def make_tracker_step(dev):
+    """-> callable running one frame of the device tracker (enqueue 6 Gauss-Newton iterations, ONE host read, point fusion) on the
+    512x384 synthetic tracker scene; used by bench_system.py."""
+    import numpy as np
+    from artdeco_amd import synthetic as S, tracker as T
+    sc = S.tracker_scene(height=384, width=512, seed=11, fx=420.0, pose_noise=0.04)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {k: t(v) for k, v in sc.items() if isinstance(v, np.ndarray)}
+    cfg = dict(min_match_frac=0.05, max_iters=50, C_conf=0.0, Q_conf=1.5, rel_error=1e-3, delta_norm=1e-3, huber=1.345,
+               match_frac_thresh=0.333, sigma_pixel=1.0, sigma_depth=10.0, pixel_border=-10, depth_eps=1e-6)  # config/base.yaml:19-34
+
+    def step():
+        job = T.TrackJob(384, 512, d["K"], d["Xff"], d["Cff"], 1, d["Qff"], d["Xk_canon"], d["Ck"], 1, d["Qkf"], d["idx_f2k"],
+                         d["valid_match"], d["T_WCf0"], d["T_WCk"], cfg, covariance_filter=True, thres_keyframe=0.8, chunk=6)
+        o = job.outcome()
+        X, C = d["Xk_canon"].clone(), d["Ck"].reshape(-1).clone()
+        T.fuse_pointmap(job.result, d["Xkf"], d["Ckf"], X, C)
+        return o
+    return step
 
 
 def tracker_bench(dev, iters, cpu_baseline):
@@ -169,7 +230,7 @@ def tracker_bench(dev, iters, cpu_baseline):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="tf32eq", choices=["tf32eq", "bf16", "fp16", "fp32"])
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one hipGraph")
     args = ap.parse_args()
@@ -178,8 +239,10 @@ def main():
     net = vit_large().to(dev).eval()
     img1 = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
     img2 = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
-    td = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
-    if td is not None:
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None, "tf32eq": torch.float16}[args.dtype]
+    if args.dtype == "tf32eq":
+        net.to_inference_dtype(torch.float16, fp32_stream=True, heads=True)  # fp16 GEMM / conv operands only; everything else fp32 (TF32-class)
+    elif td is not None:
         net.to_inference_dtype(td)  # trunk weights cast once; heads stay fp32 (dust3r/model.py:205)
     ac = None
     for _ in range(3):
@@ -214,7 +277,7 @@ def main():
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
-    peak = MFMA_F32_PEAK_TFLOPS if td is None else MFMA_BF16_PEAK_TFLOPS
+    peak = MFMA_F32_PEAK_TFLOPS if td is None else MFMA_BF16_PEAK_TFLOPS  # dense fp16 peak = dense bf16 peak on gfx950
     out = {"metric": "MASt3R ViT-L 512x384 asymmetric pair matches per second (2 encodes + decoder + 2 heads + iter_proj + refine_matches)",
            "value": 1.0 / dt, "unit": "pairs/s", "ms_per_pair": dt * 1e3, "dtype": args.dtype, "data": "synthetic, random-init weights",
            "launch": "eager" if args.no_graph else f"hipGraph replay (matches identical to eager: {graph_vs_eager:.4f}; eager vs eager: {eager_repeat:.4f})",
@@ -230,7 +293,7 @@ def main():
         out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"one fp32 pair inference (model only, no matching kernels) on the host: {cdt:.2f} s"}
     try:  # the per-frame path of the running system (not BASELINE's 2-encode pair): reported next to `value`, never instead of it
-        out["tracking_frame"] = tracking_frame_bench(net, img1, img2, args.iters)
+        out["tracking_frame"] = tracking_frame_bench(net, img1, img2, args.iters, use_graph=not args.no_graph)
     except Exception as e:
         out["tracking_frame"] = {"error": repr(e)[:200]}
     out["tracker"] = tracker_bench(dev, max(args.iters, 20), args.cpu_baseline)
