@@ -46,6 +46,8 @@ def parse():
                     help="skip the secondary measurements (other BASELINE configs, unfused glue) reported next to `value`")
     ap.add_argument("--unfused-glue", action="store_true",
                     help="time ARTDECO's render() glue as stock torch ops instead of artdeco_amd.fused (SURVEY 8 f-1)")
+    ap.add_argument("--no-frontend", action="store_true",
+                    help="skip the bounded frontend / whole-system measurements reported next to `value` (N = 1 only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU work: a constant CPU step through the same launch / barrier / all-reduce / report code "
@@ -247,10 +249,76 @@ def main():
             out["other_configs"] = extra_configs(args, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+        if not args.no_frontend and world == 1:
+            del scene
+            torch.cuda.empty_cache()
+            out["frontend"] = frontend_summary(args, dev, cpu=not args.no_cpu_baseline)
+            out["system"] = system_summary()
         if args.stage_detail:
             print(json.dumps(stages, indent=1), file=sys.stderr)
         print(json.dumps(out))
     multigpu.shutdown()
+
+
+def frontend_summary(args, dev, cpu=True):
+    """BASELINE configs[0]/[1], bounded: the MASt3R ViT-L 512x384 frontend on this GPU (TF32-class precision = the reference's
+    allow_tf32 setting, see bench_frontend.py) -- one asymmetric pair match and one tracked frame, each as a hipGraph replay --
+    next to the reference's PyTorch-CPU MASt3R path (fp32, model only, ONE pair) on this box's host cores."""
+    try:
+        import bench_frontend as BF
+        from artdeco_amd.mast3r_model import vit_large
+        torch.manual_seed(0)
+        cpu_net = vit_large().eval()
+        img1, img2 = torch.rand(1, 3, 384, 512) * 2 - 1, torch.rand(1, 3, 384, 512) * 2 - 1
+        res = {"precision": "tf32eq: fp16 GEMM/conv operands (TF32's 10-bit mantissa), fp32 accumulate / residual stream / LayerNorm / softmax",
+               "data": "synthetic images, random-init weights"}
+        if cpu:
+            with torch.inference_mode():
+                t0 = time.perf_counter()
+                cpu_net({"img": img1}, {"img": img2})
+                cdt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"ONE fp32 pair inference (2 encodes + decoder + 2 heads, no matching kernels) of the same module on the host: {cdt:.2f} s"}
+        net = cpu_net.to(dev).to_inference_dtype(torch.float16, fp32_stream=True, heads=True)
+        g1, g2 = img1.to(dev), img2.to(dev)
+        res["tracking_frame"] = BF.tracking_frame_bench(net, g1, g2, 20)
+        for _ in range(3):
+            BF.pair_match(net, g1, g2, None)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            BF.pair_match(net, g1, g2, None)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            BF.pair_match(net, g1, g2, None)
+        graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        res["pair_match"] = {"ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt,
+                             "roofline": {"bound": "mfma", "achieved": BF.PAIR_TFLOP / dt, "peak": BF.MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": BF.PAIR_TFLOP / dt / BF.MFMA_BF16_PEAK_TFLOPS}}
+        del net, graph
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:  # report, never hide
+        return {"error": repr(e)[:300]}
+
+
+def system_summary():
+    """Mapper and frontend as two processes on this one GPU (bench_system.py, 120 tracked frames): min of the two rates."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_system.py"), "--frames", "120", "--alone-seconds", "2"],
+                           capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
 
 
 def _time_steps(scene, steps=10, warmup=3, repeats=2):
