@@ -372,3 +372,20 @@ def test_patch_refuses_unsupported_shapes():
 
     d = Dummy()
     assert not fused.patch_scene_model(d) and d.render() == "unfused"
+
+
+@pytest.mark.gpu
+def test_fused_paths_on_an_empty_scene(dev):
+    """The auto-install hook patches a SceneModel inside its constructor, i.e. while it holds NO Gaussians; the viewer thread
+    may call render() before the first keyframe has added any (h3dgsv3.py:617-624), and optimization_step() returns early
+    (:402-403)."""
+    from artdeco_amd import fused
+    from harness import mapper
+    sc = mapper.MapperScene(96, 64, 80.0, dev)
+    empty = torch.zeros(0, 3)
+    sc.set_gaussians(empty, torch.zeros(0, 4), empty, torch.zeros(0), torch.zeros(0, 16, 3), n_voxels=1)
+    assert fused.patch_scene_model(sc)
+    pkg = sc.render(96, 64, torch.eye(4, device=dev), torch.tensor([0.2, 0.4, 0.6], device=dev))
+    assert pkg["render"].shape == (3, 64, 96) and pkg["visibility_filter"].numel() == 0
+    assert torch.allclose(pkg["render"], torch.tensor([0.2, 0.4, 0.6], device=dev)[:, None, None].expand(3, 64, 96))
+    assert sc.optimization_step(0) is None
