@@ -151,6 +151,155 @@ __global__ __launch_bounds__(256) void count_isects_kernel(const int32_t* __rest
     }
 }
 
+
+// ================================================================================================================
+// Round 2: TILE-LOCAL binning.  The global route above sorts N depth keys (4 radix passes) and then I tile ids (2 passes)
+// in 18 dependent launches of 5-35 us on lists far too small to hide them (0.27 ms at 1 M / 1080p, ~5 % of HBM speed).
+// The order upstream asks for -- (tile, depth bits, Gaussian id) -- does not need a global sort at all:
+//   1. counting sort by tile: every workgroup owns a contiguous slice of the Gaussians and a histogram over ALL tiles in LDS
+//      (4 B x tiles: 32 KB at 1080p, 79 KB at 2592x1944), counts each covered tile, and the [slices][tiles] table is
+//      scanned (column scan per tile, then one small scan over the tiles = the `offsets` output and n_isects);
+//   2. the same slices scatter their (depth bits << 32 | id) keys to LDS cursors initialised from the table: every tile's
+//      segment is now complete, in arbitrary order;
+//   3. one workgroup per tile sorts its segment IN LDS (bitonic on the 64-bit keys; unique keys, so the result is exactly
+//      the stable (tile, depth, id) order) and writes the ids back in place.
+// 5 launches, one read of the records per step 1/2, 8 B per intersection written and read twice.  Bit-identical output.
+// Falls back to the global route when the tile histogram does not fit LDS or a tile holds more than BIN_SORT_BIG entries
+// (the host learns the largest tile together with n_isects, the one value it waits for anyway).
+#define BIN_SLICES 256
+#define BIN_THREADS 1024  // per slice: 16 waves share one LDS histogram (256 slices x 4 waves left most of the chip idle: 89 us -> see DESIGN)
+#define BIN_SORT_SMALL 1024
+#define BIN_SORT_BIG 8192
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec, int N,
+                                                        int tile_w, int tile_h, uint32_t* __restrict__ table /* [BIN_SLICES][n_tiles] */)
+{
+    extern __shared__ uint32_t hist[];
+    const int n_tiles = tile_w * tile_h;
+    for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0u;
+    __syncthreads();
+    const int chunk = (int)ceil_div(N, BIN_SLICES);
+    const int g0 = blockIdx.x * chunk, g1 = min(N, g0 + chunk);
+    for (int g = g0 + threadIdx.x; g < g1; g += BIN_THREADS) {
+        if (tiles_per_gauss[g] == 0) continue;
+        const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
+        const float4 a = r4[0], b = r4[1];
+        int x0, x1, y0, y1;
+        tile_range_bin(a.x, a.y, a.w, b.w, tile_w, tile_h, x0, x1, y0, y1);
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * tile_w + tx], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = table + (int64_t)blockIdx.x * n_tiles;
+    for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) row[t] = hist[t];
+}
+
+// thread = tile: exclusive scan down the slices (in place), tile total out
+__global__ __launch_bounds__(256) void bin_colscan_kernel(uint32_t* __restrict__ table, int n_tiles, uint32_t* __restrict__ tile_count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t run = 0;
+    for (int b = 0; b < BIN_SLICES; ++b) {
+        const uint32_t c = table[(int64_t)b * n_tiles + t];
+        table[(int64_t)b * n_tiles + t] = run;
+        run += c;
+    }
+    tile_count[t] = run;
+}
+
+// one workgroup: offsets[t] = exclusive scan of tile_count; stats[0] = n_isects, stats[1] = largest tile (int64, device)
+__global__ __launch_bounds__(1024) void bin_tilescan_kernel(const uint32_t* __restrict__ tile_count, int n_tiles, int32_t* __restrict__ offsets,
+                                                            int64_t* __restrict__ stats)
+{
+    __shared__ uint32_t wsum[16], wmax[16];
+    __shared__ uint32_t carry_s, max_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { carry_s = 0; max_s = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < n_tiles; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_count[i] : 0u;
+        uint32_t s = v, m = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 63) { wsum[wv] = s; wmax[wv] = m; }
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < n_tiles) offsets[i] = (int32_t)(carry + woff + s - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + s;
+        if (threadIdx.x == 0) { uint32_t mm = max_s; for (int w = 0; w < 16; ++w) mm = max(mm, wmax[w]); max_s = mm; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { stats[0] = (int64_t)carry_s; stats[1] = (int64_t)max_s; }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec,
+                                                          const uint32_t* __restrict__ depth_keys, int N, int tile_w, int tile_h,
+                                                          const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets,
+                                                          int64_t capacity, unsigned long long* __restrict__ pairs)
+{
+    extern __shared__ uint32_t cur[];
+    const int n_tiles = tile_w * tile_h;
+    const uint32_t* row = table + (int64_t)blockIdx.x * n_tiles;
+    for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) cur[t] = (uint32_t)offsets[t] + row[t];
+    __syncthreads();
+    const int chunk = (int)ceil_div(N, BIN_SLICES);
+    const int g0 = blockIdx.x * chunk, g1 = min(N, g0 + chunk);
+    for (int g = g0 + threadIdx.x; g < g1; g += BIN_THREADS) {
+        if (tiles_per_gauss[g] == 0) continue;
+        const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
+        const float4 a = r4[0], b = r4[1];
+        int x0, x1, y0, y1;
+        tile_range_bin(a.x, a.y, a.w, b.w, tile_w, tile_h, x0, x1, y0, y1);
+        const unsigned long long key = ((unsigned long long)depth_keys[g] << 32) | (unsigned long long)(uint32_t)g;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                const uint32_t pos = atomicAdd(&cur[ty * tile_w + tx], 1u);
+                if ((int64_t)pos < capacity) pairs[pos] = key;
+            }
+    }
+}
+
+// One workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS.  MAXN = capacity of this
+// instantiation; tiles outside (lo, MAXN] are left to the other instantiation.
+template <int MAXN>
+__global__ __launch_bounds__(256) void bin_tile_sort_kernel(const unsigned long long* __restrict__ pairs, const int32_t* __restrict__ offsets,
+                                                            int n_tiles, int64_t n_isects, int lo, int32_t* __restrict__ flatten_ids,
+                                                            uint32_t* __restrict__ tile_ids)
+{
+    __shared__ unsigned long long sk[MAXN];
+    const int t = blockIdx.x;
+    const int64_t s = offsets[t];
+    const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
+    const int n = (int)(e - s);
+    if (n <= lo || n > MAXN) return;
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += 256) sk[i] = i < n ? pairs[s + i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < (m >> 1); i += 256) {
+                const int l = 2 * i - (i & (j - 1)); // lower index of the i-th compare-exchange pair at distance j
+                const unsigned long long a = sk[l], b = sk[l + j];
+                const bool asc = (l & k) == 0;
+                if ((a > b) == asc) { sk[l] = b; sk[l + j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        flatten_ids[s + i] = (int32_t)(uint32_t)sk[i];
+        if (tile_ids) tile_ids[s + i] = (uint32_t)t;
+    }
+}
+
 } // namespace adk
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -252,6 +401,91 @@ extern "C" int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids
     else res = adk::radix_sort_pairs(k0, v0, k1, v1, ko, vo, n_isects, 0, hi, scratch, stream) == 1 ? 0 : -1;
     if (res != 0) return ADK_EUNSUPPORTED;
     hipLaunchKernelGGL(adk::tile_offsets_kernel, dim3((unsigned)adk::ceil_div(n_isects, 256)), dim3(256), 0, stream, tile_ids, n_isects, n_tiles, offsets);
+    ADK_RETURN_LAST_ERROR();
+}
+
+
+// ---- tile-local route (round 2): counting sort by tile + per-tile LDS sort -----------------------------------------------
+// LDS the per-slice tile histogram may use (bytes): the count / scatter kernels ask for 4 B x tiles of dynamic LDS.
+#define ADK_BIN_LDS_LIMIT (128 * 1024)
+
+// 1 if adk_bin_local_* can handle this image size (tile histogram fits LDS), else the caller uses adk_bin_depth_order / adk_bin_tiles.
+extern "C" int adk_bin_local_supported(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    const int64_t n_tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
+    return n_tiles * 4 <= ADK_BIN_LDS_LIMIT ? 1 : 0;
+}
+
+extern "C" int64_t adk_bin_local_workspace_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return ADK_EINVAL;
+    const int64_t n_tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
+    return align256((int64_t)BIN_SLICES * n_tiles * 4) + align256(n_tiles * 4) + 256;
+}
+
+// Step 1: per-tile counts.  offsets [tile_h*tile_w] (the isect_offset_encode output) and stats [2] int64 (device):
+// stats[0] = n_isects, stats[1] = entries of the fullest tile.  The workspace is consumed by adk_bin_local_fill.
+extern "C" int adk_bin_local_count(int N, const int32_t* tiles_per_gauss, const float* rec, int width, int height, int32_t* offsets,
+                                   int64_t* stats, void* workspace, int64_t workspace_bytes, hipStream_t stream)
+{
+    using namespace adk;
+    if (N < 0 || width <= 0 || height <= 0 || !offsets || !stats || !workspace) return ADK_EINVAL;
+    if (!adk_bin_local_supported(width, height)) return ADK_EUNSUPPORTED;
+    if (workspace_bytes < adk_bin_local_workspace_bytes(width, height) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
+    if (N > 0 && (!tiles_per_gauss || !rec)) return ADK_EINVAL;
+    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    uint32_t* table = (uint32_t*)workspace;
+    uint32_t* tile_count = (uint32_t*)((char*)workspace + align256((int64_t)BIN_SLICES * n_tiles * 4));
+    const size_t lds = (size_t)n_tiles * 4;
+    static bool attr_set = false; // > 64 KB of dynamic LDS needs the opt-in (idempotent; a race only repeats it)
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ADK_BIN_LDS_LIMIT);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ADK_BIN_LDS_LIMIT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bin_count_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), lds, stream, tiles_per_gauss, rec, N, tile_w, tile_h, table);
+    hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, stream, table, n_tiles, tile_count);
+    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, n_tiles, offsets, stats);
+    ADK_RETURN_LAST_ERROR();
+}
+
+extern "C" int64_t adk_bin_local_pairs_bytes(int64_t n_isects) { return n_isects < 0 ? ADK_EINVAL : align256((n_isects > 0 ? n_isects : 1) * 8); }
+
+// Step 2: every slice scatters its (depth bits << 32 | id) keys into the tiles' segments of `pairs` (capacity entries of 8 B; entries
+// beyond the capacity are dropped, so the host may launch this with an ESTIMATED capacity before it has read n_isects and repeat it in
+// the rare case the estimate was too small).  Order inside a segment is arbitrary.
+extern "C" int adk_bin_local_scatter(int N, int64_t capacity, const uint32_t* depth_keys, const int32_t* tiles_per_gauss, const float* rec,
+                                     int width, int height, const int32_t* offsets, const void* workspace, int64_t workspace_bytes,
+                                     void* pairs, hipStream_t stream)
+{
+    using namespace adk;
+    if (N < 0 || capacity < 0 || width <= 0 || height <= 0 || !offsets || !workspace) return ADK_EINVAL;
+    if (N == 0 || capacity == 0) return 0;
+    if (!depth_keys || !tiles_per_gauss || !rec || !pairs) return ADK_EINVAL;
+    if (workspace_bytes < adk_bin_local_workspace_bytes(width, height) || ((uintptr_t)workspace & 255) || ((uintptr_t)pairs & 7)) return ADK_EWORKSPACE;
+    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), (size_t)n_tiles * 4, stream, tiles_per_gauss, rec, depth_keys, N, tile_w,
+                       tile_h, (const uint32_t*)workspace, offsets, capacity, (unsigned long long*)pairs);
+    ADK_RETURN_LAST_ERROR();
+}
+
+// Step 3: n_isects / max_tile = the HOST copies of stats (pairs must have held all n_isects entries).  Out: flatten_ids [I] in
+// (tile, depth, id) order, tile_ids [I] (or NULL).  max_tile must not exceed 8192 (otherwise: ADK_EUNSUPPORTED, use the global route).
+extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets, const void* pairs,
+                                  int32_t* flatten_ids, uint32_t* tile_ids, hipStream_t stream)
+{
+    using namespace adk;
+    if (n_isects < 0 || width <= 0 || height <= 0 || !offsets) return ADK_EINVAL;
+    if (n_isects == 0) return 0;
+    if (max_tile > BIN_SORT_BIG || n_isects >= ((int64_t)1 << 31)) return ADK_EUNSUPPORTED;
+    if (!pairs || !flatten_ids) return ADK_EINVAL;
+    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    hipLaunchKernelGGL(bin_tile_sort_kernel<BIN_SORT_SMALL>, dim3(n_tiles), dim3(256), 0, stream, (const unsigned long long*)pairs, offsets,
+                       n_tiles, n_isects, 0, flatten_ids, tile_ids);
+    if (max_tile > BIN_SORT_SMALL)
+        hipLaunchKernelGGL(bin_tile_sort_kernel<BIN_SORT_BIG>, dim3(n_tiles), dim3(256), 0, stream, (const unsigned long long*)pairs, offsets,
+                           n_tiles, n_isects, BIN_SORT_SMALL, flatten_ids, tile_ids);
     ADK_RETURN_LAST_ERROR();
 }
 

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 5
+#define ADK_ABI_VERSION 6
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -164,6 +164,26 @@ int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids, const uin
                   const int32_t* tiles_per_gauss, const float* rec, int width, int height,
                   int32_t* flatten_ids, uint32_t* tile_ids, int32_t* offsets, void* workspace,
                   int64_t workspace_bytes, adk_stream_t stream);
+/* The same outputs by the TILE-LOCAL route (default when supported): counting sort by tile with a per-slice tile histogram
+ * in LDS, then one workgroup per tile sorts its (depth bits << 32 | id) keys in LDS.  5 launches instead of 18, no sort of
+ * the N depth keys at all; bit-identical (tile, depth, id) order.
+ *   adk_bin_local_supported(w, h)  1 when the tile histogram fits LDS (<= 32768 tiles), else use the two calls above;
+ *   adk_bin_local_count            offsets [tile_h*tile_w] and stats [2] int64 (device): n_isects, entries of the fullest tile;
+ *   adk_bin_local_scatter          keys of every (Gaussian, tile) pair into the tiles' segments of `pairs` (capacity x 8 B; entries past
+ *                                  the capacity are dropped, so it may be launched with an ESTIMATED capacity before n_isects is read);
+ *   adk_bin_local_sort             n_isects / max_tile = the host copies of stats; max_tile > 8192 -> ADK_EUNSUPPORTED (use the
+ *                                  global route); sorts every tile's segment in LDS; tile_ids may be NULL. */
+int adk_bin_local_supported(int width, int height);
+int64_t adk_bin_local_workspace_bytes(int width, int height);
+int adk_bin_local_count(int N, const int32_t* tiles_per_gauss, const float* rec, int width, int height,
+                        int32_t* offsets, int64_t* stats, void* workspace, int64_t workspace_bytes,
+                        adk_stream_t stream);
+int64_t adk_bin_local_pairs_bytes(int64_t n_isects);
+int adk_bin_local_scatter(int N, int64_t capacity, const uint32_t* depth_keys, const int32_t* tiles_per_gauss,
+                          const float* rec, int width, int height, const int32_t* offsets,
+                          const void* workspace, int64_t workspace_bytes, void* pairs, adk_stream_t stream);
+int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets,
+                       const void* pairs, int32_t* flatten_ids, uint32_t* tile_ids, adk_stream_t stream);
 /* Optional: rebuild upstream's sorted int64 isect_ids for meta['isect_ids']. */
 int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int32_t* flatten_ids,
                            const uint32_t* depth_keys, int64_t* isect_ids, adk_stream_t stream);
