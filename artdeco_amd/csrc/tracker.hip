@@ -58,6 +58,13 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ K, int H, int 
     return c;
 }
 
+// the camera the iterations use: K's principal point with the state's focal lengths (= K's own unless optimize_focal moved them)
+__device__ __forceinline__ Cam state_cam(const float* __restrict__ K, int H, int W, const State* s) {
+    Cam c = load_cam(K, H, W);
+    c.fx = s->fx; c.fy = s->fy;
+    return c;
+}
+
 __device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_prepare_kernel(int n, int H, in
 __global__ __launch_bounds__(TRK_BLOCK) void trk_gather_kernel(
     int n, int W, const int64_t* __restrict__ idx_f2k, const uint8_t* __restrict__ valid_match, const float* __restrict__ Cf,
     float inv_Nf, const float* __restrict__ Ck, float inv_Nk, const float* __restrict__ Qf, const float* __restrict__ Qk,
-    const float* __restrict__ Xk_canon, Cfg g, TrkWs ws, uint8_t* __restrict__ dbg_valid_opt)
+    const float* __restrict__ Xk_canon, Cfg g, int focal, TrkWs ws, uint8_t* __restrict__ dbg_valid_opt)
 {
     __shared__ unsigned wcnt[TRK_BLOCK / 64][2];
     const int k = blockIdx.x * TRK_BLOCK + threadIdx.x;
@@ -124,7 +131,9 @@ __global__ __launch_bounds__(TRK_BLOCK) void trk_gather_kernel(
         opt = kf && (Cf[ix] * inv_Nf > g.C_conf) && (Ck[k] * inv_Nk > g.C_conf);
         const float zk = Xk_canon[3 * (int64_t)k + 2];
         const bool vmeas = zk > g.z_eps;
-        ws.recA[k] = ws.Xfc[ix];
+        float4 a = ws.Xfc[ix];
+        if (focal) { a.x = (float)(int)(ix % W); a.y = (float)(int)(ix / W); } // the frame PIXEL: the point is rebuilt with the current focal
+        ws.recA[k] = a;
         ws.recB[k] = make_float2((opt && vmeas) ? sqrtf(q) : 0.f, vmeas ? logf(zk) : 0.f);
         if (vm) ws.seen[ix] = 1; // benign race: every writer stores the same byte
         unsigned key = TRK_SKIP_KEY;
@@ -172,7 +181,7 @@ __device__ __forceinline__ void block_locate(const unsigned* h, int64_t rank, un
 // after pass 2 it writes max(quantile, floor_value) to *out_value.
 template <int MODE>
 __global__ __launch_bounds__(TRK_SEL_THREADS) void trk_select_kernel(int n, int pass, int num_gather_blocks, int H, int W,
-                                                                     const float* __restrict__ K, TrkWs ws, float q, float floor_value,
+                                                                     const float* __restrict__ K, int focal, TrkWs ws, float q, float floor_value,
                                                                      float* __restrict__ out_value)
 {
     __shared__ unsigned hA[TRK_BINS], hB[TRK_BINS];
@@ -191,13 +200,14 @@ __global__ __launch_bounds__(TRK_SEL_THREADS) void trk_select_kernel(int n, int 
     __syncthreads();
     Cam c;
     Pose T;
-    if (MODE == 1 && pass == 0) { c = load_cam(K, H, W); T = load_pose(ws.state->T); }
+    if (MODE == 1 && pass == 0) { c = state_cam(K, H, W, ws.state); T = load_pose(ws.state->T); }
     unsigned seen_cnt = 0;
     for (int k = blockIdx.x * TRK_SEL_THREADS + tid; k < n; k += TRK_SEL_BLOCKS * TRK_SEL_THREADS) {
         unsigned key;
         if (MODE == 1 && pass == 0) {
             const float4 a = ws.recA[k];
-            const float X[3] = {a.x, a.y, a.z};
+            float X[3] = {a.x, a.y, a.z};
+            if (focal) { float dX[3]; frame_point_focal(c, a.x, a.y, a.z, X, dX); }
             key = float_key(cov_det(T, c, X, a.w));
             if (key == TRK_SKIP_KEY) key = TRK_SKIP_KEY - 1u; // keep every point in the population
             ws.keys[k] = key;
@@ -273,10 +283,12 @@ __global__ __launch_bounds__(TRK_SEL_THREADS) void trk_select_kernel(int n, int 
 }
 
 // ---- 3. optimisation -----------------------------------------------------------------------------------------------------
-__global__ void trk_init_kernel(int n, const float* __restrict__ T_WCf, const float* __restrict__ T_WCk, Cfg g, TrkWs ws)
+__global__ void trk_init_kernel(int n, const float* __restrict__ K, const float* __restrict__ T_WCf, const float* __restrict__ T_WCk, Cfg g,
+                                TrkWs ws)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     State& s = *ws.state;
+    s.fx = K[0]; s.fy = K[4];
     const Pose Tf = quat2unit(load_pose(T_WCf)), Tk = quat2unit(load_pose(T_WCk)); // get_points_poses :194-195
     store_pose(mul(inv(Tk), Tf), s.T);                                              // :303
     store_pose(Tk, s.Tk);
@@ -292,47 +304,56 @@ __global__ void trk_init_kernel(int n, const float* __restrict__ T_WCf, const fl
 
 // normal equations of the current linearisation; the last workgroup to arrive sums the partials in a fixed order (fp64),
 // solves the 7x7 system, retracts and tests for convergence (gn_step)
+template <bool FOCAL>
 __global__ __launch_bounds__(TRK_BLOCK) void trk_accumulate_kernel(int n, int H, int W, const float* __restrict__ K, Cfg g,
                                                                    int use_cov, TrkWs ws, float* __restrict__ dbg_acc0)
 {
-    __shared__ float red[TRK_BLOCK / 64][TRK_NACC];
-    __shared__ double sum[TRK_NACC];
+    constexpr int NACC = FOCAL ? TRK_NACC8 : TRK_NACC;
+    __shared__ float red[TRK_BLOCK / 64][NACC];
+    __shared__ double sum[NACC];
     __shared__ int lastf;
     if (ws.state->done) return;
-    const Cam c = load_cam(K, H, W);
+    const Cam c = state_cam(K, H, W, ws.state);
     const Pose T = load_pose(ws.state->T);
     const float thr = use_cov ? ws.state->thr : 0.f;
-    float acc[TRK_NACC];
+    float acc[NACC];
 #pragma unroll
-    for (int l = 0; l < TRK_NACC; ++l) acc[l] = 0.f;
+    for (int l = 0; l < NACC; ++l) acc[l] = 0.f;
     for (int k = blockIdx.x * TRK_BLOCK + threadIdx.x; k < n; k += TRK_ACC_BLOCKS * TRK_BLOCK) {
         const float4 a = ws.recA[k];
         const float2 b = ws.recB[k];
-        const float X[3] = {a.x, a.y, a.z};
         const bool det_ok = use_cov ? (key_float(ws.keys[k]) < thr) : true;
-        point_rows(T, c, g, X, b.x, (float)(k % W), (float)(k / W), b.y, det_ok, acc);
+        if (FOCAL) {
+            point_rows_focal(T, c, g, a.x, a.y, a.z, b.x, (float)(k % W), (float)(k / W), b.y, det_ok, acc);
+        } else {
+            const float X[3] = {a.x, a.y, a.z};
+            point_rows(T, c, g, X, b.x, (float)(k % W), (float)(k / W), b.y, det_ok, acc);
+        }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int l = 0; l < TRK_NACC; ++l) { const float t = wave_sum_to_lane63(acc[l]); if (lane == 63) red[wv][l] = t; }
+    for (int l = 0; l < NACC; ++l) { const float t = wave_sum_to_lane63(acc[l]); if (lane == 63) red[wv][l] = t; }
     __syncthreads();
-    if (threadIdx.x < TRK_NACC)
-        ws.partials[blockIdx.x * TRK_NACC + threadIdx.x] =
+    if (threadIdx.x < NACC)
+        ws.partials[blockIdx.x * NACC + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (!arrive_last(&ws.arrive[2], &lastf)) return;
-    if (threadIdx.x < TRK_NACC) {
+    if (threadIdx.x < NACC) {
         double s = 0.0;
-        for (int b = 0; b < TRK_ACC_BLOCKS; ++b) s += (double)ws.partials[b * TRK_NACC + threadIdx.x];
+        for (int b = 0; b < TRK_ACC_BLOCKS; ++b) s += (double)ws.partials[b * NACC + threadIdx.x];
         sum[threadIdx.x] = s;
         if (dbg_acc0 && ws.state->iters == 0) dbg_acc0[threadIdx.x] = (float)s;
     }
     __syncthreads();
-    if (threadIdx.x == 0) gn_step(*ws.state, sum, g);
+    if (threadIdx.x == 0) {
+        if (FOCAL) gn_step_focal(*ws.state, sum, g);
+        else gn_step(*ws.state, sum, g);
+    }
 }
 
 // result[0..7] = new T_WCf (the input pose when lost / failed), [8..15] = T_CkCf, [16] lost, [17] failed, [18] iterations,
 // [19] n_opt, [20] n_kf, [21] n_unique, [22] displacement quantile, [23] last cost, [24] finished (converged, lost or
-// failed: nothing left to iterate), [25] last covariance threshold, [26..31] 0
+// failed: nothing left to iterate), [25] last covariance threshold, [26] fx, [27] fy as the iterations left them, [28..31] 0
 __global__ void trk_finish_kernel(const float* __restrict__ T_WCf, TrkWs ws, float* __restrict__ out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -344,7 +365,8 @@ __global__ void trk_finish_kernel(const float* __restrict__ T_WCf, TrkWs ws, flo
     out[16] = (float)s.lost; out[17] = (float)s.fail; out[18] = (float)s.iters;
     out[19] = (float)s.n_opt; out[20] = (float)s.n_kf; out[21] = (float)s.n_unique;
     out[22] = s.dist_q; out[23] = (float)s.cost; out[24] = (float)s.done; out[25] = s.thr;
-    for (int i = 26; i < 32; ++i) out[i] = 0.f;
+    out[26] = s.fx; out[27] = s.fy;
+    for (int i = 28; i < 32; ++i) out[i] = 0.f;
 }
 
 // Point fusion (CameraTracker.py:136-141 + ImageFrame.update_pointmap :30-48), gated on the device-side success flags:
@@ -386,7 +408,7 @@ static TrkLayout trk_layout(int64_t n)
     L.recA = o; o += trk_align(n * 16);
     L.recB = o; o += trk_align(n * 8);
     L.keys = o; o += trk_align(n * 4);
-    L.partials = o; o += trk_align((int64_t)TRK_ACC_BLOCKS * TRK_NACC * 4);
+    L.partials = o; o += trk_align((int64_t)TRK_ACC_BLOCKS * TRK_NACC8 * 4);
     L.total = o;
     return L;
 }
@@ -402,7 +424,7 @@ extern "C" int adk_track_frame(int height, int width, const float* K, const floa
                                const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
                                float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
                                float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
-                               int num_iters, int covariance_filter, float dist_quantile_q, int resume, float* result,
+                               int num_iters, int covariance_filter, int optimize_focal, float dist_quantile_q, int resume, float* result,
                                float* dbg_Xc, float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace,
                                int64_t workspace_bytes, hipStream_t stream)
 {
@@ -432,20 +454,24 @@ extern "C" int adk_track_frame(int height, int width, const float* K, const floa
         hipLaunchKernelGGL(trk_clear_kernel, dim3(stream_grid(L.zero_bytes / 16, TRK_BLOCK)), dim3(TRK_BLOCK), 0, stream, (uint4*)w, L.zero_bytes / 16);
         hipLaunchKernelGGL(trk_prepare_kernel, dim3(pt_blocks), dim3(TRK_BLOCK), 0, stream, n, height, width, K, Xf_canon, ws.Xfc, dbg_Xc, dbg_var);
         hipLaunchKernelGGL(trk_gather_kernel, dim3(pt_blocks), dim3(TRK_BLOCK), 0, stream, n, width, idx_f2k, valid_match, Cf, inv_Nf, Ck, inv_Nk,
-                           Qf, Qk, Xk_canon, g, ws, dbg_valid_opt);
+                           Qf, Qk, Xk_canon, g, optimize_focal, ws, dbg_valid_opt);
         // displacement quantile over the valid_opt matches (check_keyframe_map :181-183) + distinct matched frame pixels
         for (int pass = 0; pass < 3; ++pass)
             hipLaunchKernelGGL(trk_select_kernel<0>, dim3(TRK_SEL_BLOCKS), dim3(TRK_SEL_THREADS), 0, stream, n, pass, pt_blocks, height, width, K,
-                               ws, dist_quantile_q, -INFINITY, &ws.state->dist_q);
-        hipLaunchKernelGGL(trk_init_kernel, dim3(1), dim3(64), 0, stream, n, T_WCf, T_WCk, g, ws);
+                               0, ws, dist_quantile_q, -INFINITY, &ws.state->dist_q);
+        hipLaunchKernelGGL(trk_init_kernel, dim3(1), dim3(64), 0, stream, n, K, T_WCf, T_WCk, g, ws);
     }
     for (int it = 0; it < num_iters; ++it) {
         if (covariance_filter)
             for (int pass = 0; pass < 3; ++pass)
                 hipLaunchKernelGGL(trk_select_kernel<1>, dim3(TRK_SEL_BLOCKS), dim3(TRK_SEL_THREADS), 0, stream, n, pass, pt_blocks, height, width, K,
-                                   ws, 0.9f, 1.0f, &ws.state->thr);
-        hipLaunchKernelGGL(trk_accumulate_kernel, dim3(TRK_ACC_BLOCKS), dim3(TRK_BLOCK), 0, stream, n, height, width, K, g, covariance_filter,
-                           ws, dbg_acc0);
+                                   optimize_focal, ws, 0.9f, 1.0f, &ws.state->thr);
+        if (optimize_focal)
+            hipLaunchKernelGGL(trk_accumulate_kernel<true>, dim3(TRK_ACC_BLOCKS), dim3(TRK_BLOCK), 0, stream, n, height, width, K, g,
+                               covariance_filter, ws, dbg_acc0);
+        else
+            hipLaunchKernelGGL(trk_accumulate_kernel<false>, dim3(TRK_ACC_BLOCKS), dim3(TRK_BLOCK), 0, stream, n, height, width, K, g,
+                               covariance_filter, ws, dbg_acc0);
     }
     hipLaunchKernelGGL(trk_finish_kernel, dim3(1), dim3(64), 0, stream, T_WCf, ws, result);
     ADK_RETURN_LAST_ERROR();

@@ -21,6 +21,9 @@ namespace trk {
 
 #define TRK_NS 28   // lower triangle of the symmetric 7x7
 #define TRK_NACC 36 // + 7 gradient entries + the cost
+// --optimize_focal (CameraTracker.py:308-320,367-377): an 8th unknown, the focal length shared by fx and fy
+#define TRK_NS8 36
+#define TRK_NACC8 45
 
 struct Pose { float t[3], q[4], s; }; // q = xyzw
 
@@ -271,6 +274,60 @@ ADK_HD void point_rows(const Pose& T, const Cam& c, const Cfg& g, const float* X
     add_row(acc, J, huber_w(swd * e2, g.huber_k) * swd * swd, e2);
 }
 
+// ---- --optimize_focal ----------------------------------------------------------------------------------------------------
+// acc[0..35] += w J J^T (8x8 lower triangle), acc[36..43] += w e J, acc[44] += 0.5 w e^2
+ADK_HD void add_row8(float* acc, const float* J, float w, float e) {
+    int l = 0;
+    for (int n = 0; n < 8; ++n) {
+        const float wj = w * J[n];
+        for (int m = 0; m <= n; ++m) acc[l++] += wj * J[m];
+        acc[TRK_NS8 + n] += wj * e;
+    }
+    acc[TRK_NACC8 - 1] += 0.5f * w * e * e;
+}
+
+// The matched frame point re-backprojected with the CURRENT focal (backproject, geometry.py:116-124) and its derivative
+// with respect to the focal as the reference writes it (CameraTracker.py:313-316): (uf, vf) = the frame pixel, z its depth.
+ADK_HD void frame_point_focal(const Cam& c, float uf, float vf, float z, float* X, float* dX) {
+    X[0] = (uf - c.cx) / c.fx * z;
+    X[1] = (vf - c.cy) / c.fy * z;
+    X[2] = z;
+    dX[0] = -(uf - c.cx) / (c.fx * c.fx) * z;
+    dX[1] = -(vf - c.cy) / (c.fy * c.fy) * z;
+    dX[2] = 0.f;
+}
+
+// point_rows with the focal column of project_calib (geometry.py:110-112, kept term for term -- including the division by
+// z_inv^2): d = (s R) dXf/df, col = (x/z + fx (d0 z - d2 x) / z_inv^2, y/z + fy (d1 z - d2 y) / z_inv^2, d2 / z).
+ADK_HD void point_rows_focal(const Pose& T, const Cam& c, const Cfg& g, float uf, float vf, float zf, float w0, float uk, float vk,
+                             float logzk, bool det_ok, float* acc) {
+    float Xf[3], dXf[3], P[3], d[3];
+    frame_point_focal(c, uf, vf, zf, Xf, dXf);
+    act(T, Xf, P);
+    rot(T.q, dXf, d);
+    d[0] *= T.s; d[1] *= T.s; d[2] *= T.s;
+    const bool vz = P[2] > g.z_eps;
+    const float zinv = 1.0f / P[2];
+    const float xz = P[0] * zinv, yz = P[1] * zinv;
+    const float u = (c.fx * P[0] + c.cx * P[2]) / P[2], v = (c.fy * P[1] + c.cy * P[2]) / P[2];
+    const bool vu = (u > g.border) && (u < (float)(c.W - 1) - g.border);
+    const bool vv = (v > g.border) && (v < (float)(c.H - 1) - g.border);
+    if (!(vz && vu && vv && det_ok) || !(w0 > 0.0f)) return;
+    const float swp = w0 * g.sigma_pixel_inv, swd = w0 * g.sigma_depth_inv;
+    const float e0 = u - uk, e1 = v - vk, e2 = logf(P[2]) - logzk;
+    const float zi2 = zinv * zinv;
+    float J[8];
+    J[0] = c.fx * zinv; J[1] = 0.f; J[2] = -c.fx * xz * zinv; J[3] = -c.fx * xz * yz; J[4] = c.fx * (1.f + xz * xz); J[5] = -c.fx * yz; J[6] = 0.f;
+    J[7] = xz + c.fx * (d[0] * P[2] - d[2] * P[0]) / zi2;
+    add_row8(acc, J, huber_w(swp * e0, g.huber_k) * swp * swp, e0);
+    J[0] = 0.f; J[1] = c.fy * zinv; J[2] = -c.fy * yz * zinv; J[3] = -c.fy * (1.f + yz * yz); J[4] = c.fy * xz * yz; J[5] = c.fy * xz; J[6] = 0.f;
+    J[7] = yz + c.fy * (d[1] * P[2] - d[2] * P[1]) / zi2;
+    add_row8(acc, J, huber_w(swp * e1, g.huber_k) * swp * swp, e1);
+    J[0] = 0.f; J[1] = 0.f; J[2] = zinv; J[3] = yz; J[4] = -xz; J[5] = 0.f; J[6] = 1.f;
+    J[7] = zinv * d[2];
+    add_row8(acc, J, huber_w(swd * e2, g.huber_k) * swd * swd, e2);
+}
+
 // Device-resident state of one tracking call.
 struct State {
     float T[8];        // T_CkCf, the variable
@@ -282,39 +339,43 @@ struct State {
     float tau[7];      // last step
     float dist_q;      // displacement quantile (check_keyframe_map)
     unsigned n_opt, n_kf, n_unique;
+    float fx, fy;      // the focal lengths the iterations use (optimize_focal updates them; K itself is never written)
 };
 
-// H tau = -v by Cholesky in double; false when a pivot is not positive (torch.linalg.cholesky would raise).
-ADK_HD bool solve7(const double* acc, double* tau) {
-    double L[7][7];
+// H tau = -v by Cholesky in double (NV unknowns: acc = lower triangle, then the NV gradient entries); false when a pivot is
+// not positive (torch.linalg.cholesky would raise).
+template <int NV>
+ADK_HD bool solve_chol(const double* acc, double* tau) {
+    double L[NV][NV];
     int l = 0;
-    for (int n = 0; n < 7; ++n) for (int m = 0; m <= n; ++m) L[n][m] = acc[l++];
-    for (int k = 0; k < 7; ++k) {
+    for (int n = 0; n < NV; ++n) for (int m = 0; m <= n; ++m) L[n][m] = acc[l++];
+    for (int k = 0; k < NV; ++k) {
         double d = L[k][k];
         for (int m = 0; m < k; ++m) d -= L[k][m] * L[k][m];
         if (!(d > 0.0) || !(d < 1e300)) return false;
         const double p = sqrt(d);
         L[k][k] = p;
-        for (int r = k + 1; r < 7; ++r) {
+        for (int r = k + 1; r < NV; ++r) {
             double x = L[r][k];
             for (int m = 0; m < k; ++m) x -= L[r][m] * L[k][m];
             L[r][k] = x / p;
         }
     }
-    double y[7];
-    for (int r = 0; r < 7; ++r) {
-        double x = -acc[TRK_NS + r];
+    double y[NV];
+    for (int r = 0; r < NV; ++r) {
+        double x = -acc[NV * (NV + 1) / 2 + r];
         for (int m = 0; m < r; ++m) x -= L[r][m] * y[m];
         y[r] = x / L[r][r];
     }
-    for (int r = 6; r >= 0; --r) {
+    for (int r = NV - 1; r >= 0; --r) {
         double x = y[r];
-        for (int m = r + 1; m < 7; ++m) x -= L[m][r] * tau[m];
+        for (int m = r + 1; m < NV; ++m) x -= L[m][r] * tau[m];
         tau[r] = x / L[r][r];
     }
-    for (int r = 0; r < 7; ++r) if (!(tau[r] == tau[r])) return false;
+    for (int r = 0; r < NV; ++r) if (!(tau[r] == tau[r])) return false;
     return true;
 }
+ADK_HD bool solve7(const double* acc, double* tau) { return solve_chol<7>(acc, tau); }
 
 // One Gauss-Newton step from the summed accumulators (CameraTracker.py:372-389): solve, retract, convergence test.
 ADK_HD void gn_step(State& s, const double* acc, const Cfg& g) {
@@ -328,6 +389,26 @@ ADK_HD void gn_step(State& s, const double* acc, const Cfg& g) {
     store_pose(retract(tf, load_pose(s.T)), s.T);
     s.iters += 1;
     // check_convergence: |(old - new) / old| < rel_error or |tau| < delta_norm; old = inf gives nan -> false
+    const double rel = fabs((s.old_cost - cost) / s.old_cost);
+    if (rel < g.rel_error || sqrt(n2) < g.delta_norm) s.done = 1;
+    s.old_cost = cost;
+}
+
+// The same step with the focal as 8th unknown (CameraTracker.py:372-389): the pose takes tau[:7], both focal lengths take
+// tau[7], and the convergence test looks at tau[:7] only.
+ADK_HD void gn_step_focal(State& s, const double* acc, const Cfg& g) {
+    double tau[8];
+    const double cost = acc[TRK_NACC8 - 1];
+    s.cost = cost;
+    if (!solve_chol<8>(acc, tau)) { s.fail = 1; s.done = 1; return; }
+    float tf[8];
+    double n2 = 0.0;
+    for (int r = 0; r < 8; ++r) tf[r] = (float)tau[r];
+    for (int r = 0; r < 7; ++r) { s.tau[r] = tf[r]; n2 += (double)tf[r] * (double)tf[r]; }
+    store_pose(retract(tf, load_pose(s.T)), s.T);
+    s.fx = s.fx + tf[7];
+    s.fy = s.fy + tf[7];
+    s.iters += 1;
     const double rel = fabs((s.old_cost - cost) / s.old_cost);
     if (rel < g.rel_error || sqrt(n2) < g.delta_norm) s.done = 1;
     s.old_cost = cost;

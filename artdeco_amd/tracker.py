@@ -30,6 +30,8 @@ class TrackOutcome:
     n_unique: int
     dist_quantile: float
     cost: float
+    fx: float = 0.0          # the focal lengths the iterations ended with (= K's unless optimize_focal)
+    fy: float = 0.0
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -65,7 +67,7 @@ class TrackJob:
     chunk: iterations per call (None = all of cfg["max_iters"] at once, i.e. never more than one host read)."""
 
     def __init__(self, height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
-                 covariance_filter=True, thres_keyframe=0.8, debug=False, chunk=6):
+                 covariance_filter=True, thres_keyframe=0.8, debug=False, chunk=6, optimize_focal=False):
         n = int(height) * int(width)
         _lib.require_cuda(K, Xf_canon, Cf, Qf, Xk_canon, Ck, Qk, idx_f2k, valid_match, T_WCf, T_WCk)
         dev = Xf_canon.device
@@ -84,6 +86,7 @@ class TrackJob:
             raise ValueError("tracker: K [3,3] and poses [8] expected")
         self.height, self.width, self.n, self.dev = int(height), int(width), n, dev
         self.cfg, self.cov, self.thres = cfg, bool(covariance_filter), float(thres_keyframe)
+        self.focal = bool(optimize_focal)
         self.max_iters = int(cfg["max_iters"])
         self.chunk = self.max_iters if chunk is None else max(1, int(chunk))
         self.inv_Nf, self.inv_Nk = 1.0 / float(Nf), 1.0 / float(Nk)
@@ -94,7 +97,7 @@ class TrackJob:
             self.dbg = {}
             if debug:
                 self.dbg = dict(Xc=torch.empty(n, 3, dtype=torch.float32, device=dev), var=torch.empty(n, 3, dtype=torch.float32, device=dev),
-                                valid_opt=torch.empty(n, dtype=torch.uint8, device=dev), acc0=torch.zeros(36, dtype=torch.float32, device=dev))
+                                valid_opt=torch.empty(n, dtype=torch.uint8, device=dev), acc0=torch.zeros(45, dtype=torch.float32, device=dev))
             self.ws = torch.empty(int(self.lib.adk_track_workspace_bytes(self.height, self.width)), dtype=torch.uint8, device=dev)
         self.enqueued = 0
         self.host_reads = 0
@@ -110,7 +113,8 @@ class TrackJob:
                 Ck.data_ptr(), self.inv_Nk, Qk.data_ptr(), idx_f2k.data_ptr(), valid_match.data_ptr(), T_WCf.data_ptr(), T_WCk.data_ptr(),
                 float(cfg["sigma_pixel"]), float(cfg["sigma_depth"]), float(cfg["huber"]), float(cfg["C_conf"]), float(cfg["Q_conf"]),
                 float(cfg["min_match_frac"]), int(cfg["pixel_border"]), float(cfg["depth_eps"]), float(cfg["rel_error"]),
-                float(cfg["delta_norm"]), int(num), int(self.cov), self.thres, int(resume), self.result.data_ptr(), _lib.ptr(dbg.get("Xc")),
+                float(cfg["delta_norm"]), int(num), int(self.cov), int(self.focal), self.thres, int(resume), self.result.data_ptr(),
+                _lib.ptr(dbg.get("Xc")),
                 _lib.ptr(dbg.get("var")), _lib.ptr(dbg.get("valid_opt")), _lib.ptr(dbg.get("acc0")), self.ws.data_ptr(), self.ws.numel(),
                 _lib.stream_of(Xf_canon))
         _lib.check(rc, "adk_track_frame")
@@ -126,16 +130,17 @@ class TrackJob:
             self._enqueue(resume=True)
         r = self.result
         return TrackOutcome(T_WCf=r[0:8], T_CkCf=r[8:16], lost=bool(h[16] != 0), failed=bool(h[17] != 0), iterations=int(h[18]),
-                            n_opt=int(h[19]), n_kf=int(h[20]), n_unique=int(h[21]), dist_quantile=float(h[22]), cost=float(h[23]))
+                            n_opt=int(h[19]), n_kf=int(h[20]), n_unique=int(h[21]), dist_quantile=float(h[22]), cost=float(h[23]),
+                            fx=float(h[26]), fy=float(h[27]))
 
 
 def track_frame(height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
-                covariance_filter=True, thres_keyframe=0.8, debug=False, chunk=None):
+                covariance_filter=True, thres_keyframe=0.8, debug=False, chunk=None, optimize_focal=False):
     """Run one tracking problem to completion; returns (result [32] device tensor, debug dict).  With chunk=None all
     cfg["max_iters"] iterations are enqueued at once and nothing synchronises; with a chunk size the host reads the
     result between chunks (see TrackJob)."""
     job = TrackJob(height, width, K, Xf_canon, Cf, Nf, Qf, Xk_canon, Ck, Nk, Qk, idx_f2k, valid_match, T_WCf, T_WCk, cfg,
-                   covariance_filter, thres_keyframe, debug, chunk)
+                   covariance_filter, thres_keyframe, debug, chunk, optimize_focal)
     if chunk is not None:
         job.outcome()
     return job.result, job.dbg
@@ -161,7 +166,8 @@ def read_outcome(result: torch.Tensor) -> TrackOutcome:
     """Host view of a FINISHED result (one 128-byte copy)."""
     h = result.cpu().numpy()
     return TrackOutcome(T_WCf=result[0:8], T_CkCf=result[8:16], lost=bool(h[16] != 0), failed=bool(h[17] != 0), iterations=int(h[18]),
-                        n_opt=int(h[19]), n_kf=int(h[20]), n_unique=int(h[21]), dist_quantile=float(h[22]), cost=float(h[23]))
+                        n_opt=int(h[19]), n_kf=int(h[20]), n_unique=int(h[21]), dist_quantile=float(h[22]), cost=float(h[23]),
+                        fx=float(h[26]), fy=float(h[27]))
 
 
 def keyframe_decisions(o: TrackOutcome, n: int, match_frac_thresh: float, min_displacement: float, last_dist: float):
@@ -199,8 +205,6 @@ class CameraTracker:
         self.optimize_focal = args.optimize_focal
         self.covariance_filter = args.covariance_filter
         self.point_fusion_frontend = args.point_fusion_frontend
-        if self.optimize_focal:
-            raise NotImplementedError("artdeco_amd tracker: --optimize_focal is not supported (off in run.sh)")
         self._match_fn = match_fn
         self._mono_fn = inference_mono_fn
         self.last_embedding = None
@@ -242,8 +246,14 @@ class CameraTracker:
         job = TrackJob(self.H_slam, self.W_slam, self.K_slam, frame.X_canon, frame.C, frame.N, Qff, keyframe.X_canon, keyframe.C,
                        keyframe.N, Qkf, idx_f2k[0], valid_match_k[0], raw_pose(frame.T_WC).to(self.device),
                        raw_pose(keyframe.T_WC).to(self.device), self.cfg, self.covariance_filter, self.thres_keyframe,
-                       chunk=self.iters_per_call)
+                       chunk=self.iters_per_call, optimize_focal=self.optimize_focal)
         o = self.last_outcome = job.outcome()
+        if self.optimize_focal and not o.lost:
+            # the reference updates self.K_slam in place after every iteration (CameraTracker.py:376-377), also when a later
+            # Cholesky fails; the device keeps the running focal in its state and reports it in result[26..27]
+            with torch.no_grad():
+                self.K_slam[0, 0] = job.result[26].to(self.K_slam.device)
+                self.K_slam[1, 1] = job.result[27].to(self.K_slam.device)
         X_new = C_new = None
         if self.point_fusion_frontend and not (o.lost or o.failed):
             X_new, C_new = keyframe.X_canon.clone().contiguous(), keyframe.C.clone().contiguous()

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 6
+#define ADK_ABI_VERSION 7
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -401,21 +401,27 @@ int adk_gauss_newton(int kind, int num_poses, int num_edges, int num_points, flo
  * [16] lost (matches below min_match_frac), [17] Cholesky failed, [18] iterations done so far, [19] valid_opt
  * count, [20] valid_kf count, [21] number of distinct matched frame pixels, [22] dist_quantile_q-quantile of the
  * match displacement over valid_opt (torch.quantile semantics), [23] cost of the last linearisation, [24] finished
- * (converged, lost or failed), [25] last covariance-filter threshold, [26..31] zero.
+ * (converged, lost or failed), [25] last covariance-filter threshold, [26] fx, [27] fy as the iterations left them
+ * (= K's unless optimize_focal), [28..31] zero.
+ * optimize_focal != 0 = the reference's --optimize_focal (CameraTracker.py:308-320,367-377; geometry.py:110-112): every
+ * iteration rebuilds the matched frame points from their pixel and depth with the current focal, the system gets an 8th
+ * unknown shared by fx and fy (Jacobian column exactly as project_calib writes it), the pose takes tau[:7], both focal
+ * lengths take tau[7].  K itself is never written: the caller copies result[26..27] into its K (the reference updates
+ * self.K_slam in place).
  * A call enqueues num_iters Gauss-Newton iterations (they become no-ops once converged) and never synchronises.
  * resume = 0: full call (prepare, gather, statistics, init, iterations).  resume = 1: only further iterations on the
  * state left in the SAME workspace by the previous call (same inputs): the host reads result[24] and continues in
  * chunks until finished or the reference's max_iters (50) is reached -- a no-op launch still costs ~4 us of GPU time,
  * so enqueueing all 50 iterations up front would triple the cost of a frame that converges in three.
  * dbg_* (optional, resume = 0): constrained frame points [n,3], local variances [n,3], valid_opt [n] bytes, the
- * summed accumulators of iteration 0 [36] (28 lower-triangle H, 7 J^T e, cost). */
+ * summed accumulators of iteration 0 [36] (28 lower-triangle H, 7 J^T e, cost; [45] = 36 + 8 + 1 with optimize_focal). */
 int64_t adk_track_workspace_bytes(int height, int width);
 int adk_track_frame(int height, int width, const float* K, const float* Xf_canon, const float* Cf, float inv_Nf,
                     const float* Qf, const float* Xk_canon, const float* Ck, float inv_Nk, const float* Qk,
                     const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
                     float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
                     float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
-                    int num_iters, int covariance_filter, float dist_quantile_q, int resume, float* result,
+                    int num_iters, int covariance_filter, int optimize_focal, float dist_quantile_q, int resume, float* result,
                     float* dbg_Xc, float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, void* workspace,
                     int64_t workspace_bytes, adk_stream_t stream);
 /* Point fusion after a successful track (CameraTracker.py:136-141 + ImageFrame.update_pointmap, ImageFrame.py:30-48):

@@ -4,7 +4,8 @@ Follows, function by function:
   VSLAM/CameraTracker.py:53-155   track()  (masks :83-87, lost test :90-118, pose :123-135, fusion :136-141,
                                   keyframe decisions :144-153)
   :159-167 check_keyframe, :170-186 check_keyframe_map, :189-219 get_points_poses, :223-238 solve,
-  :296-396 opt_pose_calib_sim3 (covariance filter :335-346; optimize_focal is off in run.sh and not restated)
+  :296-396 opt_pose_calib_sim3 (covariance filter :335-346; --optimize_focal :308-320,367-377: re-backprojection of the
+                                  frame points with the current focal, 8th Jacobian column, K updated in place)
   VSLAM/mast3r_slam/geometry.py:38-43,116-124 constrain_points_to_ray / backproject, :47-54 act_Sim3,
   :66-113 project_calib;  nonlinear_optimizer.py:5-26 check_convergence, :29-34 huber
   VSLAM/utils_uncertainty.py:5-53 local_diag_cov_from_X1;  VSLAM/ImageFrame.py:30-52 update_pointmap / get_average_conf
@@ -102,8 +103,9 @@ def local_diag_var(X, H, W, win=5, var_floor=1e-12):
     return np.maximum(ex2 - mean * mean, X.dtype.type(var_floor)).reshape(-1, 3)
 
 
-def project_calib(P, K, H, W, border, z_eps):
-    """geometry.py:66-113 without the focal column: pz [n,3] = (u, v, log z), dpz_dP [n,3,3], valid [n]."""
+def project_calib(P, K, H, W, border, z_eps, dP_df=None):
+    """geometry.py:66-113: pz [n,3] = (u, v, log z), dpz_dP [n,3,3], valid [n]; with dP_df [n,3] (= dXf_Ck_d_f) also the
+    focal column [n,3] exactly as the reference writes it (:110-112, including its division by z_inv**2)."""
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     x, y, z = P[:, 0], P[:, 1], P[:, 2]
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -119,6 +121,12 @@ def project_calib(P, K, H, W, border, z_eps):
     J[:, 0, 2] = -fx * x * z_inv * z_inv
     J[:, 1, 2] = -fy * y * z_inv * z_inv
     J[:, 2, 2] = z_inv
+    if dP_df is not None:
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            d0, d1, d2 = dP_df[:, 0], dP_df[:, 1], dP_df[:, 2]
+            zi2 = z_inv * z_inv                                   # z_inv ** 2
+            Jf = np.stack([x * z_inv + fx * (d0 * z - d2 * x) / zi2, y * z_inv + fy * (d1 * z - d2 * y) / zi2, z_inv * d2], -1).astype(P.dtype)
+        return np.stack([u, v, logz], -1).astype(P.dtype), J, valid, Jf
     return np.stack([u, v, logz], -1).astype(P.dtype), J, valid
 
 
@@ -185,11 +193,17 @@ def check_convergence(rel_thr, delta_thr, old_cost, new_cost, delta):
 
 
 # ------------------------------------------------------------------------------------------------ the optimisation
-def normal_equations(T, Xf, var_f, meas_k, valid_meas_k, sqrt_info, K, H, W, cfg, covariance_filter, det_mode):
-    """One linearisation (CameraTracker.py:321-372 + solve :223-234): H [7,7], g [7], cost, threshold used."""
+def normal_equations(T, Xf, var_f, meas_k, valid_meas_k, sqrt_info, K, H, W, cfg, covariance_filter, det_mode, dXf_df=None):
+    """One linearisation (CameraTracker.py:321-372 + solve :223-234): H [7,7], g [7], cost, threshold used.  With dXf_df [n,3]
+    (optimize_focal: derivative of the re-backprojected frame point w.r.t. the focal, :313-316) the system is 8 x 8."""
     dt = Xf.dtype
     P = sim3_act(T.astype(dt), Xf)
-    pz, dpz, valid_proj = project_calib(P, K.astype(dt), H, W, cfg["pixel_border"], cfg["depth_eps"])
+    Jf = None
+    if dXf_df is not None:
+        dP_df = (dXf_df.astype(dt) @ rot_scale_matrix(T.astype(dt)).T).astype(dt)     # T.matrix()[:3,:3] @ dXf_f  (:323,333)
+        pz, dpz, valid_proj, Jf = project_calib(P, K.astype(dt), H, W, cfg["pixel_border"], cfg["depth_eps"], dP_df)
+    else:
+        pz, dpz, valid_proj = project_calib(P, K.astype(dt), H, W, cfg["pixel_border"], cfg["depth_eps"])
     thr = None
     if covariance_filter:
         det = pixel_cov_det(P, T.astype(dt), var_f, K.astype(dt), det_mode)
@@ -201,9 +215,11 @@ def normal_equations(T, Xf, var_f, meas_k, valid_meas_k, sqrt_info, K, H, W, cfg
     si2 = sqrt_info * valid2[:, None].astype(dt)
     r = meas_k - pz
     J = -(dpz @ act_jacobian(P))
+    if Jf is not None:
+        J = np.concatenate([J, -Jf[..., None]], -1)                                     # :368-369
     whitened = si2 * r
     robust = si2 * np.sqrt(huber(whitened, dt.type(cfg["huber"])))
-    A = (robust[..., None] * J).reshape(-1, 7)
+    A = (robust[..., None] * J).reshape(-1, J.shape[-1])
     b = (robust * r).reshape(-1, 1)
     Hm = A.T @ A
     g = -(A.T @ b)[:, 0]
@@ -212,28 +228,40 @@ def normal_equations(T, Xf, var_f, meas_k, valid_meas_k, sqrt_info, K, H, W, cfg
 
 
 def opt_pose_calib_sim3(Xf, var_f, T_WCf, T_WCk, Qk, valid, meas_k, valid_meas_k, K, H, W, cfg, covariance_filter=True,
-                        det_mode="lu", dtype=F, trace=None):
+                        det_mode="lu", dtype=F, trace=None, idx_f2k=None):
     """CameraTracker.py:296-396.  Xf / var_f / Qk / valid / meas_k / valid_meas_k are in keyframe pixel order.
-    Returns (T_WCf [8], T_CkCf [8], iterations); raises np.linalg.LinAlgError where torch.linalg.cholesky would."""
+    Returns (T_WCf [8], T_CkCf [8], iterations); raises np.linalg.LinAlgError where torch.linalg.cholesky would.
+    idx_f2k given = --optimize_focal: K [3,3] is UPDATED IN PLACE (the reference writes self.K_slam, :376-377)."""
     Xf, var_f = Xf.astype(dtype), (var_f.astype(dtype) if var_f is not None else None)
+    focal = idx_f2k is not None
+    if focal:
+        uf, vf = (idx_f2k % W).astype(dtype), (idx_f2k // W).astype(dtype)
     w = (valid[:, 0] * np.sqrt(Qk[:, 0])).astype(dtype)
     sqrt_info = np.stack([w / dtype(cfg["sigma_pixel"])] * 2 + [w / dtype(cfg["sigma_depth"])], -1).astype(dtype)
     T = sim3_mul(sim3_inv(T_WCk.astype(dtype)), T_WCf.astype(dtype))
     old_cost = float("inf")
     it = 0
     for step in range(int(cfg["max_iters"])):
+        dXf_df = None
+        if focal:                                                                       # :308-318
+            z = Xf[:, 2]
+            dXf_df = np.stack([-(uf - K[0, 2]) / (K[0, 0] ** 2) * z, -(vf - K[1, 2]) / (K[1, 1] ** 2) * z, np.zeros_like(z)], -1).astype(dtype)
+            Xf = np.stack([(uf - K[0, 2]) / K[0, 0] * z, (vf - K[1, 2]) / K[1, 1] * z, z], -1).astype(dtype)
         Hm, g, cost, thr = normal_equations(T, Xf, var_f, meas_k.astype(dtype), valid_meas_k, sqrt_info, K, H, W, cfg,
-                                            covariance_filter, det_mode)
+                                            covariance_filter, det_mode, dXf_df)
         L = np.linalg.cholesky(Hm.astype(dtype))
         if not np.isfinite(L).all():
             raise np.linalg.LinAlgError("cholesky")
         y = np.linalg.solve(L, g.astype(dtype))
         tau = np.linalg.solve(L.T, y).astype(dtype)
         if trace is not None:
-            trace.append(dict(H=Hm, g=g, cost=cost, tau=tau, thr=thr, T=T.copy()))
-        T = quat2unit(sim3_retract(tau, T).astype(dtype))
+            trace.append(dict(H=Hm, g=g, cost=cost, tau=tau, thr=thr, T=T.copy(), fx=float(K[0, 0])))
+        T = quat2unit(sim3_retract(tau[:7], T).astype(dtype))
+        if focal:                                                                       # :376-377
+            K[0, 0] = K[0, 0] + tau[7]
+            K[1, 1] = K[1, 1] + tau[7]
         it = step + 1
-        if check_convergence(cfg["rel_error"], cfg["delta_norm"], old_cost, cost, tau):
+        if check_convergence(cfg["rel_error"], cfg["delta_norm"], old_cost, cost, tau[:7]):
             break
         old_cost = cost
     return sim3_mul(T_WCk.astype(dtype), T), T, it
@@ -248,12 +276,13 @@ def update_pointmap(X_canon, C, N, X, Cn):
 
 
 def track(sc, cfg=None, covariance_filter=True, min_displacement=30.0, thres_keyframe=0.8, last_dist=0.0, det_mode="lu",
-          kf_N=None, trace=None):
+          kf_N=None, trace=None, optimize_focal=False, K=None):
     """CameraTracker.track (:53-155) on a `tracker_scene` dict for a FRESH frame (frame.N == 0) and a keyframe that holds
     (Xk_canon, Ck, kf_N).  Returns a dict with the reference's observable effects."""
     cfg = dict(BASE_CFG, **(cfg or {}))
     kf_N = int(sc.get("kf_N", 1)) if kf_N is None else kf_N
-    H, W, K = sc["height"], sc["width"], sc["K"].astype(F)
+    H, W = sc["height"], sc["width"]
+    K = (sc["K"] if K is None else K).astype(F).copy()     # optimize_focal updates it; returned as out["K"]
     n = H * W
     idx = sc["idx_f2k"]
     vm = sc["valid_match"][:, 0]
@@ -273,13 +302,14 @@ def track(sc, cfg=None, covariance_filter=True, min_displacement=30.0, thres_key
     valid_kf = vm & (Qk[:, 0] > cfg["Q_conf"])
     out = dict(lost=False, is_keyframe=False, is_keyframe_map=False, T_WCf=sc["T_WCf0"][0].copy(), iterations=0,
                last_dist=last_dist, kf_X=sc["Xk_canon"], kf_C=sc["Ck"], kf_N=kf_N, n_opt=int(valid_opt.sum()),
-               Xf_c=Xf_c, var_f=var_f, valid_opt=valid_opt, valid_kf=valid_kf, Qk=Qk, meas_k=meas_k, valid_meas_k=valid_meas_k)
+               Xf_c=Xf_c, var_f=var_f, valid_opt=valid_opt, valid_kf=valid_kf, Qk=Qk, meas_k=meas_k, valid_meas_k=valid_meas_k, K=K)
     if F(valid_opt.sum()) / F(n) < cfg["min_match_frac"]:
         out["lost"] = True
         return out
     try:
         T_new, T_CkCf, its = opt_pose_calib_sim3(Xf_c[idx], var_f[idx], T_WCf, T_WCk, Qk, valid_opt[:, None], meas_k, valid_meas_k,
-                                                 K, H, W, cfg, covariance_filter, det_mode, trace=trace)
+                                                 K, H, W, cfg, covariance_filter, det_mode, trace=trace,
+                                                 idx_f2k=idx if optimize_focal else None)
     except np.linalg.LinAlgError:
         out["lost"] = True
         return out

@@ -55,6 +55,9 @@ CASES = {
     "tracker_far": (dict(height=48, width=64, seed=4, fx=70.0, pose_noise=0.12), True, 30.0, 0.0),
     "tracker_newkf": (dict(height=48, width=64, seed=5, fx=70.0, drop_frac=0.75), True, 30.0, 0.0),
     "tracker_lost": (dict(height=48, width=64, seed=6, fx=70.0, drop_frac=0.97), True, 30.0, 0.0),
+    # --optimize_focal (CameraTracker.py:308-320,367-377): the tracker is handed a K whose focal is off by focal_scale
+    "tracker_focal": (dict(height=48, width=64, seed=10, fx=70.0), True, 30.0, 0.0, dict(focal_scale=0.96)),
+    "tracker_focal_nocov": (dict(height=40, width=56, seed=11, fx=60.0, pose_noise=0.02), False, 30.0, 0.0, dict(focal_scale=1.03)),
 }
 
 
@@ -63,7 +66,7 @@ class Keyframes(list):
         return self[-1]
 
 
-def run_case(name, scene_kw, cov_filter, min_disp, last_dist):
+def run_case(name, scene_kw, cov_filter, min_disp, last_dist, focal=None):
     if "kf_pose" in scene_kw:
         kp = scene_kw["kf_pose"].astype(np.float64)
         kp[3:7] /= np.linalg.norm(kp[3:7])
@@ -72,14 +75,19 @@ def run_case(name, scene_kw, cov_filter, min_disp, last_dist):
     H, W = sc["height"], sc["width"]
     from VSLAM.utils_config import load_config  # the reference's own loader (float resolver for "1e-6")
     cfg = load_config(os.path.join(REF, "config", "base.yaml"))
-    args = types.SimpleNamespace(optimize_focal=False, covariance_filter=cov_filter, point_fusion_frontend=True)
+    args = types.SimpleNamespace(optimize_focal=focal is not None, covariance_filter=cov_filter, point_fusion_frontend=True)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    K_in = sc["K"].astype(np.float32).copy()
+    if focal is not None:
+        K_in[0, 0] *= np.float32(focal["focal_scale"])
+        K_in[1, 1] *= np.float32(focal["focal_scale"])
+    K_t = t(K_in.copy())
     keyframe = ImageFrame(0, 0, 0.0, torch.zeros(3, H, W), pypose_stub.Sim3(t(sc["T_WCk"])))
     keyframe.update_pointmap(t(sc["Xk_canon"]), t(sc["Ck"]))
     keyframe.N = keyframe.N_updates = sc["kf_N"]  # Xk_canon / Ck already are the fused state of kf_N predictions
     frame = ImageFrame(1, 0, 0.1, torch.zeros(3, H, W), pypose_stub.Sim3(t(sc["T_WCf0"])))
     kfs = Keyframes([keyframe])
-    trk = CT.CameraTracker(args, cfg, min_disp, 0.8, None, kfs, H, W, t(sc["K"]), "cpu")
+    trk = CT.CameraTracker(args, cfg, min_disp, 0.8, None, kfs, H, W, K_t, "cpu")
     trk.last_dist = last_dist
     trk.last_embedding = [None, None]
 
@@ -104,7 +112,7 @@ def run_case(name, scene_kw, cov_filter, min_disp, last_dist):
     out = {"in_sum_" + k: np.float64(np.asarray(v, dtype=np.float64).sum()) for k, v in sc.items() if isinstance(v, np.ndarray)}
     out.update(scene_kw=np.array(repr({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in scene_kw.items()})),
                height=H, width=W, covariance_filter=cov_filter, min_displacement=min_disp, last_dist_in=last_dist,
-               thres_keyframe=0.8,
+               thres_keyframe=0.8, optimize_focal=focal is not None, K_in=K_in, out_K=trk.K_slam.numpy().copy(),
                out_flags=np.array([bool(lost), bool(is_kf), bool(is_kf_map)]), out_T_WCf=frame.T_WC.tensor().numpy(),
                out_taus=np.stack(taus) if taus else np.zeros((0, 7), np.float32), out_costs=np.array(costs, dtype=np.float64), out_last_dist=np.float64(trk.last_dist),
                out_kf_X=kfs[0].X_canon.numpy(), out_kf_C=kfs[0].C.numpy(), out_kf_N=kfs[0].N,
@@ -116,5 +124,7 @@ def run_case(name, scene_kw, cov_filter, min_disp, last_dist):
 
 
 if __name__ == "__main__":
-    for name, (kw, cov, md, ld) in CASES.items():
-        run_case(name, kw, cov, md, ld)
+    only = sys.argv[1:]
+    for name, case in CASES.items():
+        if not only or name in only:
+            run_case(name, *case)

@@ -64,7 +64,8 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
                               const int64_t* idx_f2k, const uint8_t* valid_match, const float* T_WCf, const float* T_WCk,
                               float sigma_pixel, float sigma_depth, float huber_k, float C_conf, float Q_conf,
                               float min_match_frac, int pixel_border, float depth_eps, float rel_error, float delta_norm,
-                              int max_iters, int covariance_filter, float dist_quantile_q, float* result /* [32] */, float* dbg_Xc,
+                              int max_iters, int covariance_filter, int optimize_focal, float dist_quantile_q, float* result /* [32] */,
+                              float* dbg_Xc,
                               float* dbg_var, uint8_t* dbg_valid_opt, float* dbg_acc0, float* dbg_thr /* [max_iters] */)
 {
     const int n = height * width, H = height, W = width;
@@ -102,6 +103,7 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
         const float zk = Xk_canon[3 * (size_t)k + 2];
         const bool vmeas = zk > g.z_eps;
         for (int a = 0; a < 4; ++a) recA[4 * (size_t)k + a] = Xfc[4 * (size_t)ix + a];
+        if (optimize_focal) { recA[4 * (size_t)k] = (float)(int)(ix % W); recA[4 * (size_t)k + 1] = (float)(int)(ix / W); }
         recB[2 * (size_t)k] = (opt && vmeas) ? sqrtf(q) : 0.f;
         recB[2 * (size_t)k + 1] = vmeas ? logf(zk) : 0.f;
         if (vm && !seen[ix]) { seen[ix] = 1u; counts[2]++; }
@@ -124,13 +126,17 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
     store_pose(Tk, s.Tk);
     s.old_cost = (double)INFINITY;
     s.thr = INFINITY;
+    s.fx = K[0]; s.fy = K[4];
     s.lost = ((float)counts[0] / (float)n < g.min_match_frac) ? 1 : 0;
     s.done = s.lost;
     for (int it = 0; it < max_iters && !s.done; ++it) {
         const Pose T = load_pose(s.T);
+        c.fx = s.fx; c.fy = s.fy;
         if (covariance_filter) {
             for (int k = 0; k < n; ++k) {
-                uint32_t key = float_key(cov_det(T, c, &recA[4 * (size_t)k], recA[4 * (size_t)k + 3]));
+                float X[3] = {recA[4 * (size_t)k], recA[4 * (size_t)k + 1], recA[4 * (size_t)k + 2]}, dX[3];
+                if (optimize_focal) frame_point_focal(c, recA[4 * (size_t)k], recA[4 * (size_t)k + 1], recA[4 * (size_t)k + 2], X, dX);
+                uint32_t key = float_key(cov_det(T, c, X, recA[4 * (size_t)k + 3]));
                 if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
                 keys[k] = key;
             }
@@ -138,20 +144,26 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
             if (dbg_thr) dbg_thr[it] = s.thr;
         }
         // accumulate: one float accumulator set per "workgroup slot" of 256 threads x grid-stride, summed in double
-        double acc[TRK_NACC];
-        for (int l = 0; l < TRK_NACC; ++l) acc[l] = 0.0;
+        const int nacc = optimize_focal ? TRK_NACC8 : TRK_NACC;
+        double acc[TRK_NACC8];
+        for (int l = 0; l < nacc; ++l) acc[l] = 0.0;
         const int chunk = 4096;
         for (int k0 = 0; k0 < n; k0 += chunk) {
-            float part[TRK_NACC];
-            for (int l = 0; l < TRK_NACC; ++l) part[l] = 0.f;
+            float part[TRK_NACC8];
+            for (int l = 0; l < nacc; ++l) part[l] = 0.f;
             for (int k = k0; k < n && k < k0 + chunk; ++k) {
                 const bool det_ok = covariance_filter ? (key_float(keys[k]) < s.thr) : true;
-                point_rows(T, c, g, &recA[4 * (size_t)k], recB[2 * (size_t)k], (float)(k % W), (float)(k / W), recB[2 * (size_t)k + 1], det_ok, part);
+                const float* a = &recA[4 * (size_t)k];
+                if (optimize_focal)
+                    point_rows_focal(T, c, g, a[0], a[1], a[2], recB[2 * (size_t)k], (float)(k % W), (float)(k / W), recB[2 * (size_t)k + 1], det_ok, part);
+                else
+                    point_rows(T, c, g, a, recB[2 * (size_t)k], (float)(k % W), (float)(k / W), recB[2 * (size_t)k + 1], det_ok, part);
             }
-            for (int l = 0; l < TRK_NACC; ++l) acc[l] += (double)part[l];
+            for (int l = 0; l < nacc; ++l) acc[l] += (double)part[l];
         }
-        if (dbg_acc0 && s.iters == 0) for (int l = 0; l < TRK_NACC; ++l) dbg_acc0[l] = (float)acc[l];
-        gn_step(s, acc, g);
+        if (dbg_acc0 && s.iters == 0) for (int l = 0; l < nacc; ++l) dbg_acc0[l] = (float)acc[l];
+        if (optimize_focal) gn_step_focal(s, acc, g);
+        else gn_step(s, acc, g);
     }
     const bool ok = !s.lost && !s.fail;
     if (ok) store_pose(quat2unit(mul(load_pose(s.Tk), load_pose(s.T))), result);
@@ -160,7 +172,8 @@ extern "C" int th_track_frame(int height, int width, const float* K, const float
     result[16] = (float)s.lost; result[17] = (float)s.fail; result[18] = (float)s.iters;
     result[19] = (float)counts[0]; result[20] = (float)counts[1]; result[21] = (float)counts[2];
     result[23] = (float)s.cost; result[24] = (float)s.done; result[25] = s.thr;
-    for (int i = 26; i < 32; ++i) result[i] = 0.f;
+    result[26] = s.fx; result[27] = s.fy;
+    for (int i = 28; i < 32; ++i) result[i] = 0.f;
     return 0;
 }
 

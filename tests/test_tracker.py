@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = ["tracker_cov", "tracker_nocov", "tracker_moved_kf", "tracker_ragged", "tracker_rough", "tracker_kfN3", "tracker_baddepth",
          "tracker_far", "tracker_newkf", "tracker_lost"]
+FOCAL_CASES = ["tracker_focal", "tracker_focal_nocov"]     # --optimize_focal: goldens from the reference run with args.optimize_focal = True
 CFG = dict(TO.BASE_CFG)
 
 
@@ -40,14 +41,24 @@ def load_case(name):
     return sc, d
 
 
+def is_focal(d):
+    return "optimize_focal" in d.files and bool(d["optimize_focal"])
+
+
+def case_K(sc, d):
+    """The K the tracker was handed (the focal cases start from a deliberately wrong focal)."""
+    return np.ascontiguousarray(d["K_in"] if is_focal(d) else sc["K"], dtype=np.float32)
+
+
 def oracle_run(sc, d, det_mode, trace=None):
     return TO.track(sc, covariance_filter=bool(d["covariance_filter"]), min_displacement=float(d["min_displacement"]),
-                    thres_keyframe=float(d["thres_keyframe"]), last_dist=float(d["last_dist_in"]), det_mode=det_mode, trace=trace)
+                    thres_keyframe=float(d["thres_keyframe"]), last_dist=float(d["last_dist_in"]), det_mode=det_mode, trace=trace,
+                    optimize_focal=is_focal(d), K=case_K(sc, d))
 
 
 # ---------------------------------------------------------------------------------- CPU: oracle vs the reference's outputs
 @pytest.mark.parametrize("det_mode", ["lu", "analytic"])
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + FOCAL_CASES)
 def test_oracle_matches_reference_goldens(name, det_mode):
     sc, d = load_case(name)
     tr = []
@@ -101,46 +112,46 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def run_host(host, sc, cov, thres, cfg=CFG, max_iters=None):
+def run_host(host, sc, cov, thres, cfg=CFG, max_iters=None, focal=False, K=None):
     n = sc["height"] * sc["width"]
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-    arrs = dict(K=f(sc["K"]), Xf=f(sc["Xff"]), Cf=f(sc["Cff"]), Qf=f(sc["Qff"]), Xk=f(sc["Xk_canon"]), Ck=f(sc["Ck"]), Qk=f(sc["Qkf"]),
+    arrs = dict(K=f(sc["K"] if K is None else K), Xf=f(sc["Xff"]), Cf=f(sc["Cff"]), Qf=f(sc["Qff"]), Xk=f(sc["Xk_canon"]), Ck=f(sc["Ck"]), Qk=f(sc["Qkf"]),
                 idx=np.ascontiguousarray(sc["idx_f2k"]), vm=np.ascontiguousarray(sc["valid_match"].astype(np.uint8)),
                 Tf=f(sc["T_WCf0"]), Tk=f(sc["T_WCk"]))
     res = np.zeros(32, np.float32)
     mi = int(cfg["max_iters"] if max_iters is None else max_iters)
-    dbg = dict(Xc=np.zeros((n, 3), np.float32), var=np.zeros((n, 3), np.float32), valid_opt=np.zeros(n, np.uint8), acc0=np.zeros(36, np.float32),
+    dbg = dict(Xc=np.zeros((n, 3), np.float32), var=np.zeros((n, 3), np.float32), valid_opt=np.zeros(n, np.uint8), acc0=np.zeros(45, np.float32),
                thr=np.zeros(max(mi, 1), np.float32))
     c_f = ctypes.c_float
     rc = host.th_track_frame(sc["height"], sc["width"], _ptr(arrs["K"]), _ptr(arrs["Xf"]), _ptr(arrs["Cf"]), c_f(1.0), _ptr(arrs["Qf"]),
                              _ptr(arrs["Xk"]), _ptr(arrs["Ck"]), c_f(1.0 / sc["kf_N"]), _ptr(arrs["Qk"]), _ptr(arrs["idx"]), _ptr(arrs["vm"]),
                              _ptr(arrs["Tf"]), _ptr(arrs["Tk"]), c_f(cfg["sigma_pixel"]), c_f(cfg["sigma_depth"]), c_f(cfg["huber"]),
                              c_f(cfg["C_conf"]), c_f(cfg["Q_conf"]), c_f(cfg["min_match_frac"]), int(cfg["pixel_border"]),
-                             c_f(cfg["depth_eps"]), c_f(cfg["rel_error"]), c_f(cfg["delta_norm"]), mi, int(cov), c_f(thres), _ptr(res),
+                             c_f(cfg["depth_eps"]), c_f(cfg["rel_error"]), c_f(cfg["delta_norm"]), mi, int(cov), int(focal), c_f(thres), _ptr(res),
                              _ptr(dbg["Xc"]), _ptr(dbg["var"]), _ptr(dbg["valid_opt"]), _ptr(dbg["acc0"]), _ptr(dbg["thr"]))
     assert rc == 0
     return res, dbg
 
 
-def run_hip(dev, sc, cov, thres, cfg=CFG, max_iters=None, chunk=None):
+def run_hip(dev, sc, cov, thres, cfg=CFG, max_iters=None, chunk=None, focal=False, K=None):
     from artdeco_amd import tracker as T
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     cfg = dict(cfg, max_iters=cfg["max_iters"] if max_iters is None else max_iters)
-    res, dbg = T.track_frame(sc["height"], sc["width"], t(sc["K"]), t(sc["Xff"]), t(sc["Cff"]), 1, t(sc["Qff"]), t(sc["Xk_canon"]),
+    res, dbg = T.track_frame(sc["height"], sc["width"], t(sc["K"] if K is None else K), t(sc["Xff"]), t(sc["Cff"]), 1, t(sc["Qff"]), t(sc["Xk_canon"]),
                              t(sc["Ck"]), sc["kf_N"], t(sc["Qkf"]), t(sc["idx_f2k"]), t(sc["valid_match"]), t(sc["T_WCf0"]), t(sc["T_WCk"]), cfg,
-                             covariance_filter=cov, thres_keyframe=thres, debug=True, chunk=chunk)
+                             covariance_filter=cov, thres_keyframe=thres, debug=True, chunk=chunk, optimize_focal=focal)
     torch.cuda.synchronize()
     return res.cpu().numpy(), {k: v.cpu().numpy() for k, v in dbg.items()}
 
 
-def unpack_acc(acc):
-    H = np.zeros((7, 7))
+def unpack_acc(acc, nv=7):
+    H = np.zeros((nv, nv))
     l = 0
-    for n in range(7):
+    for n in range(nv):
         for m in range(n + 1):
             H[n, m] = H[m, n] = acc[l]
             l += 1
-    return H, -np.asarray(acc[28:35], dtype=np.float64), float(acc[35])  # (H, g = -J^T e, cost) in the reference's convention
+    return H, -np.asarray(acc[l:l + nv], dtype=np.float64), float(acc[l + nv])  # (H, g = -J^T e, cost) in the reference's convention
 
 
 def check_against_oracle_and_golden(name, res, dbg):
@@ -161,7 +172,7 @@ def check_against_oracle_and_golden(name, res, dbg):
         assert np.array_equal(res[0:8], sc["T_WCf0"][0])
         return
     # first linearisation: H, g, cost
-    H, g, cost = unpack_acc(dbg["acc0"])
+    H, g, cost = unpack_acc(dbg["acc0"], 8 if is_focal(d) else 7)
     Ho, go, co = tr[0]["H"], tr[0]["g"], tr[0]["cost"]
     assert np.abs(H - Ho).max() < 2e-4 * np.abs(Ho).max()
     assert np.abs(g - go).max() < 2e-4 * np.abs(go).max()
@@ -172,6 +183,11 @@ def check_against_oracle_and_golden(name, res, dbg):
     assert np.abs(res[8:16] - o["T_CkCf"]).max() < 3e-5
     assert np.abs(res[0:8] - d["out_T_WCf"][0]).max() < 5e-5          # ... and the reference itself
     assert abs(res[23] / d["out_costs"][-1] - 1) < 3e-4
+    if is_focal(d):   # the focal the iterations ended with, against the oracle's and the reference's updated K_slam
+        assert res[26] == res[27]
+        assert abs(res[26] - o["K"][0, 0]) < 2e-5 * o["K"][0, 0] and abs(res[26] - d["out_K"][0, 0]) < 2e-5 * d["out_K"][0, 0]
+    else:
+        assert res[26] == np.float32(sc["K"][0, 0]) and res[27] == np.float32(sc["K"][1, 1])
     # keyframe decisions from the device counts
     from artdeco_amd.tracker import TrackOutcome, keyframe_decisions
     oc = TrackOutcome(None, None, False, False, int(res[18]), int(res[19]), int(res[20]), int(res[21]), float(res[22]), float(res[23]))
@@ -183,10 +199,10 @@ def check_against_oracle_and_golden(name, res, dbg):
 
 
 # ---------------------------------------------------------------------------------- CPU: the kernels' arithmetic on the host
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + FOCAL_CASES)
 def test_host_compiled_kernel_math(name, host):
     sc, d = load_case(name)
-    res, dbg = run_host(host, sc, bool(d["covariance_filter"]), float(d["thres_keyframe"]))
+    res, dbg = run_host(host, sc, bool(d["covariance_filter"]), float(d["thres_keyframe"]), focal=is_focal(d), K=case_K(sc, d))
     check_against_oracle_and_golden(name, res, dbg)
     if name == "tracker_rough":
         tr = []
@@ -262,10 +278,10 @@ def test_tracker_rejects_cpu_tensors():
 
 # ---------------------------------------------------------------------------------- GPU: the HIP path
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + FOCAL_CASES)
 def test_hip_tracker_matches_oracle_and_reference(name, dev, lib):
     sc, d = load_case(name)
-    res, dbg = run_hip(dev, sc, bool(d["covariance_filter"]), float(d["thres_keyframe"]))
+    res, dbg = run_hip(dev, sc, bool(d["covariance_filter"]), float(d["thres_keyframe"]), focal=is_focal(d), K=case_K(sc, d))
     check_against_oracle_and_golden(name, res, dbg)
 
 
@@ -338,7 +354,7 @@ class _Keyframes(list):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + FOCAL_CASES)
 def test_hip_camera_tracker_class_end_to_end(name, dev, lib):
     """CameraTracker.track() as VSLAM/Frontend.py:80 calls it, against the reference's own run of the same frame."""
     from artdeco_amd.tracker import CameraTracker
@@ -355,8 +371,9 @@ def test_hip_camera_tracker_class_end_to_end(name, dev, lib):
         return (t(sc["idx_f2k"])[None], t(sc["valid_match"])[None], t(sc["Xff"]), t(sc["Cff"]), t(sc["Qff"]), t(sc["Xkf"]), t(sc["Ckf"]),
                 t(sc["Qkf"]), "featf", "posf")
 
-    args = types.SimpleNamespace(optimize_focal=False, covariance_filter=bool(d["covariance_filter"]), point_fusion_frontend=True)
-    trk = CameraTracker(args, {"tracking": CFG}, float(d["min_displacement"]), float(d["thres_keyframe"]), None, kfs, H, W, t(sc["K"]), dev,
+    args = types.SimpleNamespace(optimize_focal=is_focal(d), covariance_filter=bool(d["covariance_filter"]), point_fusion_frontend=True)
+    K_slam = t(case_K(sc, d))
+    trk = CameraTracker(args, {"tracking": CFG}, float(d["min_displacement"]), float(d["thres_keyframe"]), None, kfs, H, W, K_slam, dev,
                         match_fn=match)
     trk.last_dist = float(d["last_dist_in"])
     trk.last_embedding = [None, None]
@@ -371,6 +388,10 @@ def test_hip_camera_tracker_class_end_to_end(name, dev, lib):
     assert np.abs(kfs[0].C.cpu().numpy() - d["out_kf_C"]).max() < 1e-5
     if bool(d["out_flags"][1]):
         assert trk.last_embedding == ["featf", "posf"]
+    if is_focal(d):    # the caller's K_slam tensor is updated in place, as the reference does (CameraTracker.py:376-377)
+        assert trk.K_slam is K_slam and np.abs(K_slam.cpu().numpy() - d["out_K"]).max() < 2e-5 * float(d["out_K"][0, 0])
+    else:
+        assert np.array_equal(K_slam.cpu().numpy(), case_K(sc, d))
 
 
 @pytest.mark.gpu
