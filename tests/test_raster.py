@@ -209,6 +209,53 @@ def test_binning_is_bit_exact_at_baseline_sizes(N, W, H, dev):
     assert torch.equal(meta["conics"][0].cpu()[vis], p["conics"][vis])
 
 
+def _binning_outputs(meta):
+    return {k: meta[k].cpu().numpy() for k in ("isect_ids", "flatten_ids", "isect_offsets", "tiles_per_gauss")}
+
+
+@pytest.mark.gpu
+def test_binning_routes_agree_and_survive_a_wrong_capacity_guess(dev, monkeypatch):
+    """The two binning routes (tile-local counting sort + per-tile LDS sort; global two-level radix sort) produce the same
+    bytes, and the tile-local route's pre-launched scatter is correct when its capacity guess is far too small (first frame
+    of a scene / a map that grew by more than 25 %: the scatter is repeated with the exact count) or far too large."""
+    from artdeco_amd import rasterizer
+    N, W, H = 1_000_000, 1920, 1080
+    sc = dict(_scene(N, W, H, 0), viewmat=_tilted_viewmat(1))
+    monkeypatch.setenv("ADK_BIN_LOCAL", "0")
+    ref = _binning_outputs(_run_hip(sc, dev)[2])
+    assert ref["flatten_ids"].size > (1 << 21)
+    monkeypatch.setenv("ADK_BIN_LOCAL", "1")
+    key = (torch.device(dev).index or 0, N, W, H)
+    for hint in (None, 10, 3 * ref["flatten_ids"].size):
+        rasterizer._CAPACITY_HINT.pop(key, None)
+        if hint is not None:
+            rasterizer._CAPACITY_HINT[key] = hint
+        got = _binning_outputs(_run_hip(sc, dev)[2])
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), (hint, k)
+        assert rasterizer._CAPACITY_HINT[key] == ref["flatten_ids"].size
+
+
+@pytest.mark.gpu
+def test_binning_tile_list_longer_than_the_lds_sort(dev):
+    """More than 8192 splats on ONE tile (the in-LDS sort's limit): the forward falls back to the global route for that
+    frame; lists and render still match the oracle."""
+    N, W, H = 9000, 64, 48
+    g = torch.Generator().manual_seed(3)
+    sc = _scene(N, W, H, 4)
+    means = sc["means"].clone()
+    means[:, 0] = 0.02 * torch.randn(N, generator=g)      # everything lands around the principal point
+    means[:, 1] = 0.02 * torch.randn(N, generator=g)
+    sc = dict(sc, means=means, opacities=torch.full((N,), 0.02))
+    ro, ao, ometa = go.rasterization(**sc, eps2d=0.01)
+    counts = np.diff(np.append(ometa["isects"]["offsets"].reshape(-1), ometa["isects"]["n_isects"]))
+    assert counts.max() > 8192
+    r, a, meta, _ = _run_hip(sc, dev)
+    assert np.array_equal(meta["flatten_ids"].cpu().numpy(), ometa["isects"]["flatten_ids"])
+    assert np.array_equal(meta["isect_offsets"][0].cpu().numpy(), ometa["isects"]["offsets"])
+    assert float((r[0].cpu() - ro).abs().max()) <= 2e-3 * float(ro.abs().max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,W,H,window,tilt", [(200_000, 512, 384, (10, 8, 18, 14), 2), (1_000_000, 1920, 1080, (50, 30, 56, 34), 2),
                                                (1_000_000, 1920, 1080, (0, 0, 4, 3), 2),
