@@ -168,7 +168,6 @@ __global__ __launch_bounds__(256) void count_isects_kernel(const int32_t* __rest
 // (the host learns the largest tile together with n_isects, the one value it waits for anyway).
 #define BIN_SLICES 256
 #define BIN_THREADS 1024  // per slice: 16 waves share one LDS histogram (256 slices x 4 waves left most of the chip idle: 89 us -> see DESIGN)
-#define BIN_SORT_SMALL 1024
 #define BIN_SORT_BIG 8192
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec, int N,
@@ -194,49 +193,61 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* _
     for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) row[t] = hist[t];
 }
 
-// thread = tile: exclusive scan down the slices (in place), tile total out
-__global__ __launch_bounds__(256) void bin_colscan_kernel(uint32_t* __restrict__ table, int n_tiles, uint32_t* __restrict__ tile_count)
+// Exclusive scan down the slices (in place) + tile totals.  A workgroup owns 64 tiles x 16 groups of BIN_SLICES / 16 slices: every
+// thread loads its group's counts back to back (the first version walked all 256 slices per thread with 32 workgroups in flight: 39 us
+// of dependent latency), the 16 group sums are scanned through LDS, then the prefixes are written.
+#define BIN_CS_PARTS 16
+__global__ __launch_bounds__(1024) void bin_colscan_kernel(uint32_t* __restrict__ table, int n_tiles, uint32_t* __restrict__ tile_count)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    constexpr int PER = BIN_SLICES / BIN_CS_PARTS;
+    __shared__ uint32_t part[BIN_CS_PARTS][64];
+    const int tl = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    uint32_t c[PER];
+    uint32_t sum = 0;
+    uint32_t* col = table + (int64_t)p * PER * n_tiles + t;
+    if (t < n_tiles) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) c[i] = col[(int64_t)i * n_tiles];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) sum += c[i];
+    }
+    part[p][tl] = sum;
+    __syncthreads();
     if (t >= n_tiles) return;
     uint32_t run = 0;
-    for (int b = 0; b < BIN_SLICES; ++b) {
-        const uint32_t c = table[(int64_t)b * n_tiles + t];
-        table[(int64_t)b * n_tiles + t] = run;
-        run += c;
-    }
-    tile_count[t] = run;
+    for (int q = 0; q < p; ++q) run += part[q][tl];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { col[(int64_t)i * n_tiles] = run; run += c[i]; }
+    if (p == BIN_CS_PARTS - 1) tile_count[t] = run;
 }
 
-// one workgroup: offsets[t] = exclusive scan of tile_count; stats[0] = n_isects, stats[1] = largest tile (int64, device)
+// one workgroup: offsets[t] = exclusive scan of tile_count; stats[0] = n_isects, stats[1] = largest tile (int64, device).
+// Every thread owns a contiguous run of tiles (two passes over it) and the 1024 run sums are scanned once.
 __global__ __launch_bounds__(1024) void bin_tilescan_kernel(const uint32_t* __restrict__ tile_count, int n_tiles, int32_t* __restrict__ offsets,
                                                             int64_t* __restrict__ stats)
 {
     __shared__ uint32_t wsum[16], wmax[16];
-    __shared__ uint32_t carry_s, max_s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { carry_s = 0; max_s = 0; }
+    const int per = (int)ceil_div(n_tiles, 1024);
+    const int i0 = min(n_tiles, (int)threadIdx.x * per), i1 = min(n_tiles, i0 + per);
+    uint32_t sum = 0, mx = 0;
+    for (int i = i0; i < i1; ++i) { const uint32_t v = tile_count[i]; sum += v; mx = max(mx, v); }
+    uint32_t s = sum, m = mx;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(s, o, 64); if (lane >= o) s += u; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if (lane == 63) { wsum[wv] = s; wmax[wv] = m; }
     __syncthreads();
-    for (int b0 = 0; b0 < n_tiles; b0 += 1024) {
-        const int i = b0 + threadIdx.x;
-        const uint32_t v = i < n_tiles ? tile_count[i] : 0u;
-        uint32_t s = v, m = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-        if (lane == 63) { wsum[wv] = s; wmax[wv] = m; }
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wv; ++w) woff += wsum[w];
-        const uint32_t carry = carry_s;
-        if (i < n_tiles) offsets[i] = (int32_t)(carry + woff + s - v);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + s;
-        if (threadIdx.x == 0) { uint32_t mm = max_s; for (int w = 0; w < 16; ++w) mm = max(mm, wmax[w]); max_s = mm; }
-        __syncthreads();
+    uint32_t run = s - sum;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+    for (int i = i0; i < i1; ++i) { offsets[i] = (int32_t)run; run += tile_count[i]; }
+    if (threadIdx.x == 1023) {
+        uint32_t mm = 0;
+        for (int w = 0; w < 16; ++w) mm = max(mm, wmax[w]);
+        stats[0] = (int64_t)run; stats[1] = (int64_t)mm;
     }
-    if (threadIdx.x == 0) { stats[0] = (int64_t)carry_s; stats[1] = (int64_t)max_s; }
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec,
@@ -298,6 +309,100 @@ __global__ __launch_bounds__(256) void bin_tile_sort_kernel(const unsigned long 
         flatten_ids[s + i] = (int32_t)(uint32_t)sk[i];
         if (tile_ids) tile_ids[s + i] = (uint32_t)t;
     }
+}
+
+// ---- the same sort for lists of up to 1024 entries (all of them at the benchmark densities): ONE WAVE per tile, keys in REGISTERS ----
+// The LDS version above pays a workgroup barrier per compare-exchange stage (45 for 512 keys): 74 us for the 8 100 tiles of a 1080p
+// frame.  Here lane l holds keys [l E, (l + 1) E) of a bitonic network over 64 E slots: compare distances below E never leave the lane
+// (plain register compare-exchanges), distances of E .. 32 E are an exchange with lane l ^ d -- quad-perm DPP for d = 1, 2, ds_swizzle for
+// d = 4, 8 (no address register, no memory), v_permlane16/32_swap for d = 16, 32.  No LDS, no barriers, 4 tiles per workgroup.
+template <int D> __device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane);
+template <> __device__ __forceinline__ uint32_t lane_xor<1>(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ uint32_t lane_xor<2>(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ uint32_t lane_xor<4>(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f); }
+template <> __device__ __forceinline__ uint32_t lane_xor<8>(uint32_t x, int) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (8 << 10) | 0x1f); }
+template <> __device__ __forceinline__ uint32_t lane_xor<16>(uint32_t x, int lane) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 sw = __builtin_amdgcn_permlane16_swap(x, x, false, false); // x' odd rows <- y even rows; y' even rows <- x odd rows
+    return (lane & 16) ? sw.x : sw.y;
+}
+template <> __device__ __forceinline__ uint32_t lane_xor<32>(uint32_t x, int lane) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane & 32) ? sw.x : sw.y;
+}
+
+template <int E, int K, int J>
+__device__ __forceinline__ void bitonic_substage(unsigned long long (&v)[E], int lane)
+{
+    constexpr int M = 64 * E;
+    if constexpr (J >= E) {
+        constexpr int D = J / E;
+        const bool lower = (lane & D) == 0;
+        const bool asc = (K >= M) ? true : ((lane & (K / E)) == 0);
+        const bool keep_min = lower == asc;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t plo = lane_xor<D>((uint32_t)v[r], lane), phi = lane_xor<D>((uint32_t)(v[r] >> 32), lane);
+            const unsigned long long p = ((unsigned long long)phi << 32) | plo;
+            const bool lt = v[r] < p;
+            v[r] = (lt != keep_min) ? p : v[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if ((r & J) != 0) continue;
+            const unsigned long long a = v[r], b = v[r | J];
+            const bool asc = (K < E) ? ((r & K) == 0) : ((K >= M) ? true : ((lane & (K / E)) == 0));
+            const bool sw = (a > b) == asc;
+            v[r] = sw ? b : a;
+            v[r | J] = sw ? a : b;
+        }
+    }
+}
+template <int E, int K, int J> struct BitonicSub {
+    static __device__ __forceinline__ void run(unsigned long long (&v)[E], int lane) {
+        bitonic_substage<E, K, J>(v, lane);
+        if constexpr (J > 1) BitonicSub<E, K, J / 2>::run(v, lane);
+    }
+};
+template <int E, int K> struct BitonicStage {
+    static __device__ __forceinline__ void run(unsigned long long (&v)[E], int lane) {
+        BitonicSub<E, K, K / 2>::run(v, lane);
+        if constexpr (K < 64 * E) BitonicStage<E, 2 * K>::run(v, lane);
+    }
+};
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(const unsigned long long* __restrict__ pairs, int64_t s, int n, int lane, uint32_t t,
+                                               int32_t* __restrict__ flatten_ids, uint32_t* __restrict__ tile_ids)
+{
+    unsigned long long v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) { const int i = lane * E + r; v[r] = i < n ? pairs[s + i] : ~0ull; }
+    BitonicStage<E, 2>::run(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = lane * E + r;
+        if (i < n) { flatten_ids[s + i] = (int32_t)(uint32_t)v[r]; if (tile_ids) tile_ids[s + i] = t; }
+    }
+}
+
+#define BIN_SORT_WAVE 1024
+__global__ __launch_bounds__(256) void bin_tile_sort_wave_kernel(const unsigned long long* __restrict__ pairs, const int32_t* __restrict__ offsets,
+                                                                 int n_tiles, int64_t n_isects, int32_t* __restrict__ flatten_ids,
+                                                                 uint32_t* __restrict__ tile_ids)
+{
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int64_t s = offsets[t];
+    const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
+    const int n = (int)(e - s);
+    if (n <= 0 || n > BIN_SORT_WAVE) return;
+    if (n <= 128) wave_sort_tile<2>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
+    else if (n <= 256) wave_sort_tile<4>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
+    else if (n <= 512) wave_sort_tile<8>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
+    else wave_sort_tile<16>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
 }
 
 } // namespace adk
@@ -445,7 +550,7 @@ extern "C" int adk_bin_local_count(int N, const int32_t* tiles_per_gauss, const 
         attr_set = true;
     }
     hipLaunchKernelGGL(bin_count_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), lds, stream, tiles_per_gauss, rec, N, tile_w, tile_h, table);
-    hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, stream, table, n_tiles, tile_count);
+    hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)ceil_div(n_tiles, 64)), dim3(1024), 0, stream, table, n_tiles, tile_count);
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, n_tiles, offsets, stats);
     ADK_RETURN_LAST_ERROR();
 }
@@ -481,11 +586,11 @@ extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width,
     if (max_tile > BIN_SORT_BIG || n_isects >= ((int64_t)1 << 31)) return ADK_EUNSUPPORTED;
     if (!pairs || !flatten_ids) return ADK_EINVAL;
     const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
-    hipLaunchKernelGGL(bin_tile_sort_kernel<BIN_SORT_SMALL>, dim3(n_tiles), dim3(256), 0, stream, (const unsigned long long*)pairs, offsets,
-                       n_tiles, n_isects, 0, flatten_ids, tile_ids);
-    if (max_tile > BIN_SORT_SMALL)
+    hipLaunchKernelGGL(bin_tile_sort_wave_kernel, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, stream, (const unsigned long long*)pairs,
+                       offsets, n_tiles, n_isects, flatten_ids, tile_ids);
+    if (max_tile > BIN_SORT_WAVE)
         hipLaunchKernelGGL(bin_tile_sort_kernel<BIN_SORT_BIG>, dim3(n_tiles), dim3(256), 0, stream, (const unsigned long long*)pairs, offsets,
-                           n_tiles, n_isects, BIN_SORT_SMALL, flatten_ids, tile_ids);
+                           n_tiles, n_isects, BIN_SORT_WAVE, flatten_ids, tile_ids);
     ADK_RETURN_LAST_ERROR();
 }
 
