@@ -166,8 +166,13 @@ __global__ __launch_bounds__(256) void count_isects_kernel(const int32_t* __rest
 // 5 launches, one read of the records per step 1/2, 8 B per intersection written and read twice.  Bit-identical output.
 // Falls back to the global route when the tile histogram does not fit LDS or a tile holds more than BIN_SORT_BIG entries
 // (the host learns the largest tile together with n_isects, the one value it waits for anyway).
+#ifndef BIN_SLICES
 #define BIN_SLICES 256
-#define BIN_THREADS 1024  // per slice: 16 waves share one LDS histogram (256 slices x 4 waves left most of the chip idle: 89 us -> see DESIGN)
+#endif
+#ifndef BIN_THREADS
+#define BIN_THREADS 1024
+#endif
+// per slice: 16 waves share one LDS histogram (256 slices x 4 waves left most of the chip idle: 89 us -> see DESIGN)
 #define BIN_SORT_BIG 8192
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec, int N,
