@@ -267,6 +267,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t*
     __syncthreads();
     const int chunk = (int)ceil_div(N, BIN_SLICES);
     const int g0 = blockIdx.x * chunk, g1 = min(N, g0 + chunk);
+#ifdef BIN_LAB
+    uint32_t lab_acc = 0; int lab_k = 0; (void)lab_acc; (void)lab_k;
+#endif
     for (int g = g0 + threadIdx.x; g < g1; g += BIN_THREADS) {
         if (tiles_per_gauss[g] == 0) continue;
         const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
@@ -277,9 +280,18 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t*
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
                 const uint32_t pos = atomicAdd(&cur[ty * tile_w + tx], 1u);
+#if defined(BIN_LAB) && BIN_LAB == 1   // lab only: atomics without the scattered stores
+                lab_acc += pos;
+#elif defined(BIN_LAB) && BIN_LAB == 2 // lab only: the same number of 8-byte stores, to consecutive addresses per thread
+                if ((int64_t)pos < capacity) pairs[((int64_t)g * 4 + (lab_k++ & 3)) % capacity] = key + pos;
+#else
                 if ((int64_t)pos < capacity) pairs[pos] = key;
+#endif
             }
     }
+#if defined(BIN_LAB) && BIN_LAB == 1
+    if (lab_acc == 0xFFFFFFFFu) pairs[0] = lab_acc;
+#endif
 }
 
 // One workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS.  MAXN = capacity of this
