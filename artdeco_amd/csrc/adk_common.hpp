@@ -106,25 +106,46 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // DPP-modified VALU ops issue at ~1/3.3 of the plain rate on gfx950 (measured, tools/dpp_bench.hip), so
 // instead of 10 independent 4-step row reductions (40 DPP ops) this is a TRANSPOSING butterfly inside each
 // 16-lane row: at every stage a lane keeps one half of its values and ships the other half to its partner
-// (row_mirror, row_half_mirror, quad mirror, quad xor-1), 5 + 3 + 2 + 1 = 11 DPP ops + ~20 selects.
+// (row_mirror, row_half_mirror, quad mirror, quad xor-1): 10 + 5 bank-masked DPP adds for the two bank-level stages,
+// 2 + 1 DPP adds + 6 selects for the two in-quad stages.
 // Afterwards lane `owner lanes` {0,1,2,4,6} (+8 for values 5..9) of each row hold the row sums of values
 // {0,1,2,3,4} (+5); two permlane-swap adds finish the 4 rows.
 // Returns the total of value `slot` (valid in every row's owner lanes); is_owner is true for the 10 lanes
 // of row 0 that should publish it.
+// MEASURED AND REJECTED (round 2, same box A/B): the whole reduction on the otherwise idle matrix cores -- ten chained
+// v_mfma_f32_16x16x4_f32 with the value as A and a one-hot column as B add the 4 lane rows of quantity q into column q of D
+// (exact), 3 adds + 2 permlane swaps finish -- is bit-compatible and 45 % SLOWER (raster bwd 0.60 -> 0.87 ms): the 8-pass
+// MFMAs of the 5 resident waves serialise on the SIMD's one matrix pipe instead of hiding under the other waves' VALU work.
 struct Reduce10 { float value; int slot; bool is_owner; };
+
 __device__ __forceinline__ Reduce10 wave_reduce10(const float (&a)[10], int lane) {
     const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-    float r[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) { // stage 1: row_mirror, class bit 3
-        const float keep = b3 ? a[j + 5] : a[j], send = b3 ? a[j] : a[j + 5];
-        r[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x140, 0xf, 0xf, false));
-    }
-    // stage 2: row_half_mirror, class bit 2: b2=0 keeps r0,r1,r2 ; b2=1 keeps r3,r4
-    const float k0 = b2 ? r[3] : r[0], k1 = b2 ? r[4] : r[1], s0 = b2 ? r[0] : r[3], s1 = b2 ? r[1] : r[4];
-    const float u0 = k0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x141, 0xf, 0xf, false));
-    const float u1 = k1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x141, 0xf, 0xf, false));
-    const float u2 = r[2] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r[2]), 0x141, 0xf, 0xf, false)); // b2=0 lanes only
+    // Stages 1 and 2 exchange whole BANKS (4-lane groups), so the keep / send choice is the DPP bank_mask itself: the lanes
+    // of banks 0,1 (0,2) execute `own + partner` on the registers they keep, the lanes of banks 2,3 (1,3) on the others;
+    // 15 DPP adds and no selects instead of 8 DPP adds + 16 selects.  One asm block: hipcc's hazard recogniser does not
+    // look into inline asm, so the 2 wait states a DPP read needs after a VALU write of the same register are the s_nop 1
+    // in front (the inputs come straight out of the accumulation fmas), the instruction order inside (every read is >= 3
+    // instructions after the write it depends on) and the s_nop 1 behind (the compiler's own DPP ops follow).
+    float r0, r1, r2, r3, r4, u0, u1, u2;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %15, %15 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %16, %16 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %17, %17 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(u0), "=&v"(u1), "=&v"(u2)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]));
     // stage 3: quad mirror [3,2,1,0] (0x1B), class bit 1
     const float k30 = b2 ? (b1 ? u1 : u0) : (b1 ? u2 : u0);
     const float s30 = b2 ? (b1 ? u0 : u1) : (b1 ? u0 : u2);
