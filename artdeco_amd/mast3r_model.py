@@ -17,8 +17,10 @@ dust3r/heads/dpt_head.py:20-57, post-processing dust3r/heads/postprocess.py and
 mast3r/catmlp_dpt_head.py:19-40.  Hyper-parameters of the released checkpoint:
 thirdparty/mast3r/README.md:277.
 
-MI355X specifics: attention goes through torch's fused scaled_dot_product_attention (flash/mem-efficient
-kernels on MFMA) instead of materialising the N x N softmax (blocks.py:105-109); RoPE runs on the HIP
+MI355X specifics: in the fp16-operand inference mode attention runs on the hand-written MFMA kernel of csrc/attention.hip
+(one workgroup per 64 query rows and head, transposed products, LDS transpose reads; 768 tokens fill 192 of the 256 CUs
+where the library flash kernel launches 96 workgroups), otherwise on torch's fused scaled_dot_product_attention; the
+N x N softmax of blocks.py:105-109 is never materialised; RoPE runs on the HIP
 `curope.rope_2d` kernel when the tensors are on the GPU (pure-torch rotation otherwise, pos_embed.py:112-158);
 GEMMs are hipBLASLt (bf16/fp16 under autocast, fp32 otherwise).  Heads run in fp32 like the reference
 (model.py:205).  Inference only (the frontend never trains).
@@ -77,6 +79,19 @@ class RoPE2D(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ blocks
+def _attend(q, k, v):
+    """softmax(q k^T / sqrt(D)) v, returned as [B, N, H*D] (blocks.py:105-109).  fp16 GPU tensors with 64-wide heads (the
+    TF32-class inference mode, every block of the released model) run on the hand-written gfx950 kernel; anything else
+    (CPU, fp32 / bf16 modes, other head sizes) on torch's scaled_dot_product_attention."""
+    if q.is_cuda and q.dtype == torch.float16:
+        from artdeco_amd import attention as _att
+        if _att.supported(q, k, v):
+            return _att.attention(q, k, v)
+    x = F.scaled_dot_product_attention(q, k, v)
+    B, H, N, D = x.shape
+    return x.transpose(1, 2).reshape(B, N, H * D)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None):
         super().__init__()
@@ -106,8 +121,7 @@ class Attention(nn.Module):
         else:
             qkv = qkv5.transpose(1, 3)  # [B,H,3,N,D]
             q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        x = F.scaled_dot_product_attention(q, k, v)  # softmax(q k^T / sqrt(D)) v
-        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+        return self.proj(_attend(q, k, v))
 
 
 class CrossAttention(nn.Module):
@@ -129,8 +143,7 @@ class CrossAttention(nn.Module):
         k = self.projk(key).reshape(B, key.shape[1], H, D).permute(0, 2, 1, 3)
         v = self.projv(value).reshape(B, value.shape[1], H, D).permute(0, 2, 1, 3)
         q, k = self.rope(q, qpos), self.rope(k, kpos)
-        x = F.scaled_dot_product_attention(q, k, v)
-        return self.proj(x.transpose(1, 2).reshape(B, Nq, C))
+        return self.proj(_attend(q, k, v))
 
 
 class Block(nn.Module):

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 7
+#define ADK_ABI_VERSION 8
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -229,6 +229,17 @@ int adk_refine_matches(const void* D11, const void* D21, const int64_t* p1, int 
  * positions [B,N,2] int64 (y, x); fwd = +F0 forward, -F0 backward (curope2d.py:20,27). */
 int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, int B, int N, int64_t stride_b,
                 int64_t stride_n, int H, int D, float base, float fwd, adk_stream_t stream);
+
+/* -------------------------------------------------------------------- attention
+ * Replaces the attention of the MASt3R blocks -- VSLAM/thirdparty/mast3r/dust3r/croco/models/blocks.py:97-111 (self:
+ * `attn = (q @ k.transpose(-2, -1)) * self.scale; attn = attn.softmax(dim=-1); x = (attn @ v).transpose(1, 2).reshape(B, N, C)`)
+ * and :138-157 (cross, same arithmetic on separate q / k / v projections).  Head dim 64, float16 operands, float32 scores,
+ * softmax and accumulation.  q [B,H,Nq,64], k / v [B,H,Nk,64] as base pointers + ELEMENT strides {batch, head, token} (last
+ * dim dense; the model passes views of its fused qkv projection), out [B,Nq,H,64] contiguous, i.e. already the
+ * `.transpose(1, 2).reshape(B, N, C)` of blocks.py:109.  Strides multiples of 8, pointers 16-byte aligned. */
+int adk_attention_fwd_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk,
+                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
+                          adk_stream_t stream);
 
 /* -------------------------------------------------------------------- simple-knn
  * Exact K nearest neighbours, squared distances, self excluded by index.  Workspace sized by the
