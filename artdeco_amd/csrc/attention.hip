@@ -7,8 +7,8 @@
 // workgroups for 256 CUs and takes 34 us per call, 72 calls per tracked frame (profiles/r02_frontend_kernel_stats.csv).
 //
 // Design (gfx950, wave64, v_mfma_f32_16x16x32_f16):
-//   * workgroup = 4 waves = 64 query rows of one (batch, head); wave w owns 16 query rows; 12 x 16 = 192 workgroups at
-//     768 tokens / 16 heads -- one per CU, one wave per SIMD;
+//   * workgroup = 64 query rows of one (batch, head), wave w of each 4-wave group owns 16 query rows; 12 x 16 = 192
+//     workgroups at 768 tokens / 16 heads -- one per CU; up to 3 wave groups per workgroup split the key tiles (below);
 //   * K / V are walked in tiles of 64 keys, staged once per workgroup in LDS (row pitch 144 B for K: the 16 rows a
 //     ds_read_b128 fragment load touches land on 16 different 4-bank slots; 160 B for V: conflict-free for the
 //     transposing reads), the next tile's global loads in flight in registers while the current one is consumed;
@@ -46,6 +46,11 @@ struct AttnArgs {
     float scale_log2e;
 };
 
+__device__ __forceinline__ float att_max3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
 __device__ __forceinline__ float att_xor_max(float v) { // max over lanes c, c+16, c+32, c+48
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -61,11 +66,19 @@ __device__ __forceinline__ float att_xor_sum(float v) {
     return __uint_as_float(sw.x) + __uint_as_float(sw.y);
 }
 
-__global__ __launch_bounds__(256) void attention_fwd_f16_kernel(AttnArgs a)
+// NSPLIT wave groups of 4 waves share the 64 query rows and split the KEY tiles between them (group s takes tiles s, s +
+// NSPLIT, ...).  Measured on MI355X at 768 x 768 x 16 heads (tools/lab/att_bench.py, hipGraph of 200 calls): one group
+// 15.5 us -- ~0.9 us per tile whatever the instruction count, i.e. the L2 latency of the one K/V tile a group has in flight;
+// two groups 11.6, three 11.0 (a fourth changes nothing: 3 waves per SIMD already saturate VALU + MFMA issue), 2.4 us of
+// which are launch + first-tile latency + the merge.  torch's scaled_dot_product_attention + the layout copy: 30.5 us.
+// The groups' (m, l, O) triples are merged through LDS at the end.
+template <int NSPLIT>
+__global__ __launch_bounds__(256 * NSPLIT) void attention_fwd_f16_kernel(AttnArgs a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 sk[ATT_KB * ATT_KP];
-    __shared__ __attribute__((aligned(16))) _Float16 sv[ATT_KB * ATT_VP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[NSPLIT * ATT_KB * (ATT_KP + ATT_VP)];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    _Float16* const sk = smem + grp * ATT_KB * (ATT_KP + ATT_VP);
+    _Float16* const sv = sk + ATT_KB * ATT_KP;
     const int g = lane >> 4, c = lane & 15;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * ATT_QB + wave * 16;
@@ -112,23 +125,39 @@ __global__ __launch_bounds__(256) void attention_fwd_f16_kernel(AttnArgs a)
     float m_run = -INFINITY, l_run = 0.f; // running max (raw score units) and this lane's share of the running sum
 
     const int n_tiles = (a.Nk + ATT_KB - 1) / ATT_KB;
-    fetch(0);
-    stash();
+    const int n_rounds = (n_tiles + NSPLIT - 1) / NSPLIT; // every group runs every round's barriers; a group without a tile idles
+    if (grp < n_tiles) { fetch(grp * ATT_KB); stash(); }
     __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        if (t + 1 < n_tiles) fetch((t + 1) * ATT_KB);
+    for (int round = 0; round < n_rounds; ++round) {
+        const int t = round * NSPLIT + grp;
+        const bool have = t < n_tiles, have_next = t + NSPLIT < n_tiles;
+        if (have_next) fetch((t + NSPLIT) * ATT_KB);
+        if (have) {
 
-        // ---- S^T = K Q^T: st[kb][r] = <K[16 kb + 4 g + r], Q[c]>
+        // ---- S^T = K Q^T: st[kb][r] = <K[16 kb + 4 g + r], Q[c]>.  All 8 K fragments are requested before the first MFMA and
+        // all 16 V fragments right behind the MFMAs (the sched_barriers keep hipcc from sinking each read in front of its
+        // consumer, which serialised every MFMA behind a full LDS latency): the V reads land while the softmax runs.
+        att_f16x8 kf[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = *reinterpret_cast<const att_f16x8*>(kfrag + 16 * kb * ATT_KP + 32 * ks);
+        __builtin_amdgcn_sched_barrier(0);
         att_f32x4 st[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            st[kb] = att_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const att_f16x8 kf = *reinterpret_cast<const att_f16x8*>(kfrag + 16 * kb * ATT_KP + 32 * ks);
-                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], st[kb], 0, 0, 0);
-            }
+            st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[0], att_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[1], st[kb], 0, 0, 0);
         }
+        att_s16x4 vr[4][2][2]; // [db][s][half]: V[key 32 s + 16 half + 4 g + j][d = 16 db + c], j = 0..3
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    vr[db][s][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vfrag + (32 * s + 16 * hf) * ATT_VP + 16 * db));
+        __builtin_amdgcn_sched_barrier(0);
         if ((t + 1) * ATT_KB > a.Nk) { // ragged last tile: keys past the end get -inf
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
@@ -138,53 +167,84 @@ __global__ __launch_bounds__(256) void attention_fwd_f16_kernel(AttnArgs a)
         }
 
         // ---- online softmax (per query = per lane & 15; the 4 lane groups share the row)
-        float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-        for (int kb = 1; kb < 4; ++kb) tmax = fmaxf(tmax, fmaxf(fmaxf(st[kb][0], st[kb][1]), fmaxf(st[kb][2], st[kb][3])));
-        tmax = att_xor_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2e);
+        // 16 scores + the running max through v_max3_f32 (fmaxf() would canonicalise every MFMA result with a v_max x, x first)
+        float tmax = att_max3(att_max3(st[0][0], st[0][1], st[0][2]), att_max3(st[0][3], st[1][0], st[1][1]),
+                              att_max3(st[1][2], st[1][3], st[2][0]));
+        tmax = att_max3(tmax, att_max3(st[2][1], st[2][2], st[2][3]), att_max3(st[3][0], st[3][1], st[3][2]));
+        tmax = att_xor_max(att_max3(tmax, st[3][3], m_run));
+        const float m_new = tmax; // >= m_run
         const float neg_m = -m_new * a.scale_log2e;
+        // the rescale of O and l is skipped while no row of the wave raised its maximum (alpha == 1 exactly)
+        const bool grew = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull;
+        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2e) : 1.0f;
         m_run = m_new;
-        float psum = 0.f;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
         att_f16x8 pf[2]; // P^T fragments: pf[s][e] = P[c][key 32 s + 4 g + e] (e < 4), P[c][key 32 s + 16 + 4 g + e - 4] (e >= 4)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(st[kb][r], a.scale_log2e, neg_m));
-                psum += p;
+                ps[r] += p;
                 pf[kb >> 1][(kb & 1) * 4 + r] = (_Float16)p;
             }
-        l_run = l_run * alpha + psum;
+        if (grew) {
+            l_run *= alpha;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) ot[db] *= alpha;
+            for (int db = 0; db < 4; ++db) ot[db] *= alpha;
+        }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const att_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4*)(vfrag + (32 * s) * ATT_VP + 16 * db));
-                const att_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4*)(vfrag + (32 * s + 16) * ATT_VP + 16 * db));
-                att_f16x8 vf;
-                const att_f16x4 lo_h = __builtin_bit_cast(att_f16x4, lo), hi_h = __builtin_bit_cast(att_f16x4, hi);
-                vf[0] = lo_h[0]; vf[1] = lo_h[1]; vf[2] = lo_h[2]; vf[3] = lo_h[3];
-                vf[4] = hi_h[0]; vf[5] = hi_h[1]; vf[6] = hi_h[2]; vf[7] = hi_h[3];
+                const att_f16x4 lo_h = __builtin_bit_cast(att_f16x4, vr[db][s][0]), hi_h = __builtin_bit_cast(att_f16x4, vr[db][s][1]);
+                const att_f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
                 ot[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s], ot[db], 0, 0, 0);
             }
 
-        __syncthreads(); // every wave is done with this tile
-        if (t + 1 < n_tiles) {
-            stash();
+        } // have
+        __syncthreads(); // every wave is done with this round's tiles
+        if (round + 1 < n_rounds) {
+            if (have_next) stash();
             __syncthreads();
         }
     }
 
+    // ---- merge the groups: groups 1.. publish (m, row sum, O^T), group 0 folds them in (the tiles are dead: smem is reused)
+    float l_tot = att_xor_sum(l_run);
+    if (NSPLIT > 1) {
+        float* const mbuf = reinterpret_cast<float*>(smem); // [group - 1][18][256]
+        if (grp > 0) {
+            float* mb = mbuf + (grp - 1) * 18 * 256 + tid;
+            mb[0] = m_run; mb[256] = l_tot;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mb[(2 + 4 * db + r) * 256] = ot[db][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int s2 = 1; s2 < NSPLIT; ++s2) {
+            const float* mb = mbuf + (s2 - 1) * 18 * 256 + tid;
+            const float m2 = mb[0], l2 = mb[256];
+            const float m_new = fmaxf(m_run, m2);
+            const float a1 = __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2e);
+            const float a2 = __builtin_amdgcn_exp2f((m2 - m_new) * a.scale_log2e); // a group that never had a tile: m2 = -inf -> 0
+            m_run = m_new;
+            l_tot = l_tot * a1 + l2 * a2;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[db][r] = ot[db][r] * a1 + mb[(2 + 4 * db + r) * 256] * a2;
+        }
+    }
+
     // ---- normalise and store: out [B, Nq, H, 64]; this lane holds d = 16 db + 4 g + 0..3 of query q0 + c
-    const float inv = __builtin_amdgcn_rcpf(att_xor_sum(l_run));
+    const float inv = __builtin_amdgcn_rcpf(l_tot);
     const int qrow = q0 + c;
     if (qrow < a.Nq) {
         _Float16* op = a.out + (((int64_t)b * a.Nq + qrow) * a.H + h) * ATT_D + 4 * g;
@@ -220,6 +280,13 @@ extern "C" int adk_attention_fwd_f16(const void* q, const void* k, const void* v
     a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
     a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
     a.scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(adk::attention_fwd_f16_kernel, dim3((Nq + ATT_QB - 1) / ATT_QB, H, B), dim3(256), 0, stream, a);
+    const dim3 grid((Nq + ATT_QB - 1) / ATT_QB, H, B);
+    const int n_tiles = (Nk + ATT_KB - 1) / ATT_KB;
+    if (n_tiles >= 6)
+        hipLaunchKernelGGL(adk::attention_fwd_f16_kernel<3>, grid, dim3(768), 0, stream, a);
+    else if (n_tiles >= 2)
+        hipLaunchKernelGGL(adk::attention_fwd_f16_kernel<2>, grid, dim3(512), 0, stream, a);
+    else
+        hipLaunchKernelGGL(adk::attention_fwd_f16_kernel<1>, grid, dim3(256), 0, stream, a);
     ADK_RETURN_LAST_ERROR();
 }
