@@ -176,6 +176,15 @@ class DecoderBlock(nn.Module):
         x = x + self.cross_attn(self.norm2(x), y_, y_, xpos, ypos)
         return x + self.mlp(self.norm3(x)), y
 
+    def fused_tail(self, x, x_n1, mem, xpos, ypos):
+        """The block from its first sub-layer on, given x (fp32, complete), x_n1 = norm1(x) and mem = norm_y(y) as fp16
+        operands: returns (x after the cross-attention residual, the MLP output still to be added) -- the caller folds that
+        last add into the next LayerNorm launch (artdeco_amd/fused_norm.py)."""
+        from artdeco_amd.fused_norm import add_layernorm
+        x, x_n2 = add_layernorm(x, self.attn(x_n1, xpos), self.norm2)
+        x, x_n3 = add_layernorm(x, self.cross_attn(x_n2, mem, mem, xpos, ypos), self.norm3)
+        return x, self.mlp(x_n3)
+
 
 class PatchEmbed(nn.Module):
     def __init__(self, patch_size, embed_dim):
@@ -372,10 +381,27 @@ class AsymmetricMASt3R(nn.Module):
         ckpt = {k: v for k, v in ckpt.items() if not k.startswith("prediction_head")}
         return super().load_state_dict(ckpt, **kw)
 
+    def _fused_norms(self, x) -> bool:
+        """TF32-class mode on the GPU: residual add + LayerNorm + operand cast run as one HIP launch per sub-layer
+        (ADK_MAST3R_FUSED_NORM=0 keeps the three torch kernels, for A/B measurements and the equivalence test)."""
+        import os
+        return bool(getattr(self, "_fp32_stream", False) and x.is_cuda and self.patch_embed.proj.weight.dtype == torch.float16
+                    and os.environ.get("ADK_MAST3R_FUSED_NORM", "1") != "0")
+
     def _encode_image(self, image, true_shape=None):
         x, pos = self.patch_embed(image.to(self.patch_embed.proj.weight.dtype), true_shape)
         if getattr(self, "_fp32_stream", False):
             x = x.float()   # the residual stream, the LayerNorms and the softmax stay fp32; only GEMM operands are narrow
+        if self._fused_norms(x):
+            from artdeco_amd.fused_norm import add_layernorm
+            x = x.contiguous()
+            pend = None  # the previous sub-layer's output, added inside the next LayerNorm launch
+            for blk in self.enc_blocks:
+                x, xn = add_layernorm(x, pend, blk.norm1)
+                x, xn = add_layernorm(x, blk.attn(xn, pos), blk.norm2)
+                pend = blk.mlp(xn)
+            _, feat = add_layernorm(x, pend, self.enc_norm, out_f16=False)
+            return feat, pos, None
         for blk in self.enc_blocks:
             x = blk(x, pos)
         return self.enc_norm(x), pos, None
@@ -388,6 +414,8 @@ class AsymmetricMASt3R(nn.Module):
             f1, f2 = f1.float(), f2.float()
         final.append((f1, f2))
         side = self._side_stream(f1)
+        if self._fused_norms(f1):
+            return self._decoder_fused(final, f1.contiguous(), pos1, f2.contiguous(), pos2, side)
         for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
             a, b = final[-1]
             if side is None:
@@ -406,6 +434,37 @@ class AsymmetricMASt3R(nn.Module):
             final.append((n1, n2))
         del final[1]
         final[-1] = (self.dec_norm(final[-1][0]), self.dec_norm(final[-1][1]))
+        return zip(*final)
+
+    def _decoder_fused(self, final, a, pos1, b, pos2, side):
+        """_decoder's loop with every residual add folded into the LayerNorm launch that follows it.  (a, pa) / (b, pb): the
+        two branches' streams and the MLP outputs still to be added to them; a level's complete outputs exist from the next
+        level's first launch on, which is also where `final` collects them for the heads' hooks."""
+        from artdeco_amd.fused_norm import add_layernorm
+        pa = pb = None
+        main = torch.cuda.current_stream(a.device)
+        for lvl, (blk1, blk2) in enumerate(zip(self.dec_blocks, self.dec_blocks2)):
+            a, a_n1 = add_layernorm(a, pa, blk1.norm1)
+            b, b_n1 = add_layernorm(b, pb, blk2.norm1)
+            if lvl > 0:
+                final.append((a, b))
+            mem1 = add_layernorm(b, None, blk1.norm_y)[1]  # branch 1 attends to view 2's tokens
+            mem2 = add_layernorm(a, None, blk2.norm_y)[1]
+            if side is None:
+                a, pa = blk1.fused_tail(a, a_n1, mem1, pos1, pos2)
+                b, pb = blk2.fused_tail(b, b_n1, mem2, pos2, pos1)
+            else:
+                side.wait_stream(main)
+                a, pa = blk1.fused_tail(a, a_n1, mem1, pos1, pos2)
+                with torch.cuda.stream(side):
+                    b, pb = blk2.fused_tail(b, b_n1, mem2, pos2, pos1)
+                main.wait_stream(side)
+                b.record_stream(main)
+                pb.record_stream(main)
+        o1 = add_layernorm(a, pa, self.dec_norm, out_f16=False)[1]
+        o2 = add_layernorm(b, pb, self.dec_norm, out_f16=False)[1]
+        final.append((o1, o2))
+        del final[1]
         return zip(*final)
 
     def _side_stream(self, t):

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 8
+#define ADK_ABI_VERSION 9
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -240,6 +240,14 @@ int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, int B, int N,
 int adk_attention_fwd_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk,
                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
                           adk_stream_t stream);
+
+/* Replaces the `x = x + f(norm(x))` glue of the MASt3R blocks -- croco/models/blocks.py:88-95 (Block.forward) and
+ * :176-191 (DecoderBlock.forward): residual add, nn.LayerNorm(eps=1e-6) and the cast of its output to the GEMM operand type.
+ * x_in [rows,C] float32; delta [rows,C] float16 or NULL; gamma / beta [C] float32.  With delta: x_out [rows,C] float32 (may be
+ * x_in) = x_in + delta and y = LayerNorm(x_out); without: y = LayerNorm(x_in), x_out ignored.  y_out [rows,C] float16 when
+ * y_f16 != 0, else float32.  Biased variance, fp32 statistics.  C % 4 == 0, C <= 2048. */
+int adk_add_layernorm(const float* x_in, const void* delta, const float* gamma, const float* beta, float eps, int rows, int C,
+                      float* x_out, void* y_out, int y_f16, adk_stream_t stream);
 
 /* -------------------------------------------------------------------- simple-knn
  * Exact K nearest neighbours, squared distances, self excluded by index.  Workspace sized by the
