@@ -48,8 +48,8 @@ class RoPE2D(nn.Module):
         if tokens.is_cuda and tokens.dtype in (torch.float32, torch.float16, torch.bfloat16):
             view = tokens.transpose(1, 2)  # [B,N,H,D]
             if view.stride(3) == 1 and view.stride(2) == view.shape[3]:
-                import curope  # drop-in HIP kernel (artdeco_amd/dropin/curope.py)
-                curope.rope_2d(view, positions.contiguous(), self.base, self.F0)
+                import curope  # drop-in HIP kernel (artdeco_amd/dropin/curope.py); trigonometry cached per positions tensor
+                curope.rope_2d_cached(view, positions.contiguous(), self.base, self.F0)
                 return tokens
         return self._torch(tokens, positions)
 
@@ -60,7 +60,7 @@ class RoPE2D(nn.Module):
         B, N, _, H, D = qkv5.shape
         import curope
         qk = qkv5.as_strided((B, N, 2 * H, D), (N * 3 * H * D, 3 * H * D, D, 1))
-        curope.rope_2d(qk, positions.contiguous(), self.base, self.F0)
+        curope.rope_2d_cached(qk, positions.contiguous(), self.base, self.F0)
         return True
 
     def _torch(self, tokens, positions):
@@ -134,14 +134,30 @@ class CrossAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.rope = rope
 
+    def _stacked_kv(self):
+        """[projk; projv] weight and bias, rebuilt whenever either parameter was replaced, cast or edited in place (inference only)."""
+        ps = (self.projk.weight, self.projk.bias, self.projv.weight, self.projv.bias)
+        key = tuple((p.data_ptr(), -1 if p.is_inference() else p._version, p.dtype, p.device) for p in ps)
+        if getattr(self, "_kv_key", None) != key:
+            with torch.no_grad():
+                self._kv = (torch.cat([ps[0], ps[2]], 0).contiguous(), torch.cat([ps[1], ps[3]], 0).contiguous())
+            self._kv_key = key
+        return self._kv
+
     def forward(self, query, key, value, qpos, kpos):
         B, Nq, C = query.shape
         H, D = self.num_heads, C // self.num_heads
         wd = self.projq.weight.dtype
         query, key, value = query.to(wd), key.to(wd), value.to(wd)
         q = self.projq(query).reshape(B, Nq, H, D).permute(0, 2, 1, 3)
-        k = self.projk(key).reshape(B, key.shape[1], H, D).permute(0, 2, 1, 3)
-        v = self.projv(value).reshape(B, value.shape[1], H, D).permute(0, 2, 1, 3)
+        if key is value and not torch.is_grad_enabled() and key.is_cuda:
+            # the decoder passes the same normalised memory as key and value (blocks.py:188): ONE GEMM against the stacked
+            # projk / projv weights (at 768 tokens every launch costs ~12 us whatever its size), k and v as views of its output
+            kv = F.linear(key, *self._stacked_kv()).reshape(B, key.shape[1], 2, H, D)
+            k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+        else:
+            k = self.projk(key).reshape(B, key.shape[1], H, D).permute(0, 2, 1, 3)
+            v = self.projv(value).reshape(B, value.shape[1], H, D).permute(0, 2, 1, 3)
         q, k = self.rope(q, qpos), self.rope(k, kpos)
         return self.proj(_attend(q, k, v))
 

@@ -233,9 +233,22 @@ def main():
     ap.add_argument("--dtype", default="tf32eq", choices=["tf32eq", "bf16", "fp16", "fp32"])
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one hipGraph")
+    ap.add_argument("--tune-gemms", default=None, metavar="CSV",
+                    help="let torch's TunableOp time every hipBLASLt / rocBLAS solution for the model's GEMM shapes during warm-up and write the winners to CSV")
+    ap.add_argument("--gemm-table", default=None, metavar="CSV", help="use the GEMM solutions recorded in CSV (no tuning)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
+    if args.tune_gemms or args.gemm_table:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(bool(args.tune_gemms))
+        tunable.set_filename(args.tune_gemms or args.gemm_table)
+        if args.tune_gemms:
+            tunable.set_max_tuning_duration(30)
+            tunable.set_max_tuning_iterations(20)
+        else:
+            tunable.read_file(args.gemm_table)
     net = vit_large().to(dev).eval()
     img1 = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
     img2 = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 9
+#define ADK_ABI_VERSION 10
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -229,6 +229,14 @@ int adk_refine_matches(const void* D11, const void* D21, const int64_t* p1, int 
  * positions [B,N,2] int64 (y, x); fwd = +F0 forward, -F0 backward (curope2d.py:20,27). */
 int adk_rope_2d(void* tokens, const int64_t* positions, int dtype, int B, int N, int64_t stride_b,
                 int64_t stride_n, int H, int D, float base, float fwd, adk_stream_t stream);
+
+/* The same rotation split in two: every block of the model rotates q and k by the SAME positions, so the powf / cosf / sinf of
+ * kernels.cu:38-44 are evaluated once into table [B*N][2 (y, x)][D/4][2 (cos, sin)] float32 (adk_rope_2d_table, the identical
+ * fp32 expressions) and adk_rope_2d_apply streams the tokens through it: results bit-identical to adk_rope_2d.
+ * apply: D % 16 == 0, strides multiples of 4 elements. */
+int adk_rope_2d_table(const int64_t* positions, int64_t n_tokens, int D, float base, float fwd, float* table, adk_stream_t stream);
+int adk_rope_2d_apply(void* tokens, const float* table, int dtype, int B, int N, int64_t stride_b, int64_t stride_n, int H, int D,
+                      adk_stream_t stream);
 
 /* -------------------------------------------------------------------- attention
  * Replaces the attention of the MASt3R blocks -- VSLAM/thirdparty/mast3r/dust3r/croco/models/blocks.py:97-111 (self:

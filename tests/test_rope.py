@@ -79,3 +79,35 @@ def test_strided_qkv_view_like_the_reference_wrapper(dev):
     assert np.abs(dq.cpu().numpy() - ref).max() < 2e-5       # q and v slices untouched, k rotated
     with pytest.raises(RuntimeError):
         curope.rope_2d(torch.randn(1, 4, 10, 64, device=dev).transpose(1, 2), pos[:1].to(dev), 100.0, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,H,D", [(1, 768, 32, 64), (2, 100, 12, 64), (3, 33, 2, 48), (1, 7, 3, 20)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_cached_table_variant_is_bit_identical(B, N, H, D, dtype, dev):
+    """rope_2d_cached (table built once per positions tensor, streaming apply) == rope_2d, bit for bit, on dense tensors and on
+    the strided q/k view of a fused qkv projection; a positions tensor edited in place gets a new table."""
+    import curope
+    g = torch.Generator().manual_seed(N + D)
+    pos = torch.randint(0, 32, (B, N, 2), generator=g).to(dev)
+    big = torch.randn(B, N, 3 * H * D, generator=g).to(dtype).to(dev)
+    for view_of in ("dense", "strided"):
+        if view_of == "dense":
+            a = torch.randn(B, N, H, D, generator=g).to(dtype).to(dev)
+            b = a.clone()
+        else:
+            a = big.clone().as_strided((B, N, H, D), (N * 3 * H * D, 3 * H * D, D, 1))
+            b = big.clone().as_strided((B, N, H, D), (N * 3 * H * D, 3 * H * D, D, 1))
+        curope.rope_2d(a, pos, 100.0, 1.0)
+        curope.rope_2d_cached(b, pos, 100.0, 1.0)
+        curope.rope_2d_cached(b, pos, 100.0, -1.0)   # a second table (fwd = -1) ...
+        curope.rope_2d_cached(b, pos, 100.0, 1.0)    # ... and the first one again, from the cache
+        curope.rope_2d(a, pos, 100.0, -1.0)
+        curope.rope_2d(a, pos, 100.0, 1.0)
+        assert torch.equal(a, b)
+    pos.add_(1)                                       # same storage, new contents: the version counter invalidates the table
+    a = torch.randn(B, N, H, D, generator=g).to(dtype).to(dev)
+    b = a.clone()
+    curope.rope_2d(a, pos, 100.0, 1.0)
+    curope.rope_2d_cached(b, pos, 100.0, 1.0)
+    assert torch.equal(a, b)
