@@ -542,6 +542,10 @@ class AsymmetricMASt3R(nn.Module):
                 for m in head.modules():
                     if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
                         m.to(dtype)
+                # the DPT adapter's inputs are token-major [B, N, C] activations viewed as [B, C, h, w], i.e. ALREADY channels-last
+                # in memory: with channels-last weights MIOpen picks NHWC kernels and the layout transposes around every
+                # convolution disappear (tracked frame 8.09 -> 7.71 ms)
+                head.dpt.to(memory_format=torch.channels_last)
         return self
 
     @torch.inference_mode()
