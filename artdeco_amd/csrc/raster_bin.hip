@@ -294,40 +294,6 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t*
 #endif
 }
 
-// One workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS.  MAXN = capacity of this
-// instantiation; tiles outside (lo, MAXN] are left to the other instantiation.
-template <int MAXN>
-__global__ __launch_bounds__(256) void bin_tile_sort_kernel(const unsigned long long* __restrict__ pairs, const int32_t* __restrict__ offsets,
-                                                            int n_tiles, int64_t n_isects, int lo, int32_t* __restrict__ flatten_ids,
-                                                            uint32_t* __restrict__ tile_ids)
-{
-    __shared__ unsigned long long sk[MAXN];
-    const int t = blockIdx.x;
-    const int64_t s = offsets[t];
-    const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
-    const int n = (int)(e - s);
-    if (n <= lo || n > MAXN) return;
-    int m = 1;
-    while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 256) sk[i] = i < n ? pairs[s + i] : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < (m >> 1); i += 256) {
-                const int l = 2 * i - (i & (j - 1)); // lower index of the i-th compare-exchange pair at distance j
-                const unsigned long long a = sk[l], b = sk[l + j];
-                const bool asc = (l & k) == 0;
-                if ((a > b) == asc) { sk[l] = b; sk[l + j] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < n; i += 256) {
-        flatten_ids[s + i] = (int32_t)(uint32_t)sk[i];
-        if (tile_ids) tile_ids[s + i] = (uint32_t)t;
-    }
-}
-
 // ---- the same sort for lists of up to 1024 entries (all of them at the benchmark densities): ONE WAVE per tile, keys in REGISTERS ----
 // The LDS version above pays a workgroup barrier per compare-exchange stage (45 for 512 keys): 74 us for the 8 100 tiles of a 1080p
 // frame.  Here lane l holds keys [l E, (l + 1) E) of a bitonic network over 64 E slots: compare distances below E never leave the lane
@@ -420,6 +386,76 @@ __global__ __launch_bounds__(256) void bin_tile_sort_wave_kernel(const unsigned 
     else if (n <= 256) wave_sort_tile<4>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
     else if (n <= 512) wave_sort_tile<8>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
     else wave_sort_tile<16>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
+}
+
+// ---- lists of 1025 .. 8192 entries (1 M Gaussians on a 512x384 frame: every tile): the SAME register network, 1024 keys per wave,
+// up to 8 waves per tile.  Wave c sorts chunk c in registers -- ascending for even c, descending for odd c (the ascending network run
+// on the bitwise complements), i.e. exactly the state a 64 x 16 x C bitonic network is in after its K = 1024 stage; the remaining
+// stages K = 2048 .. m then need, per stage, log2(K / 1024) compare-exchanges BETWEEN chunks (same position, partner chunk c ^ J /
+// 1024: one round trip through LDS each) followed by the in-register merge J = 512 .. 1.  6 LDS exchanges + 12 workgroup barriers for
+// 8192 keys, where a plain LDS bitonic sort (256 threads, one barrier per compare-exchange stage: 91 of them) took 332 us for the
+// 768 tiles of that frame -- 20 % of the mapper step.
+__global__ __launch_bounds__(512) void bin_tile_sort_merge_kernel(const unsigned long long* __restrict__ pairs, const int32_t* __restrict__ offsets,
+                                                                  int n_tiles, int64_t n_isects, int32_t* __restrict__ flatten_ids,
+                                                                  uint32_t* __restrict__ tile_ids)
+{
+    constexpr int E = 16, CH = 64 * E; // keys per lane, keys per wave
+    __shared__ unsigned long long sk[BIN_SORT_BIG];
+    const int t = blockIdx.x;
+    const int64_t s = offsets[t];
+    const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
+    const int n = (int)(e - s);
+    if (n <= BIN_SORT_WAVE || n > BIN_SORT_BIG) return; // workgroup-uniform
+    int m = 2 * CH;
+    while (m < n) m <<= 1;
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool active = c * CH < m;
+    unsigned long long v[E];
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) { const int i = c * CH + lane * E + r; v[r] = i < n ? pairs[s + i] : ~0ull; }
+        const unsigned long long flip = (c & 1) ? ~0ull : 0ull;
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] ^= flip;
+        BitonicStage<E, 2>::run(v, lane);
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] ^= flip;
+    }
+    for (int K = 2 * CH; K <= m; K <<= 1) {
+        const bool asc = (K == m) || (((c * CH) & K) == 0);
+        for (int J = K >> 1; J >= CH; J >>= 1) {
+            const int dc = J / CH;
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) sk[c * CH + r * 64 + lane] = v[r];
+            }
+            __syncthreads();
+            if (active) {
+                const bool keep_min = ((c & dc) == 0) == asc;
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const unsigned long long p = sk[(c ^ dc) * CH + r * 64 + lane];
+                    v[r] = ((v[r] < p) != keep_min) ? p : v[r];
+                }
+            }
+            __syncthreads();
+        }
+        if (active) {
+            const unsigned long long flip = asc ? 0ull : ~0ull;
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] ^= flip;
+            BitonicSub<E, CH, CH / 2>::run(v, lane); // K >= 64 E: every compare-exchange ascending
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] ^= flip;
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int i = c * CH + lane * E + r;
+            if (i < n) { flatten_ids[s + i] = (int32_t)(uint32_t)v[r]; if (tile_ids) tile_ids[s + i] = (uint32_t)t; }
+        }
+    }
 }
 
 } // namespace adk
@@ -606,8 +642,8 @@ extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width,
     hipLaunchKernelGGL(bin_tile_sort_wave_kernel, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, stream, (const unsigned long long*)pairs,
                        offsets, n_tiles, n_isects, flatten_ids, tile_ids);
     if (max_tile > BIN_SORT_WAVE)
-        hipLaunchKernelGGL(bin_tile_sort_kernel<BIN_SORT_BIG>, dim3(n_tiles), dim3(256), 0, stream, (const unsigned long long*)pairs, offsets,
-                           n_tiles, n_isects, BIN_SORT_WAVE, flatten_ids, tile_ids);
+        hipLaunchKernelGGL(bin_tile_sort_merge_kernel, dim3(n_tiles), dim3(512), 0, stream, (const unsigned long long*)pairs, offsets,
+                           n_tiles, n_isects, flatten_ids, tile_ids);
     ADK_RETURN_LAST_ERROR();
 }
 

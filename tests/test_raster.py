@@ -237,6 +237,23 @@ def test_binning_routes_agree_and_survive_a_wrong_capacity_guess(dev, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,W,H", [(1_000_000, 512, 384), (150_000, 200, 150), (18_000, 96, 64), (8_000, 96, 64)])
+def test_binning_routes_agree_on_long_tile_lists(N, W, H, dev, monkeypatch):
+    """Tile lists of 1025 .. 8192 entries (1 M Gaussians on the north-star 512x384 frame: every tile) go through the
+    register-sorted-chunks + LDS-exchange merge sort of the tile-local route: the same bytes as the global radix route, for
+    list lengths that are not powers of two and for 2, 4 and 8 chunks per tile."""
+    sc = dict(_scene(N, W, H, 7), viewmat=_tilted_viewmat(2))
+    monkeypatch.setenv("ADK_BIN_LOCAL", "0")
+    ref = _binning_outputs(_run_hip(sc, dev)[2])
+    monkeypatch.setenv("ADK_BIN_LOCAL", "1")
+    got = _binning_outputs(_run_hip(sc, dev)[2])
+    counts = np.diff(np.append(ref["isect_offsets"].reshape(-1), ref["flatten_ids"].size))
+    assert counts.max() > 1024 and counts.max() <= 8192, counts.max()   # the merge sort's range (otherwise this test tests nothing)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.gpu
 def test_binning_tile_list_longer_than_the_lds_sort(dev):
     """More than 8192 splats on ONE tile (the in-LDS sort's limit): the forward falls back to the global route for that
     frame; lists and render still match the oracle."""

@@ -26,6 +26,9 @@ def build(specs):
         print(name, extra, B.build(variant=name, extra_flags=extra), flush=True)
 
 
+PASS = [a for i, a in enumerate(sys.argv) if a in ("--gaussians", "--width", "--height") or (i and sys.argv[i - 1] in ("--gaussians", "--width", "--height"))]
+
+
 def main():
     if "--build" in sys.argv:
         return build(sys.argv[sys.argv.index("--build") + 1:])
@@ -50,7 +53,7 @@ def main():
         for name, so in libs.items():
             env = dict(os.environ, ARTDECO_HIP_LIB=so)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "10", "--no-extra-configs",
-                                "--no-cpu-baseline", "--no-frontend"], env=env, cwd=ROOT, capture_output=True, text=True)
+                                "--no-cpu-baseline", "--no-frontend", *PASS], env=env, cwd=ROOT, capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode or not line:
                 print(f"{name}: FAILED rc={r.returncode}\n{r.stderr[-600:]}", flush=True)
