@@ -12,6 +12,17 @@ namespace adk {
 
 typedef _Float16 ln_f16x4 __attribute__((ext_vector_type(4)));
 
+// Full 64-lane sum in EVERY lane: 4 DPP adds inside the 16-lane rows + 2 permlane swaps across them, all in the VALU (the
+// __shfl_xor form is six ds_bpermute round trips through the LDS crossbar with an lgkmcnt wait each).
+__device__ __forceinline__ float wave_allsum_dpp(float v) {
+    v = row16_allreduce_sum(v);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+    sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(sw.x) + __uint_as_float(sw.y);
+}
+
 template <int CHUNKS, bool HAS_DELTA, bool Y_F16>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x_in, const _Float16* __restrict__ delta,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -38,7 +49,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
+    const float mean = wave_allsum_dpp(sum) / (float)C;
     float sq = 0.f;
 #pragma unroll
     for (int j = 0; j < CHUNKS; ++j) {
@@ -47,7 +58,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
             sq += (a * a + b * b) + (c * c + d * d);
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const float rstd = rsqrtf(wave_allsum_dpp(sq) / (float)C + eps);
 #pragma unroll
     for (int j = 0; j < CHUNKS; ++j) {
         const int c4 = lane + 64 * j;
