@@ -199,6 +199,8 @@ struct AdamMultiArgs {
     float b1, b2, eps;
 };
 
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
 {
     const float omb1 = 1.0f - A.b1, omb2 = 1.0f - A.b2;
@@ -231,8 +233,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
         const bool vec = (cnt == 4) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
         float pv[4], gv[4], mv[4], vv[4];
         if (vec) {
-            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(g);
-            const float4 c = *reinterpret_cast<const float4*>(m), d = *reinterpret_cast<const float4*>(v);
+            // nontemporal: every byte of this kernel is touched exactly once per step, and what it leaves out of the L2 / MALL is
+            // room for the next step's first kernels (measured: adam_multi 0.168 -> 0.151 ms, project_fwd 0.071 -> 0.062)
+            const nt_f4 a = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(g));
+            const nt_f4 c = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(m)), d = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(v));
             pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
             mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
         } else {
@@ -248,9 +252,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
             if (lrp && lrn == total && A.lr_decay[t] != 1.0f) lrp[e0 + j] = fmaxf(lr * A.lr_decay[t], A.lr_min[t]);
         }
         if (vec) {
-            *reinterpret_cast<float4*>(p) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-            *reinterpret_cast<float4*>(m) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-            *reinterpret_cast<float4*>(v) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            __builtin_nontemporal_store(nt_f4{pv[0], pv[1], pv[2], pv[3]}, reinterpret_cast<nt_f4*>(p));
+            __builtin_nontemporal_store(nt_f4{mv[0], mv[1], mv[2], mv[3]}, reinterpret_cast<nt_f4*>(m));
+            __builtin_nontemporal_store(nt_f4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<nt_f4*>(v));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (on[j]) { p[j] = pv[j]; m[j] = mv[j]; v[j] = vv[j]; }
@@ -291,6 +295,8 @@ extern "C" int adk_adam_update_multi(int n, float* const* params, const float* c
     if (k == 0) return 0;
     for (int i = k; i < ADAM_MAX_TENSORS; ++i) { A.item_end[i] = items; A.total[i] = 0; A.M[i] = 1; A.p[i] = nullptr; A.g[i] = nullptr; A.m[i] = nullptr; A.v[i] = nullptr; A.vis[i] = nullptr; A.lr_ptr[i] = nullptr; A.lr_numel[i] = 0; A.lr_val[i] = 0.f; A.lr_decay[i] = 1.f; A.lr_min[i] = 0.f; }
     A.n = k; A.b1 = b1; A.b2 = b2; A.eps = eps;
-    hipLaunchKernelGGL(adk::adam_multi_kernel, dim3(adk::stream_grid(items, 256)), dim3(256), 0, stream, A);
+    // one work item per thread, the grid covers the data: a grid-stride loop over a capped grid (2048 blocks) tops out at 4.8 TB/s on this
+    // chip, one float4 per thread reaches 6.1 (tools/lab/copy_lab.py)
+    hipLaunchKernelGGL(adk::adam_multi_kernel, dim3((unsigned)adk::ceil_div(items, 256)), dim3(256), 0, stream, A);
     ADK_RETURN_LAST_ERROR();
 }
