@@ -64,7 +64,8 @@ def main():
                               "bwd_in_region": d.get("raster_bwd_ms"), "stage_ms": st})
             print(f"{name:24s} step {d['ms_per_step']:.4f} ms  raster_fwd {st.get('raster_fwd')}  raster_bwd {st.get('raster_bwd')} "
                   f"(timed region {d.get('raster_bwd_ms'):.4f})  project_bwd {st.get('project_bwd')}  adam_multi {st.get('adam_multi')}  "
-                  f"lod_fwd {st.get('lod_params_fwd')}  lod_bwd {st.get('lod_params_bwd')}  project_fwd {st.get('project_fwd')}", flush=True)
+                  f"lod_fwd {st.get('lod_params_fwd')}  lod_bwd {st.get('lod_params_bwd')}  project_fwd {st.get('project_fwd')}  "
+                  f"bin {st.get('bin_count')} {st.get('bin_scatter')} {st.get('bin_sort')}", flush=True)
     print(json.dumps(res))
 
 
