@@ -51,7 +51,7 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
 # the same positions tensor (croco/models/blocks.py hands `xpos` to all of them), so the (cos, sin) table of a positions tensor
 # is built once (adk_rope_2d_table: the fp32 expressions of kernels.cu:38-44) and each call streams through it
 # (adk_rope_2d_apply): bit-identical to rope_2d, 7.2 -> 2.7 us per call at 768 tokens.
-_TABLES: "dict[tuple, tuple[torch.Tensor, torch.Tensor]]" = {}
+_TABLES: "dict[tuple, tuple]" = {}
 _TABLES_MAX = 8
 
 
@@ -61,6 +61,11 @@ def _table_for(positions: torch.Tensor, D: int, base: float, fwd: float) -> torc
     key = (positions.data_ptr(), version, tuple(positions.shape), positions.device, D, float(base), float(fwd))
     hit = _TABLES.get(key)
     if hit is not None:
+        # built on another stream (the model runs its two decoder branches on two streams): the first use on this one waits for it
+        cur = torch.cuda.current_stream(positions.device)
+        if hit[2] is not None and cur.cuda_stream not in hit[3] and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(hit[2])
+            hit[3].add(cur.cuda_stream)
         return hit[1]
     B, N, _ = positions.shape
     table = torch.empty(B * N, 2, D // 4, 2, dtype=torch.float32, device=positions.device)
@@ -70,7 +75,14 @@ def _table_for(positions: torch.Tensor, D: int, base: float, fwd: float) -> torc
     _lib.check(rc, "adk_rope_2d_table")
     while len(_TABLES) >= _TABLES_MAX:
         _TABLES.pop(next(iter(_TABLES)))
-    _TABLES[key] = (positions, table)  # the positions tensor is kept alive with its table: its address cannot be reused meanwhile
+    built_on = torch.cuda.current_stream(positions.device)
+    ready = None
+    if not torch.cuda.is_current_stream_capturing():
+        ready = torch.cuda.Event()
+        ready.record(built_on)
+    # the positions tensor is kept alive with its table (its address cannot be reused meanwhile); `ready` + the set of streams that
+    # have already ordered themselves behind it
+    _TABLES[key] = (positions, table, ready, {built_on.cuda_stream})
     return table
 
 
