@@ -131,3 +131,18 @@ def test_model_blocks_use_the_kernel_and_match_sdpa():
         att.supported = sup
     for new, old in ((a1, a0), (c1, c0)):
         assert float((new.float() - old.float()).abs().max()) <= 4e-3 * float(old.float().abs().max())
+
+
+def test_cpu_tensors_take_the_torch_path_and_the_kernel_refuses_them():
+    """No GPU: `supported` says no, `attention` fails loudly (no CPU fallback inside the operator), the model's `_attend` returns
+    torch's scaled_dot_product_attention in the [B, N, H*D] layout of blocks.py:109."""
+    from artdeco_amd import _lib, attention as att
+    from artdeco_amd.mast3r_model import _attend
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(2, 3, 10, 64, generator=g) for _ in range(3))
+    assert not att.supported(q, k, v) and not att.supported(q.half(), k.half(), v.half())
+    with pytest.raises(_lib.AdkError):
+        att.attention(q.half(), k.half(), v.half())
+    out = _attend(q, k, v)
+    assert out.shape == (2, 10, 192)
+    assert torch.allclose(out.double(), attention_oracle(q, k, v), atol=2e-6, rtol=1e-5)

@@ -95,3 +95,13 @@ def test_fused_trunk_matches_the_unfused_trunk():
     for a, b in zip(fused, plain):
         assert a.shape == b.shape and a.dtype == b.dtype == torch.float32
         assert float((a - b).abs().max()) <= 3e-3 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
+
+
+def test_cpu_tensors_are_refused():
+    from artdeco_amd import _lib
+    from artdeco_amd.fused_norm import add_layernorm, supported
+    norm = torch.nn.LayerNorm(64)
+    x = torch.zeros(4, 64)
+    assert not supported(x, None, norm)
+    with pytest.raises(_lib.AdkError):
+        add_layernorm(x, None, norm)
