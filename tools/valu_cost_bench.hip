@@ -69,6 +69,38 @@ template <int MODE> __global__ __launch_bounds__(64) void k(float* out, unsigned
 #define S(i) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m[i & 3]) : "s"(m[(i + 1) & 3]));
             BODY16(S)
 #undef S
+        } else if (MODE == 12) { // VOP2 fused multiply-add (dst is the addend)
+#define S(i) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            BODY16(S)
+#undef S
+        } else if (MODE == 13) {
+#define S(i) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
+            BODY16(S)
+#undef S
+        } else if (MODE == 15) {
+#define S(i) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(a[i]) : "v"(b));
+            BODY16(S)
+#undef S
+        } else if (MODE == 16) {
+#define S(i) asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
+            BODY16(S)
+#undef S
+        } else if (MODE == 17) { // multiply by an SGPR / by an inline constant
+#define S(i) asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(a[i]));
+            BODY16(S)
+#undef S
+        } else if (MODE == 18) {
+#define S(i) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(b), "v"(c), "v"(a[(i + 1) & 15]));
+            BODY16(S)
+#undef S
+        } else if (MODE == 19) { // v_max3 (VOP3, three VGPR sources)
+#define S(i) asm volatile("v_max3_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+            BODY16(S)
+#undef S
+        } else if (MODE == 20) {
+#define S(i) asm volatile("v_cvt_pk_f16_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            BODY16(S)
+#undef S
         } else if (MODE == 11) { // LDS broadcast read of one float4 (wave-uniform address), as the staged splat records are read
             __shared__ float4 lds[64];
             if (r == 0) lds[threadIdx.x] = make_float4(b, b, b, b);
@@ -125,6 +157,14 @@ int main()
     run<6>("v_cndmask_b32_e64, SGPR-pair mask");
     run<7>("v_add_f32_dpp row_mirror");
     run<8>("v_pk_fma_f32 (2 floats / lane)");
+    run<12>("v_fmac_f32_e32 (VOP2 fma)");
+    run<18>("v_fma_f32 with a separate destination");
+    run<13>("v_add_f32_e32");
+    run<16>("v_max_f32_e32");
+    run<19>("v_max3_f32");
+    run<17>("v_mul_f32_e32 by an inline constant");
+    run<15>("v_mov_b32_e32");
+    run<20>("v_cvt_pk_f16_f32");
     run<10>("s_and_b64 (SALU)");
     run<11>("ds_read_b128 broadcast + wait, + v_add", 16);
     return 0;
