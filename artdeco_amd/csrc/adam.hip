@@ -195,15 +195,14 @@ struct AdamMultiArgs {
     int64_t lr_numel[ADAM_MAX_TENSORS];
     int64_t item_end[ADAM_MAX_TENSORS];   // exclusive prefix of ceil(total/4) work items
     int M[ADAM_MAX_TENSORS];
-    int n;
-    float b1, b2, eps;
+    float b1[ADAM_MAX_TENSORS], b2[ADAM_MAX_TENSORS], eps[ADAM_MAX_TENSORS]; // per tensor: the keyframe's pose / exposure Adam
+    int n;                                                                    // (betas 0.8 / 0.99) rides in the Gaussians' launch
 };
 
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
 {
-    const float omb1 = 1.0f - A.b1, omb2 = 1.0f - A.b2;
     const int64_t n_items = A.item_end[A.n - 1];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += stride) {
@@ -212,6 +211,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
         const int64_t vi = it - (t ? A.item_end[t - 1] : 0);
         const int64_t e0 = vi << 2, total = A.total[t];
         const int M = A.M[t];
+        const float b1 = A.b1[t], b2 = A.b2[t], eps = A.eps[t];
+        const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
         const int cnt = (int)((total - e0) < 4 ? (total - e0) : 4);
         const uint8_t* vis = A.vis[t];
         float* lrp = A.lr_ptr[t];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
             if (!on[j]) continue;
             float lr = A.lr_val[t];
             if (lrp) lr = (lrn == 1) ? lrp[0] : (lrn == total ? lrp[e0 + j] : lrp[rows[j]]);
-            adam_elem(pv[j], gv[j], mv[j], vv[j], lr, A.b1, A.b2, omb1, omb2, A.eps);
+            adam_elem(pv[j], gv[j], mv[j], vv[j], lr, b1, b2, omb1, omb2, eps);
             if (lrp && lrn == total && A.lr_decay[t] != 1.0f) lrp[e0 + j] = fmaxf(lr * A.lr_decay[t], A.lr_min[t]);
         }
         if (vec) {
@@ -267,15 +268,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A)
 // Arrays of length n (HOST memory, read during the call): device pointers per tensor, rows x M shapes, lr as
 // a device pointer (lr_numel in {1, rows, rows*M}) or NULL + lr_val.  lr_decay/lr_min apply to per-element lr
 // tensors only: lr[e] = max(lr[e] * decay, lr_min) for elements of visible rows, after the update.
-extern "C" int adk_adam_update_multi(int n, float* const* params, const float* const* grads, float* const* exp_avgs,
-                                     float* const* exp_avg_sqs, const uint8_t* const* visibles, float* const* lr_ptrs,
-                                     const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
-                                     const float* lr_mins, const int64_t* rows, const int64_t* Ms, float b1, float b2,
-                                     float eps, hipStream_t stream)
+// b1s / b2s / epss: HOST arrays of length n (one Adam configuration per tensor).
+extern "C" int adk_adam_update_multi_betas(int n, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                           float* const* exp_avg_sqs, const uint8_t* const* visibles, float* const* lr_ptrs,
+                                           const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
+                                           const float* lr_mins, const int64_t* rows, const int64_t* Ms, const float* b1s,
+                                           const float* b2s, const float* epss, hipStream_t stream)
 {
     if (n < 0 || n > ADAM_MAX_TENSORS) return ADK_EINVAL;
     if (n == 0) return 0;
-    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !visibles || !lr_ptrs || !lr_numels || !lr_vals || !lr_decays || !lr_mins || !rows || !Ms) return ADK_EINVAL;
+    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !visibles || !lr_ptrs || !lr_numels || !lr_vals || !lr_decays || !lr_mins || !rows || !Ms || !b1s || !b2s || !epss) return ADK_EINVAL;
     adk::AdamMultiArgs A;
     int k = 0;
     int64_t items = 0;
@@ -288,15 +290,30 @@ extern "C" int adk_adam_update_multi(int n, float* const* params, const float* c
         A.p[k] = params[i]; A.g[k] = grads[i]; A.m[k] = exp_avgs[i]; A.v[k] = exp_avg_sqs[i]; A.vis[k] = visibles[i];
         A.lr_ptr[k] = lr_ptrs[i]; A.lr_numel[k] = lr_ptrs[i] ? lr_numels[i] : 0; A.lr_val[k] = lr_vals[i];
         A.lr_decay[k] = lr_decays[i]; A.lr_min[k] = lr_mins[i]; A.total[k] = total; A.M[k] = (int)Ms[i];
+        A.b1[k] = b1s[i]; A.b2[k] = b2s[i]; A.eps[k] = epss[i];
         items += (total + 3) / 4;
         A.item_end[k] = items;
         ++k;
     }
     if (k == 0) return 0;
-    for (int i = k; i < ADAM_MAX_TENSORS; ++i) { A.item_end[i] = items; A.total[i] = 0; A.M[i] = 1; A.p[i] = nullptr; A.g[i] = nullptr; A.m[i] = nullptr; A.v[i] = nullptr; A.vis[i] = nullptr; A.lr_ptr[i] = nullptr; A.lr_numel[i] = 0; A.lr_val[i] = 0.f; A.lr_decay[i] = 1.f; A.lr_min[i] = 0.f; }
-    A.n = k; A.b1 = b1; A.b2 = b2; A.eps = eps;
+    for (int i = k; i < ADAM_MAX_TENSORS; ++i) { A.item_end[i] = items; A.total[i] = 0; A.M[i] = 1; A.p[i] = nullptr; A.g[i] = nullptr; A.m[i] = nullptr; A.v[i] = nullptr; A.vis[i] = nullptr; A.lr_ptr[i] = nullptr; A.lr_numel[i] = 0; A.lr_val[i] = 0.f; A.lr_decay[i] = 1.f; A.lr_min[i] = 0.f; A.b1[i] = 0.f; A.b2[i] = 0.f; A.eps[i] = 0.f; }
+    A.n = k;
     // one work item per thread, the grid covers the data: a grid-stride loop over a capped grid (2048 blocks) tops out at 4.8 TB/s on this
     // chip, one float4 per thread reaches 6.1 (tools/lab/copy_lab.py)
     hipLaunchKernelGGL(adk::adam_multi_kernel, dim3((unsigned)adk::ceil_div(items, 256)), dim3(256), 0, stream, A);
     ADK_RETURN_LAST_ERROR();
+}
+
+// The same Adam configuration for every tensor (SparseGaussianAdam.step, optimizers.py:77-161).
+extern "C" int adk_adam_update_multi(int n, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                     float* const* exp_avg_sqs, const uint8_t* const* visibles, float* const* lr_ptrs,
+                                     const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
+                                     const float* lr_mins, const int64_t* rows, const int64_t* Ms, float b1, float b2,
+                                     float eps, hipStream_t stream)
+{
+    if (n < 0 || n > ADAM_MAX_TENSORS) return ADK_EINVAL;
+    float b1s[ADAM_MAX_TENSORS], b2s[ADAM_MAX_TENSORS], epss[ADAM_MAX_TENSORS];
+    for (int i = 0; i < ADAM_MAX_TENSORS; ++i) { b1s[i] = b1; b2s[i] = b2; epss[i] = eps; }
+    return adk_adam_update_multi_betas(n, params, grads, exp_avgs, exp_avg_sqs, visibles, lr_ptrs, lr_numels, lr_vals, lr_decays, lr_mins,
+                                       rows, Ms, b1s, b2s, epss, stream);
 }

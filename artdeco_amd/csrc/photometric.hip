@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void photometric_ssim_partials_kernel(const fl
 __global__ __launch_bounds__(256) void photometric_loss_kernel(const float* __restrict__ l1d_partials, int n_l1d,
                                                                const float* __restrict__ ssim_partials, int n_ssim,
                                                                int64_t P, float lambda_dssim, float depth_weight,
-                                                               float* __restrict__ loss)
+                                                               float* __restrict__ loss, float* __restrict__ total_out /* nullable */)
 {
     __shared__ float red[4][3];
     float a = 0.f, d = 0.f, s = 0.f;
@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void photometric_loss_kernel(const float* __re
         const float l1 = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) / (float)(3 * P);
         const float dl = ((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])) / (float)P;
         const float ss = ((red[0][2] + red[1][2]) + (red[2][2] + red[3][2])) / (float)(3 * P);
-        loss[0] = lambda_dssim * (1.f - ss) + (1.f - lambda_dssim) * l1 + depth_weight * dl;
-        loss[1] = l1; loss[2] = ss; loss[3] = dl;
+        const float total = lambda_dssim * (1.f - ss) + (1.f - lambda_dssim) * l1 + depth_weight * dl;
+        loss[0] = total; loss[1] = l1; loss[2] = ss; loss[3] = dl;
+        if (total_out) *total_out = total;
     }
 }
 
@@ -306,7 +307,24 @@ extern "C" int adk_photometric_loss(int W, int H, const float* ssim_map, float l
     if (ns > PHOTO_SSIM_BLOCKS) ns = PHOTO_SSIM_BLOCKS;
     hipLaunchKernelGGL(adk::photometric_ssim_partials_kernel, dim3(ns), dim3(256), 0, stream, ssim_map, 3 * P, sp);
     hipLaunchKernelGGL(adk::photometric_loss_kernel, dim3(1), dim3(256), 0, stream, (const float*)l1d, photo_grid(P),
-                       (const float*)sp, ns, P, lambda_dssim, depth_weight, loss_out);
+                       (const float*)sp, ns, P, lambda_dssim, depth_weight, loss_out, (float*)nullptr);
+    ADK_RETURN_LAST_ERROR();
+}
+
+// The same four scalars from the per-strip sums of adk_fused_ssim_fwd_sums (n_sums of them) instead of the SSIM map: one
+// launch, no pass over the map.  total_out (nullable): a second copy of loss_out[0] in a buffer of its own, so that a binding
+// can hand out the differentiable scalar and the by-product vector as two tensors without a copy kernel.
+extern "C" int adk_photometric_loss_sums(int W, int H, const float* ssim_block_sums, int64_t n_sums, float lambda_dssim,
+                                         float depth_weight, void* workspace, int64_t workspace_bytes, float* loss_out,
+                                         float* total_out, hipStream_t stream)
+{
+    if (W < 0 || H < 0) return ADK_EINVAL;
+    const int64_t P = (int64_t)W * H;
+    if (P == 0) return ADK_EINVAL;
+    if (!ssim_block_sums || n_sums <= 0 || n_sums > 0x7fffffff || !workspace || !loss_out) return ADK_EINVAL;
+    if (workspace_bytes < adk_photometric_workspace_bytes(W, H)) return ADK_EWORKSPACE;
+    hipLaunchKernelGGL(adk::photometric_loss_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, photo_grid(P),
+                       ssim_block_sums, (int)n_sums, P, lambda_dssim, depth_weight, loss_out, total_out);
     ADK_RETURN_LAST_ERROR();
 }
 

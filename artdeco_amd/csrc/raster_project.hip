@@ -661,7 +661,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 // v_viewmat[4,4] += (v_R | v_t) + d(campos)/d(viewmat)^T v_campos, campos = -R^-1 t:
 //   v_t' = -R^-T v_cp ;  v_R' = -R^-T (v_Ri) ... with Ri = R^-1:  d(Ri) = -Ri dR Ri,
 //   campos = -Ri t  =>  v_Ri = -v_cp t^T ; v_R' = -Ri^T v_Ri Ri^T = Ri^T v_cp t^T Ri^T = (Ri^T v_cp)(Ri t)^T
-__global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, const float* __restrict__ cam_grad,
+// Leaves cam_grad zeroed again: a caller can keep ONE accumulator per stream instead of clearing a fresh one every step.
+__global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, float* __restrict__ cam_grad,
                                              float* __restrict__ v_viewmat)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -688,6 +689,7 @@ __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, 
         v_viewmat[i * 4 + 3] = cam_grad[9 + i] - a[i];
     }
     for (int j = 0; j < 4; ++j) v_viewmat[12 + j] = 0.f;
+    for (int j = 0; j < 16; ++j) cam_grad[j] = 0.f;
 }
 
 } // namespace adk

@@ -33,12 +33,14 @@ __constant__ float kGauss[11] = {
 #define SSIM_HALO 5
 #define SSIM_ROWBUF 80 // 64 + 10 halo, padded
 
-template <int RH, bool TRAIN>
+// SUM: the strip's share of sum(ssim_map) goes to block_sums[linear block index] (the mapper's loss needs only the
+// mean, h3dgsv3.py:441: a second pass over the map and, with ssim_map == NULL, the map itself are saved).
+template <int RH, bool TRAIN, bool SUM>
 __global__ __launch_bounds__(64) void ssim_fwd_kernel(
     int H, int W, float C1, float C2,
     const float* __restrict__ img1, const float* __restrict__ img2,
     float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
-    float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12)
+    float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12, float* __restrict__ block_sums)
 {
     __shared__ float rowbuf[2][2][SSIM_ROWBUF]; // [parity][image][column]
 
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(
     const int x = x0 + lane; // output column
 
     float win[11][5];
+    float strip_sum = 0.f;
 
     constexpr int NROWS = RH + 2 * SSIM_HALO;
 
@@ -156,7 +159,9 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(
                         const float D_ = 2.f * sigma12 + C2;
                         const float inv_AB = 1.f / (A * Bv);
                         const int64_t o = plane + (int64_t)yo * W + x;
-                        ssim_map[o] = (C_ * D_) * inv_AB;
+                        const float ssim = (C_ * D_) * inv_AB;
+                        if (!SUM || ssim_map) ssim_map[o] = ssim; // SUM: uniform pointer test
+                        if (SUM) strip_sum += ssim;
                         if (TRAIN) {
                             // d(ssim)/d(mu1), d/d(sigma1^2), d/d(sigma12): ssim.cu:260-274
                             const float inv_A = 1.f / A, inv_B = 1.f / Bv;
@@ -171,6 +176,10 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(
                 }
             }
         }
+    }
+    if (SUM) { // every lane is back here: fixed DPP order => the same bits on every run
+        const float t = wave_sum_to_lane63(strip_sum);
+        if (lane == 63) block_sums[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
     }
 }
 
@@ -286,6 +295,30 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(
 
 } // namespace adk
 
+// strip height: 32 rows when that still yields >= ~4 waves per SIMD, else 16
+static int ssim_strip_rows(int B, int CH, int H, int W)
+{
+    const int64_t waves32 = adk::ceil_div(W, 64) * adk::ceil_div(H, 32) * B * CH;
+    return waves32 >= 4096 ? 32 : 16;
+}
+
+static int ssim_fwd_launch(const float* img1, const float* img2, int B, int CH, int H, int W, float C1, float C2, float* ssim_map,
+                           float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, float* block_sums, hipStream_t stream)
+{
+    const bool train = dm_dmu1 != nullptr;
+    if (train && (!dm_dsigma1_sq || !dm_dsigma12)) return ADK_EINVAL;
+    if ((int64_t)B * CH > 65535) return ADK_EUNSUPPORTED;
+    const int rh = ssim_strip_rows(B, CH, H, W);
+    const dim3 block(64), grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, rh), (unsigned)(B * CH));
+#define SSIM_FWD(RH, TRAIN, SUM) hipLaunchKernelGGL((adk::ssim_fwd_kernel<RH, TRAIN, SUM>), grid, block, 0, stream, H, W, C1, C2, img1, img2, \
+                                                    ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, block_sums)
+    if (block_sums) { if (rh == 32) SSIM_FWD(32, true, true); else SSIM_FWD(16, true, true); }
+    else if (train) { if (rh == 32) SSIM_FWD(32, true, false); else SSIM_FWD(16, true, false); }
+    else { if (rh == 32) SSIM_FWD(32, false, false); else SSIM_FWD(16, false, false); }
+#undef SSIM_FWD
+    ADK_RETURN_LAST_ERROR();
+}
+
 extern "C" int adk_fused_ssim_fwd(const float* img1, const float* img2, int B, int CH, int H, int W,
                                   float C1, float C2, float* ssim_map, float* dm_dmu1,
                                   float* dm_dsigma1_sq, float* dm_dsigma12, hipStream_t stream)
@@ -293,22 +326,26 @@ extern "C" int adk_fused_ssim_fwd(const float* img1, const float* img2, int B, i
     if (B < 0 || CH < 0 || H < 0 || W < 0) return ADK_EINVAL;
     if ((int64_t)B * CH * H * W == 0) return 0;
     if (!img1 || !img2 || !ssim_map) return ADK_EINVAL;
-    const bool train = dm_dmu1 != nullptr;
-    if (train && (!dm_dsigma1_sq || !dm_dsigma12)) return ADK_EINVAL;
-    if ((int64_t)B * CH > 65535) return ADK_EUNSUPPORTED;
-    // Strip height: 32 rows when that still yields >= ~4 waves per SIMD, else 16.
-    const int64_t waves32 = adk::ceil_div(W, 64) * adk::ceil_div(H, 32) * B * CH;
-    const dim3 block(64);
-    if (waves32 >= 4096) {
-        const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 32), (unsigned)(B * CH));
-        if (train) hipLaunchKernelGGL((adk::ssim_fwd_kernel<32, true>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
-        else hipLaunchKernelGGL((adk::ssim_fwd_kernel<32, false>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, nullptr, nullptr, nullptr);
-    } else {
-        const dim3 grid((unsigned)adk::ceil_div(W, 64), (unsigned)adk::ceil_div(H, 16), (unsigned)(B * CH));
-        if (train) hipLaunchKernelGGL((adk::ssim_fwd_kernel<16, true>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
-        else hipLaunchKernelGGL((adk::ssim_fwd_kernel<16, false>), grid, block, 0, stream, H, W, C1, C2, img1, img2, ssim_map, nullptr, nullptr, nullptr);
-    }
-    ADK_RETURN_LAST_ERROR();
+    return ssim_fwd_launch(img1, img2, B, CH, H, W, C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, nullptr, stream);
+}
+
+extern "C" int64_t adk_fused_ssim_fwd_sums_count(int B, int CH, int H, int W)
+{
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return -1;
+    if ((int64_t)B * CH * H * W == 0) return 0;
+    return adk::ceil_div(W, 64) * adk::ceil_div(H, ssim_strip_rows(B, CH, H, W)) * (int64_t)B * CH;
+}
+
+// Training forward that also (or only: ssim_map may be NULL) leaves sum(ssim_map) as adk_fused_ssim_fwd_sums_count(...)
+// partial sums, one per strip, in a fixed order.
+extern "C" int adk_fused_ssim_fwd_sums(const float* img1, const float* img2, int B, int CH, int H, int W, float C1, float C2,
+                                       float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                                       float* block_sums, hipStream_t stream)
+{
+    if (B < 0 || CH < 0 || H < 0 || W < 0) return ADK_EINVAL;
+    if ((int64_t)B * CH * H * W == 0) return 0;
+    if (!img1 || !img2 || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !block_sums) return ADK_EINVAL;
+    return ssim_fwd_launch(img1, img2, B, CH, H, W, C1, C2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, block_sums, stream);
 }
 
 extern "C" int adk_fused_ssim_bwd(const float* img1, const float* img2, const float* dL_dmap, float dL_scalar,

@@ -9,6 +9,9 @@ All of them run on the HIP kernels of libartdeco_hip.so; there is no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
+import threading
+
 import torch
 
 from artdeco_amd import _lib
@@ -64,6 +67,37 @@ def adamUpdate(param, param_grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps,
     _lib.check(rc, "adk_adam_update")
 
 
+_tls = threading.local()
+
+
+def _launch_basic(param, grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
+    lib = _lib.load()
+    with torch.cuda.device(param.device):
+        rc = lib.adk_adam_update_basic(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                       float(lr), float(b1), float(b2), float(eps), param.numel(),
+                                       _lib.stream_of(param))
+    _lib.check(rc, "adk_adam_update_basic")
+
+
+@contextlib.contextmanager
+def deferred_basic_updates():
+    """Inside the block (on this thread) adamUpdateBasic validates and RECORDS its arguments instead of launching; the
+    block yields the list of (param, grad, exp_avg, exp_avg_sq, lr, b1, b2, eps) records.  A caller that is about to
+    launch a multi-tensor update anyway (artdeco_amd.fused: the Gaussians' step right after Keyframe.step(), whose three
+    calls are 6, 3 and 12 floats) takes the records out of the list and packs them into that launch.  Whatever is
+    still in the list when the block ends is launched then, one kernel each, so no update can be lost."""
+    queue: list = []
+    prev = getattr(_tls, "queue", None)
+    _tls.queue = queue
+    try:
+        yield queue
+    finally:
+        _tls.queue = prev
+        for rec in queue:
+            _launch_basic(*rec)
+        queue.clear()
+
+
 @torch.no_grad()
 def adamUpdateBasic(param, param_grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
     """In-place dense Adam with a python-float lr (optimizers.py:48-57, :90-99)."""
@@ -71,9 +105,9 @@ def adamUpdateBasic(param, param_grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
     if param.numel() == 0:
         return
     grad = param_grad.contiguous()
-    lib = _lib.load()
-    with torch.cuda.device(param.device):
-        rc = lib.adk_adam_update_basic(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
-                                       float(lr), float(b1), float(b2), float(eps), param.numel(),
-                                       _lib.stream_of(param))
-    _lib.check(rc, "adk_adam_update_basic")
+    rec = (param, grad, exp_avg, exp_avg_sq, float(lr), float(b1), float(b2), float(eps))
+    queue = getattr(_tls, "queue", None)
+    if queue is not None:
+        queue.append(rec)
+        return
+    _launch_basic(*rec)

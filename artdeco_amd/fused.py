@@ -30,11 +30,16 @@ _NW = 32 * 32 + 32 + 7 * 32 + 7
 
 class FusedLodParams(torch.autograd.Function):
     """(xyz, opacity_raw[N,1], scaling_raw[N,3], rotation[N,4], local_feat[N,16], global_feat[V,16],
-    W1, b1, W2, b2 | cls_id, d_max, viewmat) -> opac_eff [N], scale_eff [N,3], quat_eff [N,4], selected [N] bool"""
+    W1, b1, W2, b2 | cls_id, d_max, viewmat) -> opac_eff [N], scale_eff [N,3], quat_eff [N,4], selected [N] bool, xyz
+
+    The last output is xyz itself, handed through: the rasteriser takes its means from it, so the gradient of the means
+    arrives HERE and the kernel adds the (sparse) LoD fade term into that buffer (its `v_xyz_add` argument accumulates)
+    instead of autograd zero-filling a second [N,3] tensor and summing the two (one 12 MB fill and one 36 MB add per step)."""
 
     @staticmethod
     def forward(ctx, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, W1, b1, W2, b2, cls_id, d_max, viewmat):
         lib = _lib.load()
+        xyz_in = xyz
         _lib.require_cuda(xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, W1, cls_id, d_max, viewmat)
         dev, N = xyz.device, xyz.shape[0]
         c = lambda t: t.detach().contiguous()
@@ -62,10 +67,10 @@ class FusedLodParams(torch.autograd.Function):
         ctx.dims = (L, G, Hd)
         ctx.save_for_backward(xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, W1, b1, W2, b2, cls_id, d_max, viewmat)
         ctx.mark_non_differentiable(sel)
-        return opac, scale, quat, sel
+        return opac, scale, quat, sel, xyz_in
 
     @staticmethod
-    def backward(ctx, v_opac, v_scale, v_quat, _v_sel):
+    def backward(ctx, v_opac, v_scale, v_quat, _v_sel, v_xyz_through):
         lib = _lib.load()
         (xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, W1, b1, W2, b2, cls_id, d_max,
          viewmat) = ctx.saved_tensors
@@ -75,7 +80,11 @@ class FusedLodParams(torch.autograd.Function):
         with torch.cuda.device(dev):
             v_opac = z(v_opac, opacity_raw.view(-1))
             v_scale, v_quat = z(v_scale, scaling_raw), z(v_quat, rotation)
-            v_xyz = torch.zeros_like(xyz)
+            if (v_xyz_through is not None and v_xyz_through.dtype == torch.float32 and v_xyz_through.is_contiguous()
+                    and v_xyz_through.shape == xyz.shape):
+                v_xyz = v_xyz_through          # the rasteriser's v_means: the fade term is accumulated into it
+            else:
+                v_xyz = torch.zeros_like(xyz) if v_xyz_through is None else v_xyz_through.float().contiguous().clone()
             v_o, v_s, v_r = torch.empty_like(opacity_raw), torch.empty_like(scaling_raw), torch.empty_like(rotation)
             v_lf = torch.empty_like(local_feat)
             v_gf = torch.zeros_like(global_feat)
@@ -144,13 +153,13 @@ def _render_raw(self, width: int, height: int, view_matrix: torch.Tensor):
     dev = self.device
     lin1, lin2 = self.mlp_cov[0], self.mlp_cov[2]
     P = self.gaussian_params
-    opac, scaling, quat, sel = FusedLodParams.apply(
+    opac, scaling, quat, sel, xyz = FusedLodParams.apply(
         P["xyz"]["val"], P["opacity"]["val"], P["scaling"]["val"], P["rotation"]["val"], P["local_feat"]["val"],
         P["global_feat"]["val"], lin1.weight, lin1.bias, lin2.weight, lin2.bias, P["cls_id"]["val"], P["d_max"]["val"],
         view_matrix.detach())
     K = _intrinsics(self, width, height, dev)
     eps2d = self.args.low_pass_filter_eps if hasattr(self, "args") else self.eps2d
-    out = render_camera(P["xyz"]["val"], quat, scaling, opac, P["f_dc"]["val"], view_matrix.float(), K, width, height,
+    out = render_camera(xyz, quat, scaling, opac, P["f_dc"]["val"], view_matrix.float(), K, width, height,
                         sh_degree=self.active_sh_degree, eps2d=eps2d, sh_rest=P["f_rest"]["val"])
     col4, alphas, radii = out[0], out[1], out[2]
     vis, gvis = visibility_masks(radii, P["cls_id"]["val"], P["global_feat"]["val"].shape[0])
@@ -225,9 +234,11 @@ def fused_render_from_id(self, keyframe_id, pyr_lvl=0, bg=None):
     return pkg
 
 
-def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
+def fused_optimizer_step(self, visibility, N, global_visibility, N_global, extra=None):
     """Drop-in body for SparseGaussianAdam.step (Reconstruct/scene/optimizers.py:77-161): the same updates, the
-    same learning-rate decay, one kernel launch (adk_adam_update_multi) and no boolean-index host sync.
+    same learning-rate decay, one kernel launch (adk_adam_update_multi_betas) and no boolean-index host sync.
+    extra: adamUpdateBasic records (dropin.diff_gaussian_rasterization.deferred_basic_updates) of OTHER optimizers
+    (the keyframe's pose / exposure Adam, with its own betas) that ride in the same launch.
     One documented difference: the floor of a per-element learning rate (`clamp_min_(lr_init * 0.1)`, optimizers.py:134)
     is applied to the rows that were decayed (the visible ones); the reference clamps every row, which is a no-op on rows
     that were never decayed below the floor -- i.e. identical unless a caller pre-loads rates below the floor."""
@@ -235,7 +246,7 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
     lib = _lib.load()
     skip = ("id", "cls_id", "d_max")
     b1, b2 = self.betas
-    ent = []  # (param, grad, m, v, vis, lr_tensor|None, lr_val, decay, lr_min, rows, M)
+    ent = []  # (param, grad, m, v, vis, lr_tensor|None, lr_val, decay, lr_min, rows, M[, b1, b2, eps])
     keep = []
     for key, pd in self.params.items():
         if key in skip:
@@ -272,6 +283,11 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
             if lr.numel() != val.numel():  # per-row lr cannot be decayed per element in place; keep reference path
                 decay = 1.0
         ent.append((val, grad, pd["exp_avg"], pd["exp_avg_sq"], vis, lr, 0.0, decay, lr_min, int(n), val.numel() // int(n)))
+    own = (float(b1), float(b2), float(self.eps))
+    ent = [e + own for e in ent]
+    for (param, grad, m, v, lr, eb1, eb2, eeps) in (extra or ()):
+        keep.append(grad)
+        ent.append((param, grad, m, v, None, None, float(lr), 1.0, 0.0, param.numel(), 1, float(eb1), float(eb2), float(eeps)))
     if not ent:
         return
     n = len(ent)
@@ -288,11 +304,11 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global):
             VP(*[e[3].data_ptr() for e in ent]), VP(*[ptr(e[4]) for e in ent]), VP(*[ptr(e[5]) for e in ent]),
             I64(*[(e[5].numel() if e[5] is not None else 0) for e in ent]), F32(*[e[6] for e in ent]),
             F32(*[e[7] for e in ent]), F32(*[e[8] for e in ent]), I64(*[e[9] for e in ent]), I64(*[e[10] for e in ent]),
-            float(b1), float(b2), float(self.eps))
+            F32(*[e[11] for e in ent]), F32(*[e[12] for e in ent]), F32(*[e[13] for e in ent]))
     with torch.no_grad(), torch.cuda.device(dev):
         with _stage("adam_multi"):
-            rc = lib.adk_adam_update_multi(*args, torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(rc, "adk_adam_update_multi")
+            rc = lib.adk_adam_update_multi_betas(*args, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "adk_adam_update_multi_betas")
     # per-row lr tensors (finetune path, h3dgsv3.py:1240-1247) keep the reference's torch decay
     for key, pd in self.params.items():
         if key in skip or key.startswith("mlp") or key not in self.lr_dict or pd["val"].grad is None:
@@ -360,26 +376,30 @@ class FusedMapperLoss(torch.autograd.Function):
             image = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             gt_used = torch.empty(3, H, W, dtype=torch.float32, device=dev) if mo else gt
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            ssim_map = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             dm = torch.empty(3, 3, H, W, dtype=torch.float32, device=dev)
             parts = torch.empty(4, dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            n_sums = int(lib.adk_fused_ssim_fwd_sums_count(1, 3, H, W))
+            sums = torch.empty(n_sums, dtype=torch.float32, device=dev)
             ws = torch.empty(int(lib.adk_photometric_workspace_bytes(W, H)), dtype=torch.uint8, device=dev)
             with _stage("photometric_fwd"):
                 rc = lib.adk_photometric_fwd(W, H, colors4.data_ptr(), alphas.data_ptr(), bg.data_ptr(), E.data_ptr(),
                                              gt.data_ptr(), mono.data_ptr(), rdk.data_ptr(), mo, image.data_ptr(),
                                              gt_used.data_ptr() if mo else None, invdepth.data_ptr(), ws.data_ptr(), ws.numel(), st)
             _lib.check(rc, "adk_photometric_fwd")
+            # only the MEAN of the SSIM map enters the loss (h3dgsv3.py:441): the kernel leaves per-strip sums and never
+            # writes the map; the loss kernel folds them with the L1 partials and writes the scalar twice (parts[0], loss)
             with _stage("ssim_fwd"):
-                rc = lib.adk_fused_ssim_fwd(image.data_ptr(), gt_used.data_ptr(), 1, 3, H, W, _SSIM_C1, _SSIM_C2,
-                                            ssim_map.data_ptr(), dm[0].data_ptr(), dm[1].data_ptr(), dm[2].data_ptr(), st)
-            _lib.check(rc, "adk_fused_ssim_fwd")
+                rc = lib.adk_fused_ssim_fwd_sums(image.data_ptr(), gt_used.data_ptr(), 1, 3, H, W, _SSIM_C1, _SSIM_C2, None,
+                                                 dm[0].data_ptr(), dm[1].data_ptr(), dm[2].data_ptr(), sums.data_ptr(), st)
+            _lib.check(rc, "adk_fused_ssim_fwd_sums")
             with _stage("photometric_loss"):
-                rc = lib.adk_photometric_loss(W, H, ssim_map.data_ptr(), lam, wd, ws.data_ptr(), ws.numel(), parts.data_ptr(), st)
-            _lib.check(rc, "adk_photometric_loss")
+                rc = lib.adk_photometric_loss_sums(W, H, sums.data_ptr(), n_sums, lam, wd, ws.data_ptr(), ws.numel(),
+                                                   parts.data_ptr(), loss.data_ptr(), st)
+            _lib.check(rc, "adk_photometric_loss_sums")
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors4, alphas, E, bg, gt, mono, rdk, image, gt_used, dm)
         ctx.cfg = (H, W, lam, wd, mo, tuple(exposure.shape))
-        loss = parts[0].clone()
         ctx.mark_non_differentiable(image, invdepth, parts)
         return loss, image, invdepth, parts
 
@@ -425,6 +445,28 @@ def _rdk_cached(self, h, w):
         yy, xx = torch.meshgrid(y, x, indexing="ij")
         cache[key] = torch.exp(-(xx ** 2 + yy ** 2) / (2 * self.rad_decay ** 2)).to(self.device).contiguous()
     return cache[key]
+
+
+def _deferred_basic_updates():
+    """deferred_basic_updates() of the drop-in the scene's optimizers bound their adamUpdateBasic from (the top-level
+    `diff_gaussian_rasterization`, optimizers.py:14); a null context yielding None when that is not this package's."""
+    import contextlib
+    import sys
+    mod = sys.modules.get("diff_gaussian_rasterization")
+    ctx = getattr(mod, "deferred_basic_updates", None)
+    return ctx() if ctx is not None else contextlib.nullcontext(None)
+
+
+_ONES: dict = {}
+
+
+def _unit_grad(loss: torch.Tensor) -> torch.Tensor:
+    """The 1.0 that loss.backward() would otherwise build with a fill kernel on every step."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return one
 
 
 def _color_adam_state(opt):
@@ -482,11 +524,23 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     # the SH colours (48 of the 75 floats of a Gaussian) take their Adam step inside the projection backward, on
     # exactly the rows optimizer.step would touch (radii > 0); their .grad stays None and the step below skips them
     with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
-        loss.backward()
+        loss.backward(gradient=_unit_grad(loss))
     with torch.no_grad():
-        keyframe.step()
+        # Keyframe.step (scene/keyframe.py:188-192) = three adamUpdateBasic calls on 6 / 3 / 12 floats + its own counters:
+        # the calls are recorded and ride in the Gaussians' launch (one kernel instead of four)
+        step = self.optimizer.step
+        ours = getattr(step, "__func__", None) is fused_optimizer_step and not keyframe.is_test  # not a caller's override
+        extra = None
+        with _deferred_basic_updates() as pending:
+            keyframe.step()
+            if ours and pending:
+                extra = list(pending)
+                pending.clear()
         if not keyframe.is_test:
-            self.optimizer.step(vis, vis.shape[0], gvis, gvis.shape[0])
+            if extra:
+                step(vis, vis.shape[0], gvis, gvis.shape[0], extra=extra)
+            else:
+                step(vis, vis.shape[0], gvis, gvis.shape[0])
         keyframe.latest_invdepth = invdepth
     return loss.detach()
 

@@ -364,7 +364,7 @@ class RasterizeGaussians(torch.autograd.Function):
             v_viewmat = cam_grad = None
             if needs[6]:
                 v_viewmat = torch.empty(4, 4, dtype=torch.float32, device=dev)
-                cam_grad = torch.zeros(16, dtype=torch.float32, device=dev)
+                cam_grad = _cam_grad_scratch(dev, stream)
             opt = _color_adam_for(colors, rest) if (want_col_grads and ctx.has_rest and cfg.color_mode == _COLOR_SH) else None
             if opt is not None:
                 with _stage("project_bwd"):
@@ -387,6 +387,19 @@ class RasterizeGaussians(torch.autograd.Function):
                                      _lib.ptr(v_cols), _lib.ptr(v_rest), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), stream)
             _lib.check(rc, "adk_project_bwd")
         return v_means, v_quats, v_scales, v_opac, v_cols, v_rest, v_viewmat, None, None, None
+
+
+_CAM_GRAD: dict = {}
+
+
+def _cam_grad_scratch(dev, stream) -> torch.Tensor:
+    """The 16-float accumulator of the camera gradient: adk_project_bwd leaves it zeroed again, so one per (device,
+    stream) is cleared ONCE instead of a fill kernel per step."""
+    key = (dev.index, int(stream or 0))
+    buf = _CAM_GRAD.get(key)
+    if buf is None:
+        buf = _CAM_GRAD[key] = torch.zeros(16, dtype=torch.float32, device=dev)
+    return buf
 
 
 def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,

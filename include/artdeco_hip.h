@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 10
+#define ADK_ABI_VERSION 11
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -56,6 +56,15 @@ int adk_stream_copy(void* dst, const void* src, int64_t nbytes, adk_stream_t str
 int adk_fused_ssim_fwd(const float* img1, const float* img2, int B, int CH, int H, int W,
                        float C1, float C2, float* ssim_map, float* dm_dmu1,
                        float* dm_dsigma1_sq, float* dm_dsigma12, adk_stream_t stream);
+
+/* The training forward for a caller that only needs map.mean() (fused_ssim/__init__.py:42; the mapper's loss,
+ * h3dgsv3.py:441): besides the dm_* maps it leaves sum(ssim_map) as adk_fused_ssim_fwd_sums_count(B,CH,H,W) partial
+ * sums (one per strip of the kernel's grid, fixed order => deterministic) in block_sums; ssim_map may be NULL, in
+ * which case the map is never written.  adk_photometric_loss_sums consumes them. */
+int64_t adk_fused_ssim_fwd_sums_count(int B, int CH, int H, int W);
+int adk_fused_ssim_fwd_sums(const float* img1, const float* img2, int B, int CH, int H, int W, float C1, float C2,
+                            float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                            float* block_sums, adk_stream_t stream);
 
 /* dL_dmap: [B,CH,H,W], or NULL meaning "every element equals dL_scalar" (the
  * gradient of map.mean(), __init__.py:42) which saves one 4 B/px read.
@@ -92,6 +101,14 @@ int adk_adam_update_multi(int n, float* const* params, const float* const* grads
                           const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
                           const float* lr_mins, const int64_t* rows, const int64_t* Ms, float b1, float b2,
                           float eps, adk_stream_t stream);
+/* The same with one Adam configuration PER TENSOR (b1s, b2s, epss: host arrays of length n): the keyframe's own
+ * BaseAdam (scene/keyframe.py:113-125, betas (0.8, 0.99), three adamUpdateBasic calls of 6 / 3 / 12 floats per step,
+ * optimizers.py:41-57) rides in the Gaussians' launch. */
+int adk_adam_update_multi_betas(int n, float* const* params, const float* const* grads, float* const* exp_avgs,
+                                float* const* exp_avg_sqs, const uint8_t* const* visibles, float* const* lr_ptrs,
+                                const int64_t* lr_numels, const float* lr_vals, const float* lr_decays,
+                                const float* lr_mins, const int64_t* rows, const int64_t* Ms, const float* b1s,
+                                const float* b2s, const float* epss, adk_stream_t stream);
 
 /* ---------------------------------------------------------------------- gsplat
  * The five stages behind gsplat.rendering.rasterization(...) [UPSTREAM gsplat >= 1.5, not
@@ -124,7 +141,8 @@ int adk_project_fwd(int N, const float* means, const float* quats, const float* 
 
 /* Replaces fully_fused_projection bwd + spherical_harmonics bwd (+ the torch.inverse(viewmats)
  * autograd edge of rasterization()).  Any v_* output may be NULL.  cam_grad: 16 zeroed floats of
- * scratch, required iff v_viewmat [4,4] is requested. */
+ * scratch, required iff v_viewmat [4,4] is requested; the call leaves them zeroed again (stream-ordered), so a caller
+ * may keep one accumulator per stream instead of clearing a fresh one for every call. */
 int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
                     const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
                     const float* viewmat, const float* Kmat, int width, int height, float eps2d,
@@ -344,6 +362,12 @@ int adk_photometric_fwd(int W, int H, const float* colors4, const float* alphas,
  * ssim_map [3,H,W] from adk_fused_ssim_fwd(image, gt).  Same workspace, same stream, after _fwd. */
 int adk_photometric_loss(int W, int H, const float* ssim_map, float lambda_dssim, float depth_weight,
                          void* workspace, int64_t workspace_bytes, float* loss_out, adk_stream_t stream);
+/* The same from the n_sums partial sums of adk_fused_ssim_fwd_sums(image, gt) instead of the map (one launch, no pass
+ * over the map).  total_out (nullable): a second copy of loss_out[0] in a buffer of its own, so that a binding can hand
+ * out the differentiable scalar and the by-product vector as two tensors without a copy kernel. */
+int adk_photometric_loss_sums(int W, int H, const float* ssim_block_sums, int64_t n_sums, float lambda_dssim,
+                              float depth_weight, void* workspace, int64_t workspace_bytes, float* loss_out,
+                              float* total_out, adk_stream_t stream);
 /* Backward of the whole chain.  v_image_ssim [3,H,W]: adk_fused_ssim_bwd(...) with dL_dmap = NULL and
  * dL_scalar = -lambda / (3 W H); v_loss: DEVICE scalar, autograd's gradient of the loss.  Writes
  * v_colors4 [H,W,4], v_alphas [H,W] (the layouts adk_raster_bwd consumes) and v_exposure [12]. */

@@ -295,6 +295,83 @@ def test_fused_optimizer_step_is_bit_identical(dev):
 
 
 @pytest.mark.gpu
+def test_keyframe_adam_rides_in_the_gaussians_launch_bit_identically(dev):
+    """Keyframe.step's three adamUpdateBasic calls (betas 0.8 / 0.99, scene/keyframe.py:113-125) recorded by
+    deferred_basic_updates and packed into fused_optimizer_step's launch == the same calls launched one by one; the
+    Gaussians' own tensors (betas of SparseGaussianAdam) are untouched by the extra entries."""
+    from artdeco_amd import fused
+    a = _scene(dev, N=3000, seed=11)
+    import diff_gaussian_rasterization as dgr   # the drop-in (harness.mapper put it on sys.path)
+    a.optimization_step(0)
+    vis = torch.rand(3000, device=dev) < 0.7
+    gvis = torch.rand(a.global_feat.shape[0], device=dev) < 0.5
+    g = torch.Generator().manual_seed(4)
+    shapes = {"rW2C": (3, 2), "tW2C": (3,), "exposure": (3, 4)}
+    small = {k: [torch.randn(sh, generator=g).to(dev) for _ in range(3)] + [torch.rand(sh, generator=g).to(dev)] for k, sh in shapes.items()}
+    lrs = {"rW2C": 1e-3, "tW2C": 2e-3, "exposure": 5e-4}
+
+    def run(merged):
+        st = {k: [t.clone() for t in v] for k, v in small.items()}           # param, grad, exp_avg, exp_avg_sq
+        snap = {k: [v["val"].detach().clone(), v["exp_avg"].clone(), v["exp_avg_sq"].clone(),
+                    (v["lr"].clone() if torch.is_tensor(v["lr"]) else v["lr"])] for k, v in a.optimizer.params.items()
+                if k not in ("id", "cls_id", "d_max")}
+        gr = {k: v["val"].grad for k, v in a.optimizer.params.items()}
+        with dgr.deferred_basic_updates() as pending:
+            for k, (p_, g_, m_, v_) in st.items():
+                dgr.adamUpdateBasic(p_, g_, m_, v_, lrs[k], 0.8, 0.99, 1e-15)
+            assert len(pending) == 3 and all(torch.equal(st[k][0], small[k][0]) for k in st)   # nothing ran yet
+            extra = None
+            if merged:
+                extra = list(pending)
+                pending.clear()
+        fused.fused_optimizer_step(a.optimizer, vis, 3000, gvis, gvis.shape[0], extra=extra)
+        out = {k: [t.clone() for t in v] for k, v in st.items()}
+        gauss = {k: [a.optimizer.params[k]["val"].detach().clone(), a.optimizer.params[k]["exp_avg"].clone()] for k in snap}
+        with torch.no_grad():
+            for k, (p_, m_, s_, lr_) in snap.items():      # the step decays per-element learning rates in place: put them back too
+                a.optimizer.params[k]["val"].copy_(p_); a.optimizer.params[k]["exp_avg"].copy_(m_); a.optimizer.params[k]["exp_avg_sq"].copy_(s_)
+                if torch.is_tensor(lr_):
+                    a.optimizer.params[k]["lr"].copy_(lr_)
+                else:
+                    a.optimizer.params[k]["lr"] = lr_
+                a.optimizer.params[k]["val"].grad = gr[k]
+        return out, gauss
+
+    one_by_one, g1 = run(False)
+    merged, g2 = run(True)
+    for k in shapes:
+        assert not torch.equal(one_by_one[k][0], small[k][0])                # the update happened
+        for i in (0, 2, 3):
+            assert torch.equal(merged[k][i], one_by_one[k][i]), (k, i)
+    for k in g1:
+        assert torch.equal(g1[k][0], g2[k][0]) and torch.equal(g1[k][1], g2[k][1]), k
+
+
+@pytest.mark.gpu
+def test_fused_step_updates_the_keyframe_like_the_unmerged_path(dev):
+    """A fused step whose optimizer.step is overridden by the caller (so nothing is merged) and the normal fused step
+    move the keyframe's pose / exposure state the same way: counters, moments populated, gradients consumed."""
+    from artdeco_amd import fused
+    a, b = _scene(dev, N=4000, seed=2), _scene(dev, N=4000, seed=2)
+    assert fused.patch_scene_model(a) and fused.patch_scene_model(b)
+    orig = b.optimizer.step
+    b.optimizer.step = lambda *args, **kw: orig(*args, **kw)                 # a caller's override: the merged launch must not bypass it
+    torch.manual_seed(0)
+    la = float(a.optimization_step(1))
+    torch.manual_seed(0)
+    lb = float(b.optimization_step(1))
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(la))
+    ka, kb = a.keyframes[1], b.keyframes[1]
+    assert ka.depth_loss_weight == kb.depth_loss_weight
+    for name in ("rW2C", "tW2C", "exposure"):
+        pa, pb = ka.optimizer.params[name], kb.optimizer.params[name]
+        assert float(pa["exp_avg"].abs().sum()) > 0 and float(pb["exp_avg"].abs().sum()) > 0
+        # atomics in the rasteriser's backward make two renders differ in the last bits; Adam normalises, so compare moments
+        ga, gb = pa["exp_avg"].double(), pb["exp_avg"].double()
+        assert float((ga - gb).norm() / (gb.norm() + 1e-30)) <= 1e-3, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,deg", [(5000, 3), (777, 3), (1300, 2)])
 def test_colour_adam_inside_backward_is_bit_identical(N, deg, dev):
     """adk_project_bwd_adam (sparse-Adam step of f_dc / f_rest inside the projection backward) leaves the same

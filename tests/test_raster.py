@@ -188,6 +188,25 @@ def test_backward_matches_fp64_autograd_oracle(N, W, H, seed, dev):
 
 
 @pytest.mark.gpu
+def test_camera_gradient_accumulator_is_left_zeroed(dev):
+    """adk_project_bwd hands its 16-float cam_grad scratch back zeroed (include/artdeco_hip.h), which is what lets the
+    binding keep one per stream: two backward passes in a row give the same view-matrix gradient (up to the order of the
+    atomics), not the sum of both, and the cached accumulators read zero afterwards."""
+    from artdeco_amd import rasterizer
+    sc = dict(_scene(3000, 128, 96, 4), viewmat=_tilted_viewmat(3))
+    grads = []
+    for _ in range(3):
+        r, a, meta, hl = _run_hip(sc, dev, requires_grad=True)
+        (r[0].square().sum() + a[0].sum()).backward()
+        grads.append(hl["viewmat"].grad.double().cpu())
+    assert float(grads[0][:3].abs().max()) > 0
+    for g in grads[1:]:
+        assert float((g - grads[0]).abs().max()) <= 1e-4 * float(grads[0].abs().max())
+    torch.cuda.synchronize()
+    assert rasterizer._CAM_GRAD and all(float(b.abs().max()) == 0.0 for b in rasterizer._CAM_GRAD.values())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,W,H", [(1_000_000, 1920, 1080), (4_000_000, 2592, 1944)])
 def test_binning_is_bit_exact_at_baseline_sizes(N, W, H, dev):
     """BASELINE configs[2] and configs[3] at FULL size: radii, tiles per Gaussian, the sorted 64-bit (tile | depth-bits)

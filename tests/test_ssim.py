@@ -123,3 +123,37 @@ def test_hip_full_resolution_properties(dev):
     mba = fusedssim(1e-4, 9e-4, b, a, False)[0]
     assert torch.allclose(mab, mba, rtol=0, atol=3e-5)  # symmetric up to fp32 cancellation error
     assert mab.max() <= 1.0 + 1e-5 and mab.min() >= -1.0 - 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 96, 160), (1, 3, 1080, 1920), (2, 1, 37, 70)])
+def test_forward_with_strip_sums(shape, dev):
+    """adk_fused_ssim_fwd_sums: the dm_* maps (and the optional map) are bit-identical to adk_fused_ssim_fwd, the strip sums add up
+    to sum(ssim_map), are the same bits on every run, and ssim_map = NULL really skips the map."""
+    from artdeco_amd import _lib
+    lib = _lib.load()
+    B, CH, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.rand(shape, generator=g).to(dev), torch.rand(shape, generator=g).to(dev)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ref = [torch.empty(shape, device=dev) for _ in range(4)]
+    assert lib.adk_fused_ssim_fwd(x.data_ptr(), y.data_ptr(), B, CH, H, W, C1, C2, *[t.data_ptr() for t in ref], st) == 0
+    n = int(lib.adk_fused_ssim_fwd_sums_count(B, CH, H, W))
+    assert n > 0
+    got = [torch.full(shape, 7.0, device=dev) for _ in range(4)]
+    sums = torch.full((n,), float("nan"), device=dev)
+    assert lib.adk_fused_ssim_fwd_sums(x.data_ptr(), y.data_ptr(), B, CH, H, W, C1, C2, *[t.data_ptr() for t in got], sums.data_ptr(), st) == 0
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(sums).all())
+    total, want = float(sums.double().sum()), float(ref[0].double().sum())
+    assert abs(total - want) <= 2e-6 * abs(want)
+    got2 = [torch.full(shape, 7.0, device=dev) for _ in range(3)]
+    sums2 = torch.empty(n, device=dev)
+    assert lib.adk_fused_ssim_fwd_sums(x.data_ptr(), y.data_ptr(), B, CH, H, W, C1, C2, None, *[t.data_ptr() for t in got2], sums2.data_ptr(), st) == 0
+    assert torch.equal(sums2, sums)
+    for a, b in zip(got2, ref[1:]):
+        assert torch.equal(a, b)
+    # the sums are a training-mode output: the dm_* maps are required
+    assert lib.adk_fused_ssim_fwd_sums(x.data_ptr(), y.data_ptr(), B, CH, H, W, C1, C2, None, None, None, None, sums2.data_ptr(), st) != 0
