@@ -487,6 +487,108 @@ def _color_adam_state(opt):
         return None
 
 
+def _apply_steps(self, keyframe, vis, gvis, invdepth):
+    """Pose / exposure step of the keyframe, sparse-Adam step of the Gaussians, latest_invdepth (h3dgsv3.py:456-464)."""
+    with torch.no_grad():
+        # Keyframe.step (scene/keyframe.py:188-192) = three adamUpdateBasic calls on 6 / 3 / 12 floats + its own counters:
+        # the calls are recorded and ride in the Gaussians' launch (one kernel instead of four)
+        step = self.optimizer.step
+        ours = getattr(step, "__func__", None) is fused_optimizer_step and not keyframe.is_test  # not a caller's override
+        extra = None
+        with _deferred_basic_updates() as pending:
+            keyframe.step()
+            if ours and pending:
+                extra = list(pending)
+                pending.clear()
+        if not keyframe.is_test:
+            if extra:
+                step(vis, vis.shape[0], gvis, gvis.shape[0], extra=extra)
+            else:
+                step(vis, vis.shape[0], gvis, gvis.shape[0])
+        keyframe.latest_invdepth = invdepth
+
+
+def _accumulate(leaf: torch.Tensor, grad: torch.Tensor | None) -> None:
+    """What autograd's AccumulateGrad does with a gradient that reaches a leaf."""
+    if grad is None or not leaf.requires_grad:
+        return
+    if grad.shape != leaf.shape:
+        grad = grad.view(leaf.shape)
+    if leaf.grad is None:
+        leaf.grad = grad
+    else:
+        leaf.grad += grad
+
+
+def _hand_chain_ok(self, keyframe) -> bool:
+    """The hand-driven chain covers run.sh's configuration: pose parameters on the device in float32, no scaling
+    regulariser (a torch expression on `scaling` needs the autograd graph), ARTDECO_AMD_HAND_CHAIN != 0."""
+    return (self.scaling_reg_factor == 0 and keyframe.rW2C.is_cuda and keyframe.rW2C.dtype == torch.float32
+            and keyframe.tW2C.is_cuda and os.environ.get("ARTDECO_AMD_HAND_CHAIN", "1") != "0" and torch.is_grad_enabled())
+
+
+def _train_on_keyframe_by_hand(self, keyframe, is_important):
+    """fused_train_on_keyframe without the autograd engine.  The chain is fixed -- PoseRt -> FusedLodParams ->
+    RasterizeGaussians -> FusedMapperLoss and back -- so the four Functions' forward / backward static methods are called
+    directly, in that order, on rasterizer.HandCtx objects, and the gradients are handed to the leaves the way
+    AccumulateGrad would (.grad was cleared by zero_grad just before).  Same kernels, same launch order, same results;
+    what disappears is the graph construction, the hop to the engine's device thread and back, and its bookkeeping
+    (about a third of the host time of a step, tools/lab/host_profile.py)."""
+    HandCtx = rasterizer.HandCtx
+    dev = self.device
+    lvl = keyframe.pyr_lvl
+    bg = torch.rand(3, device=dev)
+    scale = 2 ** lvl
+    width, height = self.width // scale, self.height // scale
+    P = self.gaussian_params
+    lin1, lin2 = self.mlp_cov[0], self.mlp_cov[2]
+    r6, t = keyframe.rW2C, keyframe.tW2C
+    lod_leaves = (P["xyz"]["val"], P["opacity"]["val"], P["scaling"]["val"], P["rotation"]["val"], P["local_feat"]["val"],
+                  P["global_feat"]["val"], lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+    f_dc, f_rest = P["f_dc"]["val"], P["f_rest"]["val"]
+    with torch.no_grad():
+        c_pose = HandCtx()
+        view_matrix = PoseRt.forward(c_pose, r6, t)
+        lock = getattr(self, "lock", None)
+        if lock is not None:
+            lock.acquire()
+        try:
+            c_lod = HandCtx()
+            opac, scaling, quat, sel, xyz = FusedLodParams.forward(c_lod, *lod_leaves, P["cls_id"]["val"], P["d_max"]["val"], view_matrix)
+            K = _intrinsics(self, width, height, dev)
+            eps2d = self.args.low_pass_filter_eps if hasattr(self, "args") else self.eps2d
+            cfg, cols, rest = rasterizer.camera_config(f_dc, width, height, sh_degree=self.active_sh_degree, eps2d=eps2d, sh_rest=f_rest)
+            lod_grad = any(x.requires_grad for x in lod_leaves)
+            c_ras = HandCtx((xyz.requires_grad, lod_grad, lod_grad, lod_grad, f_dc.requires_grad, f_rest.requires_grad,
+                             r6.requires_grad or t.requires_grad, False, False, False))
+            out = rasterizer.RasterizeGaussians.forward(c_ras, xyz, quat, scaling, opac, cols, rest, view_matrix, K, None, cfg)
+            col4, alphas, radii = out[0], out[1], out[2]
+            vis, gvis = visibility_masks(radii, P["cls_id"]["val"], P["global_feat"]["val"].shape[0])
+        finally:
+            if lock is not None:
+                lock.release()
+        c_loss = HandCtx()
+        loss, _image, invdepth, _parts = FusedMapperLoss.forward(
+            c_loss, col4, alphas, keyframe.exposure, bg, keyframe.image_pyr[lvl], keyframe.get_mono_idepth(lvl),
+            _rdk_cached(self, height, width), self.lambda_dssim, keyframe.depth_loss_weight, not is_important)
+        # ---- backward, in the order the engine would run the nodes
+        v_col, v_alpha, v_E = FusedMapperLoss.backward(c_loss, _unit_grad(loss))[:3]
+        with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
+            v_means, v_quats, v_scales, v_opac, v_dc, v_rest, v_viewmat = rasterizer.RasterizeGaussians.backward(c_ras, v_col, v_alpha)[:7]
+        lod_grads = FusedLodParams.backward(c_lod, v_opac, v_scales, v_quats, None, v_means)[:10]
+        for leaf, g in zip(lod_leaves, lod_grads):
+            _accumulate(leaf, g)
+        _accumulate(f_dc, v_dc)
+        _accumulate(f_rest, v_rest)
+        _accumulate(keyframe.exposure, v_E)
+        if v_viewmat is not None:
+            v_r6, v_t = PoseRt.backward(c_pose, v_viewmat)
+            _accumulate(r6, v_r6)
+            _accumulate(t, v_t)
+    _apply_steps(self, keyframe, vis, gvis, invdepth)
+    return loss
+
+
 def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     """The body of SceneModel.optimization_step after the keyframe has been chosen (h3dgsv3.py:418-464): same
     order of operations (zero_grad, render at the keyframe's level with a random background, loss, backward,
@@ -495,6 +597,8 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     lvl = keyframe.pyr_lvl
     keyframe.zero_grad()
     self.optimizer.zero_grad()
+    if _hand_chain_ok(self, keyframe):
+        return _train_on_keyframe_by_hand(self, keyframe, is_important)
     dev = self.device
     bg = torch.rand(3, device=dev)
     scale = 2 ** lvl
@@ -525,23 +629,7 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     # exactly the rows optimizer.step would touch (radii > 0); their .grad stays None and the step below skips them
     with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
         loss.backward(gradient=_unit_grad(loss))
-    with torch.no_grad():
-        # Keyframe.step (scene/keyframe.py:188-192) = three adamUpdateBasic calls on 6 / 3 / 12 floats + its own counters:
-        # the calls are recorded and ride in the Gaussians' launch (one kernel instead of four)
-        step = self.optimizer.step
-        ours = getattr(step, "__func__", None) is fused_optimizer_step and not keyframe.is_test  # not a caller's override
-        extra = None
-        with _deferred_basic_updates() as pending:
-            keyframe.step()
-            if ours and pending:
-                extra = list(pending)
-                pending.clear()
-        if not keyframe.is_test:
-            if extra:
-                step(vis, vis.shape[0], gvis, gvis.shape[0], extra=extra)
-            else:
-                step(vis, vis.shape[0], gvis, gvis.shape[0])
-        keyframe.latest_invdepth = invdepth
+    _apply_steps(self, keyframe, vis, gvis, invdepth)
     return loss.detach()
 
 

@@ -252,6 +252,13 @@ class RasterizeGaussians(torch.autograd.Function):
                                      tiles_per_gauss.data_ptr(), stream)
             _lib.check(rc, "adk_project_fwd")
 
+            # the rasteriser's outputs do not depend on the list size: allocated here, BEFORE the host wait below, so that what
+            # stands between the wait and the forward rasteriser's launch is the sort's launch and nothing else
+            render_colors = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
+            render_alphas = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
+            final_T = torch.empty(H, W, dtype=torch.float32, device=dev)   # exact T_final for the backward
+            last_ids = torch.empty(H, W, **i32)
+            main_ids = torch.empty(H, W, **i32) if cfg.want_main_ids else None
             use_local = bool(lib.adk_bin_local_supported(W, H)) and os.environ.get("ADK_BIN_LOCAL", "1") != "0"
             flatten_ids = tile_ids = offsets = None
             if use_local:
@@ -299,11 +306,6 @@ class RasterizeGaussians(torch.autograd.Function):
                 flatten_ids, tile_ids, offsets, n_isects = _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids,
                                                                        tiles_per_gauss, dev, stream, i32)
 
-            render_colors = torch.empty(H, W, 4, dtype=torch.float32, device=dev)
-            render_alphas = torch.empty(H, W, 1, dtype=torch.float32, device=dev)
-            final_T = torch.empty(H, W, dtype=torch.float32, device=dev)   # exact T_final for the backward
-            last_ids = torch.empty(H, W, **i32)
-            main_ids = torch.empty(H, W, **i32) if cfg.want_main_ids else None
             with _stage("raster_fwd"):
               rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
                                     _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(), final_T.data_ptr(),
@@ -402,12 +404,9 @@ def _cam_grad_scratch(dev, stream) -> torch.Tensor:
     return buf
 
 
-def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,
-                  eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, backgrounds=None,
+def camera_config(colors, width, height, *, sh_degree, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
                   depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None):
-    """One camera.  colors: SH coefficients [N,K,3] when sh_degree is not None, else RGB [N,3]
-    (ignored when depth_only).  sh_rest: optional [N,K-1,3] -- then `colors` is band 0 only
-    ([N,1,3], ARTDECO's f_dc) and no concatenation is materialised.  backgrounds: [4] or None."""
+    """(RasterConfig, colours, sh_rest) of one render_camera call: the argument checks and the colour mode."""
     if depth_only:
         mode, K_sh, deg, cols = _COLOR_DEPTH, 0, 0, None
         sh_rest = None
@@ -431,4 +430,36 @@ def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, he
         mode, K_sh, deg, cols = _COLOR_RGB, 0, 0, colors
     cfg = RasterConfig(int(width), int(height), deg, K_sh, mode, float(eps2d), float(near_plane),
                        float(far_plane), float(radius_clip), bool(want_isect_ids), bool(inv_depth), bool(want_main_ids))
+    return cfg, cols, sh_rest
+
+
+def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,
+                  eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, backgrounds=None,
+                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None):
+    """One camera.  colors: SH coefficients [N,K,3] when sh_degree is not None, else RGB [N,3]
+    (ignored when depth_only).  sh_rest: optional [N,K-1,3] -- then `colors` is band 0 only
+    ([N,1,3], ARTDECO's f_dc) and no concatenation is materialised.  backgrounds: [4] or None."""
+    cfg, cols, sh_rest = camera_config(colors, width, height, sh_degree=sh_degree, eps2d=eps2d, near_plane=near_plane,
+                                       far_plane=far_plane, radius_clip=radius_clip, depth_only=depth_only,
+                                       want_isect_ids=want_isect_ids, inv_depth=inv_depth, want_main_ids=want_main_ids,
+                                       sh_rest=sh_rest)
     return RasterizeGaussians.apply(means, quats, scales, opacities, cols, sh_rest, viewmat, K, backgrounds, cfg)
+
+
+class HandCtx:
+    """What a torch.autograd.Function's forward / backward use of their `ctx`, for driving the two static methods by hand
+    (artdeco_amd.fused runs the mapper's fixed chain LoD -> rasteriser -> loss that way: the autograd engine -- graph
+    construction, the hop to its device thread and back, gradient accumulation -- was a third of the host time of a step)."""
+
+    def __init__(self, needs_input_grad=()):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass

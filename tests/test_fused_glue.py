@@ -145,6 +145,48 @@ def test_fused_optimization_step_gradients_match_unfused(reg, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("important", [True, False])
+def test_hand_driven_chain_matches_the_autograd_chain(important, dev, monkeypatch):
+    """fused_train_on_keyframe drives the four Functions' forward / backward by hand (no autograd engine) unless
+    ARTDECO_AMD_HAND_CHAIN=0: same loss to the bit (the forward has no atomics), the same gradient on every leaf -- Gaussian
+    parameters, mlp_cov, the keyframe's pose and exposure -- up to the order of the rasteriser's atomics, and the colours'
+    Adam step inside the projection backward in both."""
+    from artdeco_amd import fused
+    a, b = _scene(dev, N=8000, seed=9), _scene(dev, N=8000, seed=9)
+    assert fused.patch_scene_model(a) and fused.patch_scene_model(b)
+    keys = ("xyz", "scaling", "rotation", "opacity", "local_feat", "global_feat")
+    got = {}
+    for name, sc, env in (("hand", a, "1"), ("engine", b, "0")):
+        monkeypatch.setenv("ARTDECO_AMD_HAND_CHAIN", env)
+        for k in ("f_dc", "f_rest"):
+            sc.optimizer.params[k]["exp_avg"].zero_()
+        kf = sc.keyframes[1]
+        orig = sc.optimizer.step
+
+        def spy(*args, _o=orig, _sc=sc, _n=name, _kf=kf, **kw):
+            g = {k: _sc.gaussian_params[k]["val"].grad.clone() for k in keys}
+            g.update({"mlp." + n: p.grad.clone() for n, p in _sc.mlp_cov.named_parameters()})
+            g.update({"kf." + n: getattr(_kf, n).grad.clone() for n in ("rW2C", "tW2C", "exposure")})
+            assert _sc.gaussian_params["f_dc"]["val"].grad is None and _sc.gaussian_params["f_rest"]["val"].grad is None
+            got[_n] = g
+            return _o(*args, **kw)
+        sc.optimizer.step = spy
+        torch.manual_seed(5)
+        got[name + ".loss"] = sc.optimization_step(1, is_important=important)
+        sc.optimizer.step = orig
+        got[name]["f_dc.m"] = sc.optimizer.params["f_dc"]["exp_avg"].clone()
+        got[name]["f_rest.m"] = sc.optimizer.params["f_rest"]["exp_avg"].clone()
+    assert torch.equal(got["hand.loss"], got["engine.loss"])
+    assert not got["hand.loss"].requires_grad
+    assert set(got["hand"]) == set(got["engine"])
+    for k, x in got["hand"].items():
+        y = got["engine"][k]
+        assert x.shape == y.shape and float(y.abs().max()) > 0, k
+        rel = float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
+        assert rel <= 1e-5, (k, rel)
+
+
+@pytest.mark.gpu
 def test_pose_rt_matches_sixd_autograd(dev):
     """PoseRt (one kernel each way) vs Keyframe.get_Rt's torch chain (keyframe.py:150-154, utils.py:223-229)."""
     from artdeco_amd.fused import PoseRt
