@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""DEV TOOL: tools/lab/reduce_lab.hip -- is a rows-first transposing butterfly (v_permlane32/16_swap before the DPP stages)
+cheaper than the shipped wave_reduce10?  `--build-only` here (hipcc cross-compiles), run on the GPU box: checks both variants
+against a float64 sum and times them with every SIMD of the chip holding 4 waves."""
+import ctypes, os, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_build", "reduce_lab.so")
+if "--build-only" in sys.argv:
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
+                    os.path.join(HERE, "reduce_lab.hip"), "-o", SO], check=True)
+    sys.exit(0)
+import torch
+lib = ctypes.CDLL(SO)
+dev = torch.device("cuda:0")
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+g = torch.Generator().manual_seed(0)
+x = torch.randn(10, 64, generator=g).to(dev)
+o0, o1 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+s0, w0 = torch.zeros(64, dtype=torch.int32, device=dev), torch.zeros(64, dtype=torch.int32, device=dev)
+assert lib.reduce_lab_check(P(x), P(o0), P(s0), P(w0), P(o1), st()) == 0
+torch.cuda.synchronize()
+want = x.double().sum(dim=1).cpu()
+bad0 = [(l, int(s0[l]), float(o0[l]), float(want[int(s0[l])])) for l in range(64) if int(w0[l]) and abs(float(o0[l]) - float(want[int(s0[l])])) > 1e-4]
+layout = {0: [0, 2, 1, 3], 1: [8, 8, 9, 9], 2: [4, 6, 5, 7], 3: [8, 8, 9, 9]}
+bad1 = []
+for l in range(64):
+    k = layout[(l % 16) // 4][l // 16]
+    if abs(float(o1[l]) - float(want[k])) > 1e-4:
+        bad1.append((l, k, float(o1[l]), float(want[k])))
+print("shipped reduce: owners", int(w0.sum()), "mismatches", bad0[:4])
+print("rows-first reduce: mismatches", bad1[:4])
+blocks, iters = 256 * 4 * 4, 4000          # 4 waves on every SIMD
+out = torch.zeros(blocks * 64, device=dev)
+for variant, name in ((0, "shipped (in-row DPP stages first)"), (1, "rows first (permlane swaps, then DPP)")):
+    for _ in range(2):
+        lib.reduce_lab_time(variant, blocks, iters, P(out), st())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        lib.reduce_lab_time(variant, blocks, iters, P(out), st())
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    # cycles per reduction per wave slot: 4 waves share a SIMD, so SIMD cycles per reduction = ms * 2.4e6 / (iters * 4)
+    print(f"{name:42s} {ms:8.3f} ms  = {ms * 2.4e6 / (iters * 4):6.1f} SIMD cycles per (10 fma + reduction)")
