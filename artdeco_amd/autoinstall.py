@@ -6,7 +6,9 @@
 POST-IMPORT hook: once a module `...scene.scene_models.<name>` has been executed, its `SceneModel.__init__` is wrapped so
 that every constructed scene model gets `artdeco_amd.fused.patch_scene_model(self)` -- the fused HIP paths for `render`,
 `render_from_id`, `optimization_step`, `optimizer.step` / `add_and_prune` and `weed_out_gaussians`, same signatures and
-results (tests/test_fused_glue.py), installed only when the model has the supported shapes (`fused.supported`).  So an
+results (tests/test_fused_glue.py), installed only when the model has the supported shapes (`fused.supported`) AND the
+source of every ARTDECO method a fused path mirrors still hashes to the version it was written against
+(`artdeco_amd/pins.py`, `reference_pins.json`; a moved method disables its group with one warning).  So an
 UNCHANGED run_system.py with `PYTHONPATH=<repo>:<repo>/artdeco_amd/dropin` runs the fused mapper step.
 
     ARTDECO_AMD_AUTOFUSE=0      natives only: ARTDECO's own torch glue around them (the "unchanged host code" bench lines)
@@ -41,7 +43,7 @@ def _wrap_scene_model(module) -> None:
         orig_init(self, *args, **kwargs)
         if _autofuse_enabled():
             from artdeco_amd import fused
-            self._artdeco_amd_fused = bool(fused.patch_scene_model(self))
+            self._artdeco_amd_fused = bool(fused.patch_scene_model(self, verify=True))
 
     cls.__init__ = __init__
     cls._artdeco_amd_autofuse = True

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void vox_min_kernel(const float* __restrict__ 
         const float* p = vox_point(xyz, N, new_xyz, i);
 #pragma unroll
         for (int c = 0; c < 3; ++c) k[c] = min(k[c], vox_f32_key(p[c]));
-        if (i < N) mc = max(mc, (long long)cls[i]);
+        // a negative class id (never produced by ARTDECO) would be truncated by the 32-bit sort keys: report it as an
+        // out-of-range maximum, which adk_voxel_assign refuses (ADK_EUNSUPPORTED -> the caller's torch path)
+        if (i < N) { const long long c = (long long)cls[i]; mc = max(mc, c < 0 ? 0x7fffffffffffffffLL : c); }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {

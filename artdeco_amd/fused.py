@@ -290,25 +290,27 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global, extra
         ent.append((param, grad, m, v, None, None, float(lr), 1.0, 0.0, param.numel(), 1, float(eb1), float(eb2), float(eeps)))
     if not ent:
         return
-    n = len(ent)
-    if n > 16:
-        raise _lib.AdkError("fused optimizer step supports at most 16 tensors")
     dev = ent[0][0].device
-    VP, I64, F32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_float * n
     ptr = lambda t: None if t is None else t.data_ptr()
     for e in ent:
         for t in (e[0], e[2], e[3]):
             if not t.is_contiguous() or t.dtype != torch.float32:
                 raise _lib.AdkError("fused optimizer step needs contiguous float32 parameters and moments")
-    args = (n, VP(*[e[0].data_ptr() for e in ent]), VP(*[e[1].data_ptr() for e in ent]), VP(*[e[2].data_ptr() for e in ent]),
-            VP(*[e[3].data_ptr() for e in ent]), VP(*[ptr(e[4]) for e in ent]), VP(*[ptr(e[5]) for e in ent]),
-            I64(*[(e[5].numel() if e[5] is not None else 0) for e in ent]), F32(*[e[6] for e in ent]),
-            F32(*[e[7] for e in ent]), F32(*[e[8] for e in ent]), I64(*[e[9] for e in ent]), I64(*[e[10] for e in ent]),
-            F32(*[e[11] for e in ent]), F32(*[e[12] for e in ent]), F32(*[e[13] for e in ent]))
-    with torch.no_grad(), torch.cuda.device(dev):
-        with _stage("adam_multi"):
-            rc = lib.adk_adam_update_multi_betas(*args, torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(rc, "adk_adam_update_multi_betas")
+    # one launch takes ADAM_MAX_TENSORS = 16 tensors (csrc/adam.hip); run.sh's scene has 8 Gaussian tensors + 4 mlp + 3 of the
+    # keyframe = 15, anything beyond that goes into a second launch instead of failing
+    for lo in range(0, len(ent), 16):
+        part = ent[lo:lo + 16]
+        n = len(part)
+        VP, I64, F32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_float * n
+        args = (n, VP(*[e[0].data_ptr() for e in part]), VP(*[e[1].data_ptr() for e in part]), VP(*[e[2].data_ptr() for e in part]),
+                VP(*[e[3].data_ptr() for e in part]), VP(*[ptr(e[4]) for e in part]), VP(*[ptr(e[5]) for e in part]),
+                I64(*[(e[5].numel() if e[5] is not None else 0) for e in part]), F32(*[e[6] for e in part]),
+                F32(*[e[7] for e in part]), F32(*[e[8] for e in part]), I64(*[e[9] for e in part]), I64(*[e[10] for e in part]),
+                F32(*[e[11] for e in part]), F32(*[e[12] for e in part]), F32(*[e[13] for e in part]))
+        with torch.no_grad(), torch.cuda.device(dev):
+            with _stage("adam_multi"):
+                rc = lib.adk_adam_update_multi_betas(*args, torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "adk_adam_update_multi_betas")
     # per-row lr tensors (finetune path, h3dgsv3.py:1240-1247) keep the reference's torch decay
     for key, pd in self.params.items():
         if key in skip or key.startswith("mlp") or key not in self.lr_dict or pd["val"].grad is None:
@@ -494,17 +496,18 @@ def _apply_steps(self, keyframe, vis, gvis, invdepth):
         # the calls are recorded and ride in the Gaussians' launch (one kernel instead of four)
         step = self.optimizer.step
         ours = getattr(step, "__func__", None) is fused_optimizer_step and not keyframe.is_test  # not a caller's override
-        extra = None
         with _deferred_basic_updates() as pending:
             keyframe.step()
+            # the recorded updates stay queued until the multi-tensor launch that carries them has been issued: if that
+            # raises, leaving the context flushes them one by one (the drop-in's own behaviour) and nothing is lost
             if ours and pending:
-                extra = list(pending)
+                step(vis, vis.shape[0], gvis, gvis.shape[0], extra=list(pending))
                 pending.clear()
-        if not keyframe.is_test:
-            if extra:
-                step(vis, vis.shape[0], gvis, gvis.shape[0], extra=extra)
+                ours_done = True
             else:
-                step(vis, vis.shape[0], gvis, gvis.shape[0])
+                ours_done = False
+        if not keyframe.is_test and not ours_done:
+            step(vis, vis.shape[0], gvis, gvis.shape[0])
         keyframe.latest_invdepth = invdepth
 
 
@@ -799,16 +802,27 @@ def update_voxel_device(new_xyz: torch.Tensor, xyz: torch.Tensor, cls_id: torch.
 
 
 def fused_update_voxel(self, new_xyz, xyz, cls_id, voxel_size=0.1):
-    """Drop-in body for SceneModel.update_voxel."""
-    return update_voxel_device(new_xyz, xyz, cls_id, voxel_size)
+    """Drop-in body for SceneModel.update_voxel.  Inputs the device path does not take (CPU tensors; a grid too large for its
+    hash words or class ids outside [0, 2^31): ADK_EUNSUPPORTED) go to the reference's own torch body, which the patch kept."""
+    unfused = getattr(self, "_unfused_update_voxel", None)
+    if unfused is not None and not (torch.is_tensor(new_xyz) and new_xyz.is_cuda):
+        return unfused(new_xyz, xyz, cls_id, voxel_size)
+    try:
+        return update_voxel_device(new_xyz, xyz, cls_id, voxel_size)
+    except _lib.AdkError as e:
+        if unfused is None or "ADK_EUNSUPPORTED" not in str(e):
+            raise
+        return unfused(new_xyz, xyz, cls_id, voxel_size)
 
 
-def _patch_optimizer(opt) -> None:
-    if opt is None or not (hasattr(opt, "lr_dict") and hasattr(opt, "params")) or hasattr(opt, "_unfused_step"):
+def _patch_optimizer(opt, step_ok: bool = True, densify_ok: bool = True) -> None:
+    if opt is None or not (hasattr(opt, "lr_dict") and hasattr(opt, "params")) or hasattr(opt, "_artdeco_amd_patched"):
         return
-    opt._unfused_step = opt.step
-    opt.step = types.MethodType(fused_optimizer_step, opt)
-    if hasattr(opt, "add_and_prune"):
+    opt._artdeco_amd_patched = True
+    if step_ok:
+        opt._unfused_step = opt.step
+        opt.step = types.MethodType(fused_optimizer_step, opt)
+    if densify_ok and hasattr(opt, "add_and_prune"):
         opt._unfused_add_and_prune = opt.add_and_prune
         opt.add_and_prune = types.MethodType(fused_add_and_prune, opt)
 
@@ -816,15 +830,16 @@ def _patch_optimizer(opt) -> None:
 _GC_FROZEN = False
 
 
-def _freeze_gc_once() -> None:
+def freeze_gc(force: bool = True) -> None:
     """Move everything alive now (torch, the model classes, the scene: ~1 M long-lived objects) into the collector's permanent
     generation.  A fused step costs ~1.4 ms of host time against ~2.05 ms of GPU time and reads one count back per step, so the
     host is never more than one step ahead: a full (generation-2) collection walking those objects stalls it for 3-8 ms every
     ~45 steps and the GPU idles with it (tools/step_trace.py: 2.36-2.42 ms/step in the 20-step windows that contain one, 2.06
     in those that do not).  Frozen objects are skipped, so the periodic collection only sees what the steps allocate.
-    `ARTDECO_AMD_GC_FREEZE=0` leaves the collector alone."""
+    A process-wide side effect on someone else's program, therefore OPT-IN: the library never does this on import or on
+    patch_scene_model unless `ARTDECO_AMD_GC_FREEZE=1` is set; a host program (bench.py does) calls freeze_gc() itself."""
     global _GC_FROZEN
-    if _GC_FROZEN or os.environ.get("ARTDECO_AMD_GC_FREEZE", "1") == "0":
+    if _GC_FROZEN or not (force or os.environ.get("ARTDECO_AMD_GC_FREEZE", "0") == "1"):
         return
     import gc
     gc.collect()
@@ -832,36 +847,49 @@ def _freeze_gc_once() -> None:
     _GC_FROZEN = True
 
 
-def patch_scene_model(scene) -> bool:
-    """Install fused_render on this scene-model instance (ARTDECO's SceneModel or harness.mapper.MapperScene).
-    Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones."""
+def patch_scene_model(scene, verify: bool = False) -> bool:
+    """Install the fused paths on this scene-model instance (ARTDECO's SceneModel or harness.mapper.MapperScene).
+    Returns False (and leaves the object untouched) when the mlp/feature shapes are not the supported ones.
+    verify=True (what the drop-ins' post-import hook passes for ARTDECO's own class): the source of every host method a
+    fused path mirrors is compared with the pinned hashes first (artdeco_amd/pins.py); a group -- "step": render /
+    render_from_id / optimization_step / optimizer.step, "densify": update_voxel / weed_out_gaussians / add_new_gaussians /
+    add_and_prune -- whose sources moved is left as ARTDECO wrote it (one warning), running on the native operators only."""
     if not supported(scene):
         return False
-    _freeze_gc_once()
-    scene._unfused_render = scene.render
-    scene.render = types.MethodType(fused_render, scene)
-    if hasattr(scene, "render_from_id"):
-        scene._unfused_render_from_id = scene.render_from_id
-        scene.render_from_id = types.MethodType(fused_render_from_id, scene)
-    _patch_optimizer(getattr(scene, "optimizer", None))
-    if hasattr(scene, "reset_optimizer") and not hasattr(scene, "_unfused_reset_optimizer"):
+    skip: dict = {}
+    if verify:
+        from . import pins
+        skip = pins.verify(scene)
+        pins.warn_once(skip)
+    scene._artdeco_amd_skipped = dict(skip)
+    freeze_gc(force=False)   # only with ARTDECO_AMD_GC_FREEZE=1: never a side effect of an import
+    step_ok, densify_ok = "step" not in skip, "densify" not in skip
+    if step_ok:
+        scene._unfused_render = scene.render
+        scene.render = types.MethodType(fused_render, scene)
+        if hasattr(scene, "render_from_id"):
+            scene._unfused_render_from_id = scene.render_from_id
+            scene.render_from_id = types.MethodType(fused_render_from_id, scene)
+    _patch_optimizer(getattr(scene, "optimizer", None), step_ok, densify_ok)
+    if hasattr(scene, "reset_optimizer") and not hasattr(scene, "_unfused_reset_optimizer") and (step_ok or densify_ok):
         # SceneModel.reset_optimizer builds a NEW SparseGaussianAdam (h3dgsv3.py:317-330, called at the start of every
         # finetune epoch, :1234): patch the replacement as well, or the fused step silently disappears
         scene._unfused_reset_optimizer = scene.reset_optimizer
 
         def _reset_and_repatch(self, *a, **kw):
             r = self._unfused_reset_optimizer(*a, **kw)
-            _patch_optimizer(getattr(self, "optimizer", None))
+            _patch_optimizer(getattr(self, "optimizer", None), step_ok, densify_ok)
             return r
         scene.reset_optimizer = types.MethodType(_reset_and_repatch, scene)
-    if hasattr(scene, "optimization_step") and hasattr(scene, "lambda_dssim") and hasattr(scene, "rad_decay"):
+    if step_ok and hasattr(scene, "optimization_step") and hasattr(scene, "lambda_dssim") and hasattr(scene, "rad_decay"):
         scene._unfused_optimization_step = scene.optimization_step
         body = fused_optimization_step if hasattr(scene, "get_training_id") else fused_optimization_step_mirror
         scene.optimization_step = types.MethodType(body, scene)
-    if hasattr(scene, "update_voxel"):
-        scene._unfused_update_voxel = scene.update_voxel
-        scene.update_voxel = types.MethodType(fused_update_voxel, scene)
-    if hasattr(scene, "weed_out_gaussians") and hasattr(scene, "make_dummy_ext_tensor"):
-        scene._unfused_weed_out_gaussians = scene.weed_out_gaussians
-        scene.weed_out_gaussians = types.MethodType(fused_weed_out_gaussians, scene)
+    if densify_ok:
+        if hasattr(scene, "update_voxel"):
+            scene._unfused_update_voxel = scene.update_voxel
+            scene.update_voxel = types.MethodType(fused_update_voxel, scene)
+        if hasattr(scene, "weed_out_gaussians") and hasattr(scene, "make_dummy_ext_tensor"):
+            scene._unfused_weed_out_gaussians = scene.weed_out_gaussians
+            scene.weed_out_gaussians = types.MethodType(fused_weed_out_gaussians, scene)
     return True

@@ -401,8 +401,9 @@ class AsymmetricMASt3R(nn.Module):
         """TF32-class mode on the GPU: residual add + LayerNorm + operand cast run as one HIP launch per sub-layer
         (ADK_MAST3R_FUSED_NORM=0 keeps the three torch kernels, for A/B measurements and the equivalence test)."""
         import os
+        C = x.shape[-1]   # what adk_add_layernorm takes (fused_norm.supported); anything else keeps the torch kernels
         return bool(getattr(self, "_fp32_stream", False) and x.is_cuda and self.patch_embed.proj.weight.dtype == torch.float16
-                    and os.environ.get("ADK_MAST3R_FUSED_NORM", "1") != "0")
+                    and C % 4 == 0 and C <= 2048 and os.environ.get("ADK_MAST3R_FUSED_NORM", "1") != "0")
 
     def _encode_image(self, image, true_shape=None):
         x, pos = self.patch_embed(image.to(self.patch_embed.proj.weight.dtype), true_shape)
@@ -528,7 +529,7 @@ class AsymmetricMASt3R(nn.Module):
         if not fp32_stream:
             for m in trunk:
                 m.to(dtype)
-            self._trunk_dtype = dtype
+            self._trunk_dtype, self._fp32_stream = dtype, False   # a narrowed trunk has no fp32 residual stream to keep
             return self
         for root in trunk:
             for m in root.modules():

@@ -167,9 +167,9 @@ def _empty_rounded(n: int, **kw) -> torch.Tensor:
 
 
 def _isect_capacity_guess(dev: torch.device, N: int, W: int, H: int) -> int:
-    """Capacity (entries) for the scatter that is launched before n_isects is known: 1.25 x the previous call with the same
-    shapes, or 0 on the first call (the scatter then runs after the wait)."""
-    prev = _CAPACITY_HINT.get((dev.index, N, W, H))
+    """Capacity (entries) for the scatter that is launched before n_isects is known: 1.25 x the previous call at the same
+    resolution, or 0 on the first call (the scatter then runs after the wait)."""
+    prev = _CAPACITY_HINT.get((dev.index, W, H))
     return 0 if prev is None else ((int(prev * 1.25) + _GRAIN - 1) // _GRAIN) * _GRAIN
 
 
@@ -286,7 +286,7 @@ class RasterizeGaussians(torch.autograd.Function):
                     _lib.check(rc, "adk_bin_local_scatter")
                 count_ready.synchronize()  # the one host wait of the pipeline
                 n_isects, max_tile = int(host_count[0]), int(host_count[1])
-                _CAPACITY_HINT[(dev.index, N, W, H)] = n_isects
+                _CAPACITY_HINT[(dev.index, W, H)] = n_isects   # keyed on the image only: one entry per resolution however the map grows
                 if max_tile > 8192:
                     use_local = False      # a tile list too long for the in-LDS sort: global route below
                 else:
@@ -378,6 +378,7 @@ class RasterizeGaussians(torch.autograd.Function):
                                                   opt["v_dc"].data_ptr(), opt["m_rest"].data_ptr(), opt["v_rest"].data_ptr(),
                                                   opt["lr_dc"].data_ptr(), opt["lr_rest"].data_ptr(), float(opt["betas"][0]),
                                                   float(opt["betas"][1]), float(opt["eps"]), stream)
+                _cam_grad_reset(cam_grad, rc)
                 _lib.check(rc, "adk_project_bwd_adam")
                 return v_means, v_quats, v_scales, v_opac, None, None, v_viewmat, None, None, None
             with _stage("project_bwd"):
@@ -387,6 +388,7 @@ class RasterizeGaussians(torch.autograd.Function):
                                      cfg.near_plane, cfg.far_plane, int(cfg.inv_depth), radii.data_ptr(), v_rec.data_ptr(),
                                      _lib.ptr(v_means), _lib.ptr(v_quats), _lib.ptr(v_scales), _lib.ptr(v_opac),
                                      _lib.ptr(v_cols), _lib.ptr(v_rest), _lib.ptr(cam_grad), _lib.ptr(v_viewmat), stream)
+            _cam_grad_reset(cam_grad, rc)
             _lib.check(rc, "adk_project_bwd")
         return v_means, v_quats, v_scales, v_opac, v_cols, v_rest, v_viewmat, None, None, None
 
@@ -396,12 +398,20 @@ _CAM_GRAD: dict = {}
 
 def _cam_grad_scratch(dev, stream) -> torch.Tensor:
     """The 16-float accumulator of the camera gradient: adk_project_bwd leaves it zeroed again, so one per (device,
-    stream) is cleared ONCE instead of a fill kernel per step."""
-    key = (dev.index, int(stream or 0))
+    stream, THREAD) is cleared ONCE instead of a fill kernel per step.  Per thread: the accumulate and finalize kernels are two
+    launches of one C call, and two threads issuing backward on one stream (the viewer thread renders under the same null
+    stream, h3dgsv3.py:624) could otherwise interleave them -- accumulate(A), accumulate(B), finalize(A) -- on a shared buffer.
+    A failed launch leaves the buffer dirty: _cam_grad_reset() clears it on any non-zero return code."""
+    key = (dev.index, int(stream or 0), threading.get_ident())
     buf = _CAM_GRAD.get(key)
     if buf is None:
         buf = _CAM_GRAD[key] = torch.zeros(16, dtype=torch.float32, device=dev)
     return buf
+
+
+def _cam_grad_reset(buf, rc: int) -> None:
+    if rc != 0 and buf is not None:
+        buf.zero_()
 
 
 def camera_config(colors, width, height, *, sh_degree, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0,

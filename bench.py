@@ -171,6 +171,7 @@ def main():
     glue = "torch (unchanged host code)"
     if not args.unfused_glue and fused.patch_scene_model(scene):
         glue = "artdeco_amd.fused (one HIP kernel per direction)"
+    fused.freeze_gc()   # the host program's own choice (DESIGN finding 5b); the library never does it on its own
 
     def sync_all():
         multigpu.barrier(dev)

@@ -38,6 +38,7 @@ def mapper_proc(args, barrier, stop, out_q):
     torch.cuda.set_device(0)
     scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=0, targets="render")
     fused.patch_scene_model(scene)
+    fused.freeze_gc()
     nkf = len(scene.keyframes)
     for i in range(10):
         scene.optimization_step(i % nkf)

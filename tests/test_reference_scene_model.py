@@ -176,3 +176,51 @@ def test_real_scene_model_steps_bit_identically_to_the_mirror(ref_module, monkey
     assert real.xyz.shape == mirror.xyz.shape and real.xyz.shape[0] < N
     assert torch.equal(real.xyz.detach(), mirror.xyz.detach())
     assert torch.equal(real.gaussian_params["f_rest"]["exp_avg_sq"], mirror.gaussian_params["f_rest"]["exp_avg_sq"])
+
+
+def test_autofuse_refuses_a_host_method_that_moved(ref_module, monkeypatch, tmp_path, capsys):
+    """A perturbed copy of the reference module (one constant of optimization_step changed): the post-import hook must leave
+    the whole "step" group as ARTDECO wrote it -- natives only -- warn once, and still install the untouched "densify" group."""
+    import importlib.util
+    from artdeco_amd import autoinstall, fused, pins
+    autoinstall.on_dropin_import()
+    ref_module()   # the package context (Reconstruct.scene.optimizers, keyframe, utils) of the copy
+    src = open(os.path.join(REF, "Reconstruct/scene/scene_models/h3dgsv3.py")).read()
+    needle = "error_map[0] > 0.2"
+    assert src.count(needle) == 1
+    path = tmp_path / "h3dgsv3_moved.py"
+    path.write_text(src.replace(needle, "error_map[0] > 0.25"))
+    name = "Reconstruct.scene.scene_models.h3dgsv3_moved"
+    spec = importlib.util.spec_from_file_location(name, str(path))
+    mod = importlib.util.module_from_spec(spec)
+    monkeypatch.setitem(sys.modules, name, mod)
+    spec.loader.exec_module(mod)
+    autoinstall._wrap_scene_model(mod)
+    pins._warned.clear()
+    capsys.readouterr()
+    scene = mod.SceneModel(64, 48, _K(64, 48, 51.2), _args(), device="cpu")
+    mod.SceneModel(64, 48, _K(64, 48, 51.2), _args(), device="cpu")
+    ours = [ln for ln in capsys.readouterr().err.splitlines() if "[artdeco_amd] WARNING" in ln]
+    assert len(ours) == 1 and "SceneModel.optimization_step" in ours[0]      # once, naming the method
+    assert scene._artdeco_amd_skipped == {"step": ["SceneModel.optimization_step"]}
+    for attr in ("render", "render_from_id", "optimization_step"):
+        assert getattr(scene, attr).__func__ is getattr(mod.SceneModel, attr), attr
+    assert scene.optimizer.step.__func__ is mod.SparseGaussianAdam.step
+    assert scene.update_voxel.__func__ is fused.fused_update_voxel
+    assert scene.optimizer.add_and_prune.__func__ is fused.fused_add_and_prune
+    # the unperturbed class verifies clean
+    good = ref_module().SceneModel(64, 48, _K(64, 48, 51.2), _args(), device="cpu")
+    assert good._artdeco_amd_skipped == {} and good.optimization_step.__func__ is fused.fused_optimization_step
+
+
+def test_gc_freeze_is_opt_in(monkeypatch):
+    import gc
+    from artdeco_amd import fused
+    from harness import mapper
+    monkeypatch.delenv("ARTDECO_AMD_GC_FREEZE", raising=False)
+    monkeypatch.setattr(fused, "_GC_FROZEN", False)
+    before = gc.get_freeze_count()
+    import test_mapper_host_logic as H
+    sc = H._scene(mapper, seed=1)
+    assert fused.patch_scene_model(sc)
+    assert gc.get_freeze_count() == before and fused._GC_FROZEN is False
