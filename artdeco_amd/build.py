@@ -36,6 +36,7 @@ EXTRA_FLAGS = {
     "matching.hip": ["-ffp-contract=off"],
     "knn.hip": ["-ffp-contract=off"],
     "tracker.hip": ["-ffp-contract=off"],
+    "densify.hip": ["-ffp-contract=off"],  # sample positions / resize weights follow torch's operation sequence (a fused u*k-1 moves a grid_sample position by 1e-7 of the map)
     "voxel.hip": ["-ffp-contract=off"],    # voxel indices are floor((p - min) / size): integer-deciding fp32 chain  # same arithmetic as the host-compiled test harness (tests/host/)
 }
 

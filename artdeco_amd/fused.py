@@ -815,6 +815,154 @@ def fused_update_voxel(self, new_xyz, xyz, cls_id, voxel_size=0.1):
         return unfused(new_xyz, xyz, cls_id, voxel_size)
 
 
+def _quantile_rank(n: int, q: float):
+    """(rank_below, weight) of torch.quantile's linear interpolation: rank = q * (n - 1) evaluated in float32 like ATen does."""
+    import numpy as np
+    rank = np.float32(q) * np.float32(n - 1)
+    lo = int(np.floor(rank))
+    return lo, float(np.float32(rank - np.float32(lo)))
+
+
+@torch.no_grad()
+def fused_add_new_gaussians(self, keyframe_id: int = -1):
+    """Drop-in body for SceneModel.add_new_gaussians (h3dgsv3.py:766-940): the same per-LoD-level sequence -- probability of the
+    keyframe image, render from the keyframe, probability of the render, sampling, depth / confidence lookup, validity, new
+    Gaussians' attributes, update_voxel, then ONE add_and_prune and weed_out_gaussians -- with the image-space operator chain of
+    each level (~60 torch / MIOpen launches and ~10 host syncs) as five HIP launches and one host read (the level's point count,
+    which sizes its tensors).  The uniform draw stays `torch.rand_like` (the reference's RNG stream).  `torch.quantile(...).item()`
+    (identical for the four levels) is evaluated once, on the device, and never read back.  Anything outside what the kernels
+    take (CPU tensors, a non-7x7 disc kernel, a non-RGB image) goes to ARTDECO's own body, which the patch kept."""
+    unfused = getattr(self, "_unfused_add_new_gaussians", None)
+    keyframe = self.keyframes[keyframe_id]
+    if keyframe.is_test:
+        return
+    img0 = keyframe.image_pyr[0]
+    ok = (img0.is_cuda and img0.dim() == 3 and img0.shape[0] == 3 and img0.dtype == torch.float32 and self.disc_kernel.numel() == 49
+          and keyframe.point_map.is_cuda and keyframe.mono_depth_conf.is_cuda and keyframe.rW2C.is_cuda)
+    if not ok:
+        if unfused is None:
+            raise _lib.AdkError("fused add_new_gaussians needs CUDA float32 RGB keyframes and the 7x7 disc kernel")
+        return unfused(keyframe_id)
+    lib = _lib.load()
+    dev = img0.device
+    args = getattr(self, "args", self)
+    ratio = float(getattr(args, "gs_add_ratio"))
+    voxel_size = float(getattr(args, "voxel_size"))
+    L_dim, G_dim = int(getattr(args, "local_feat_dim")), int(getattr(args, "global_feat_dim"))
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        f32 = dict(dtype=torch.float32, device=dev)
+        img0 = img0.contiguous()
+        H0, W0 = img0.shape[1], img0.shape[2]
+        disc = self.disc_kernel.reshape(-1).to(**f32).contiguous()
+        depth_map = keyframe.point_map[0, 2].to(**f32).contiguous()
+        conf_map = keyframe.mono_depth_conf[0, 0].to(**f32).contiguous()
+        Hs, Ws = depth_map.shape
+        qmin = torch.empty(1, **f32)
+        lo, wgt = _quantile_rank(Hs * Ws, 0.02)
+        _lib.check(lib.adk_densify_quantile(depth_map.data_ptr(), Hs * Ws, lo, wgt, 1e-2, qmin.data_ptr(), st), "adk_densify_quantile")
+        Rt = PoseRt.forward(rasterizer.HandCtx(), keyframe.rW2C, keyframe.tW2C)
+        centre = keyframe.approx_centre.detach().to(**f32).contiguous()
+        cx, cy = (self.width - 1) / 2, (self.height - 1) / 2   # self.centre by construction (h3dgsv3.py:75); no device read-back
+        kid = len(self.keyframes) - 1 if keyframe_id == -1 else keyframe_id
+        n_sh_rest = (self.max_sh_degree + 1) * (self.max_sh_degree + 1) - 1
+        had = self.xyz.shape[0] > 0
+        ext = {k: [] for k in ("id", "cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "local_feat", "global_feat")}
+        for lod in self.lods:
+            h, w = self.height // lod, self.width // lod
+            img_l = torch.empty(3, h, w, **f32)
+            ip = torch.empty(h, w, **f32)
+            with _stage("densify_proba"):
+                rc = lib.adk_densify_proba(img0.data_ptr(), 3, H0, W0, 1, h, w, disc.data_ptr(), float(self.init_proba_scaler), img_l.data_ptr(),
+                                           ip.data_ptr(), st)
+            _lib.check(rc, "adk_densify_proba")
+            pen = None
+            if self.xyz.shape[0] > 0:
+                render = self.render_from_id(keyframe_id)["render"].to(**f32).contiguous()
+                pen = torch.empty(h, w, **f32)
+                with _stage("densify_proba"):
+                    rc = lib.adk_densify_proba(render.data_ptr(), 3, render.shape[1], render.shape[2], 0, h, w, disc.data_ptr(),
+                                               float(self.init_proba_scaler), None, pen.data_ptr(), st)
+                _lib.check(rc, "adk_densify_proba")
+            rnd = torch.rand_like(ip)
+            mask = torch.empty(h * w, dtype=torch.uint8, device=dev)
+            sw, sh = keyframe.width // lod, keyframe.height // lod
+            with _stage("densify_select"):
+                rc = lib.adk_densify_select(h, w, ip.data_ptr(), _lib.ptr(pen), rnd.data_ptr(), ratio, depth_map.data_ptr(), conf_map.data_ptr(),
+                                            Hs, Ws, sw, sh, qmin.data_ptr(), mask.data_ptr(), st)
+                _lib.check(rc, "adk_densify_select")
+                ws = torch.empty(int(lib.adk_compact_workspace_bytes(h * w)), dtype=torch.uint8, device=dev)
+                n_keep = torch.empty(1, dtype=torch.int64, device=dev)
+                _lib.check(lib.adk_compact_plan(h * w, mask.data_ptr(), n_keep.data_ptr(), ws.data_ptr(), ws.numel(), st), "adk_compact_plan")
+            L = int(n_keep.item())          # the level's one host read: sizes its tensors (the reference drains the stream ~10 times here)
+            xyz = torch.empty(L, 3, **f32)
+            f_dc = torch.empty(L, 1, 3, **f32)
+            scaling = torch.empty(L, 3, **f32)
+            opacity = torch.empty(L, 1, **f32)
+            d_max = torch.empty(L, 1, **f32)
+            if L > 0:
+                with _stage("densify_emit"):
+                    rc = lib.adk_densify_emit(h, w, int(lod), mask.data_ptr(), ws.data_ptr(), img_l.data_ptr(), ip.data_ptr(), depth_map.data_ptr(),
+                                              conf_map.data_ptr(), Hs, Ws, sw, sh, float(self.f), float(cx), float(cy), int(self.width),
+                                              Rt.data_ptr(), centre.data_ptr(), xyz.data_ptr(), f_dc.data_ptr(), scaling.data_ptr(),
+                                              opacity.data_ptr(), d_max.data_ptr(), st)
+                _lib.check(rc, "adk_densify_emit")
+            if len(self.xyz) > 0:
+                upd, new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)
+                self.gaussian_params["cls_id"]["val"] = upd
+            else:
+                new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)
+            rot = torch.zeros(L, 4, **f32)
+            rot[:, 0] = 1
+            for k, v in (("id", torch.full((L, 1), kid, device=dev, dtype=torch.long)), ("cls_id", new_cls), ("d_max", d_max), ("xyz", xyz),
+                         ("f_dc", f_dc), ("f_rest", torch.zeros(L, n_sh_rest, 3, **f32)), ("opacity", opacity), ("scaling", scaling),
+                         ("rotation", rot), ("local_feat", torch.zeros(L, L_dim, **f32)), ("global_feat", torch.zeros(n_vox, G_dim, **f32))):
+                ext[k].append(v)
+        if had:
+            P = self.gaussian_params
+            N = self.xyz.shape[0]
+            valid = torch.empty(N, dtype=torch.bool, device=dev)
+            rc = lib.adk_prune_mask(N, P["opacity"]["val"].detach().contiguous().data_ptr(), P["scaling"]["val"].detach().contiguous().data_ptr(),
+                                    P["xyz"]["val"].detach().contiguous().data_ptr(), centre.data_ptr(), float(self.f), int(self.width),
+                                    valid.data_ptr(), st)
+            _lib.check(rc, "adk_prune_mask")
+        else:
+            valid = torch.ones(0, device=dev, dtype=torch.bool)
+        all_ext = {k: torch.concat(v, dim=0) for k, v in ext.items()}
+    lock = getattr(self, "lock", None)
+    if lock is not None:
+        lock.acquire()
+    try:
+        self.optimizer.add_and_prune(all_ext, valid)
+    finally:
+        if lock is not None:
+            lock.release()
+    self.weed_out_gaussians()
+
+
+@torch.no_grad()
+def fused_rigid_transform_gs(self, old_c2ws, new_c2ws, cam_centres):
+    """Drop-in body for SceneModel.rigid_transform_gs (h3dgsv3.py:956-966 -> utils.update_gaussians, utils.py:28-62): the pose
+    update new @ inverse(old) is formed once per KEYFRAME (the reference gathers both matrices per Gaussian and inverts N of
+    them), then one kernel moves every Gaussian and composes its rotation."""
+    xyz, rot, ids = self.xyz, self.rotation, self.id
+    if not (xyz.is_cuda and rot.is_cuda and old_c2ws.is_cuda and xyz.dtype == torch.float32):
+        return self._unfused_rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)
+    lib = _lib.load()
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        delta = torch.bmm(new_c2ws.float(), torch.inverse(old_c2ws.float())).contiguous()
+        N, K = xyz.shape[0], delta.shape[0]
+        new_xyz, new_rot = torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, 4, dtype=torch.float32, device=dev)
+        rc = lib.adk_rigid_transform(N, ids.reshape(-1).contiguous().data_ptr(), K, delta.data_ptr(), xyz.detach().contiguous().data_ptr(),
+                                     rot.detach().contiguous().data_ptr(), new_xyz.data_ptr(), new_rot.data_ptr(),
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "adk_rigid_transform")
+    self.gaussian_params["xyz"]["val"] = new_xyz
+    self.gaussian_params["rotation"]["val"] = new_rot
+    self.cam_centres = cam_centres
+
+
 def _patch_optimizer(opt, step_ok: bool = True, densify_ok: bool = True) -> None:
     if opt is None or not (hasattr(opt, "lr_dict") and hasattr(opt, "params")) or hasattr(opt, "_artdeco_amd_patched"):
         return
@@ -892,4 +1040,10 @@ def patch_scene_model(scene, verify: bool = False) -> bool:
         if hasattr(scene, "weed_out_gaussians") and hasattr(scene, "make_dummy_ext_tensor"):
             scene._unfused_weed_out_gaussians = scene.weed_out_gaussians
             scene.weed_out_gaussians = types.MethodType(fused_weed_out_gaussians, scene)
+        if hasattr(scene, "add_new_gaussians") and all(hasattr(scene, a) for a in ("lods", "disc_kernel", "init_proba_scaler", "update_voxel")):
+            scene._unfused_add_new_gaussians = scene.add_new_gaussians
+            scene.add_new_gaussians = types.MethodType(fused_add_new_gaussians, scene)
+        if hasattr(scene, "rigid_transform_gs") and "id" in getattr(scene, "gaussian_params", {}):
+            scene._unfused_rigid_transform_gs = scene.rigid_transform_gs
+            scene.rigid_transform_gs = types.MethodType(fused_rigid_transform_gs, scene)
     return True

@@ -1,7 +1,7 @@
 """Source pins: which version of ARTDECO's host methods the fused paths mirror.
 
 `artdeco_amd.fused` replaces bodies of ARTDECO's own classes (SceneModel.render / render_from_id / optimization_step /
-update_voxel / weed_out_gaussians / add_new_gaussians, SparseGaussianAdam.step / add_and_prune) and re-implements what
+update_voxel / weed_out_gaussians / add_new_gaussians / rigid_transform_gs, SparseGaussianAdam.step / add_and_prune) and re-implements what
 Keyframe.step / get_Rt do inside them.  A replacement is only valid for the source it was written against: if ARTDECO's
 `optimization_step` gains a loss term or a constant changes, a silently installed fused step would train something else at
 full speed.  So the SHA-256 of `inspect.getsource` of every mirrored method is recorded (`reference_pins.json`, written by
@@ -30,7 +30,8 @@ GROUPS = {
     "step": [("scene", "render"), ("scene", "render_from_id"), ("scene", "optimization_step"), ("optimizer", "step"),
              ("keyframe", "step"), ("keyframe", "get_Rt"), ("utils", "radial_decay_kernel")],
     "densify": [("scene", "update_voxel"), ("scene", "weed_out_gaussians"), ("scene", "add_new_gaussians"),
-                ("scene", "make_dummy_ext_tensor"), ("optimizer", "add_and_prune"), ("utils", "get_lapla_norm"),
+                ("scene", "make_dummy_ext_tensor"), ("scene", "rigid_transform_gs"), ("optimizer", "add_and_prune"),
+                ("utils", "update_gaussians"), ("utils", "get_lapla_norm"),
                 ("utils", "sample"), ("utils", "depth2points"), ("utils", "RGB2SH"), ("utils", "inverse_sigmoid")],
 }
 

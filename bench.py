@@ -7,11 +7,16 @@
     `--backend gloo --cpu-dry-run` drives the same launch / barrier / all-reduce / report path on CPU for the tests.)
 
 Workload (BASELINE.json metric "on-the-fly frames/sec + raster fwd+bwd ms @1M Gaussians 1080p"):
-config[2] -- 1 M Gaussians, 1920x1080, SH degree 3, RGB+D, L1 + fused-SSIM + inverse-depth loss,
-sparse Adam -- as a seeded synthetic cloud.  One "step" = one mapper optimisation
-step (render -> loss -> backward -> keyframe Adam -> sparse Gaussian Adam), exactly the body of
-SceneModel.optimization_step (h3dgsv3.py:401-469) driven through the reference's binding surface.
-frames/s = steps/s / steps_per_frame with steps_per_frame = 10 (run.sh --num_common_iterations 10).
+configs[2] -- a 1 M-Gaussian map rendered at 1920x1080, SH degree 3, RGB+D, L1 + fused-SSIM + inverse-depth loss, sparse Adam,
+densification with LoG multi-resolution initialisation -- as a seeded synthetic cloud and a synthetic frame stream.
+
+One "step" = ONE MAPPED FRAME = one pass of the mapper loop body of run_system.py:143-234 (harness/stream.py): Keyframe
+construction (pyramids), [SLAM keyframes: pose re-read + rigid_transform_gs], add_keyframe, [important frames: add_new_gaussians
+= 4 LoD levels of probability maps + render + sampling + update_voxel, add_and_prune, weed_out_gaussians], then 20 (important) or
+10 optimisation steps (run.sh --num_key_iterations 20 --num_common_iterations 10), each = SceneModel.optimization_step
+(h3dgsv3.py:401-469: render -> loss -> backward -> keyframe Adam -> sparse Gaussian Adam).  `value` = frames / wall-seconds of
+that loop: the reference's own FPS definition (h3dgsv3.py:1129-1132).  Frame cadence (no dataset here; stated in the output):
+mapper keyframe every 5th frame, SLAM keyframe every 15th, test frame every 8th (run.sh --test_hold 8), --use_all_frames.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,17 +31,23 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-STEPS_PER_FRAME = 10   # run.sh: --num_common_iterations 10 (key frames use 20)
+STEPS_PER_FRAME = 10   # run.sh: --num_common_iterations 10 (key frames use 20); only for the secondary steps-only figures
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40, help="timed FRAMES (one step = one mapped frame)")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed frames before them")
+    ap.add_argument("--texture", type=float, default=0.05, help="amplitude of what the synthetic frames show and the map does not explain yet "
+                                                                 "(drives the number of Gaussians add_new_gaussians creates)")
+    ap.add_argument("--kf-every", type=int, default=5)
+    ap.add_argument("--slam-every", type=int, default=15)
+    ap.add_argument("--test-hold", type=int, default=8)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -114,7 +125,7 @@ def measure_hbm_copy_gbs(lib, dev):
     return 2.0 * n / (best * 1e-3) / 1e9
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, steps_per_frame=STEPS_PER_FRAME):
     """The oracle ("port") timed on this box's host cores on a bounded sample of the same workload:
     a 1/36-area window (320x180, N/36 Gaussians => same splat density per pixel), one render +
     fp32 autograd backward + SSIM + Adam in torch-CPU (about 20 s on the GPU box's host).  Scaled by 36 to the full frame."""
@@ -139,10 +150,11 @@ def cpu_baseline(args):
             v -= 1e-3 * m / (s.sqrt() + 1e-15)
     dt = time.time() - t0
     step_s_full = dt * float(DIV * DIV)
-    return {"value": 1.0 / (step_s_full * STEPS_PER_FRAME), "unit": "frames/s", "cores": torch.get_num_threads(),
+    return {"value": 1.0 / (step_s_full * steps_per_frame), "unit": "frames/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"oracle (torch-CPU) render+loss+backward+update of a 1/{DIV * DIV}-area window ({W}x{H}, {N} Gaussians, "
-                      f"same density) = {dt:.1f} s, x{DIV * DIV} to the full frame, /{STEPS_PER_FRAME} steps per frame"}
+                      f"same density) = {dt:.1f} s, x{DIV * DIV} to the full frame, x{steps_per_frame:.1f} optimisation steps per frame of "
+                      f"the timed stream (the per-frame stages other than the steps are not in the CPU figure)"}
 
 
 def main():
@@ -165,70 +177,95 @@ def main():
     multigpu.init(args.backend, dev)  # nccl = RCCL over xGMI; used for the barrier + the metric all-reduce only
     lib = _lib.load()
     torch.manual_seed(rank)
-    scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=rank, targets="render")
-    nkf = len(scene.keyframes)
+    np.random.seed(rank)
     from artdeco_amd import fused
+    from harness import stream
+    scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=rank, n_keyframes=0, targets="random")
     glue = "torch (unchanged host code)"
     if not args.unfused_glue and fused.patch_scene_model(scene):
-        glue = "artdeco_amd.fused (one HIP kernel per direction)"
+        glue = "artdeco_amd.fused (HIP kernels behind render / optimization_step / add_new_gaussians / add_and_prune / update_voxel)"
     fused.freeze_gc()   # the host program's own choice (DESIGN finding 5b); the library never does it on its own
+    cadence = dict(kf_every=args.kf_every, slam_every=args.slam_every, test_hold=args.test_hold)
+    n_detail = 10 if world == 1 else 0
+    frames = stream.synthetic_frames(scene, args.warmup + args.steps + n_detail, seed=rank, texture=args.texture)  # resident in HBM
 
     def sync_all():
         multigpu.barrier(dev)
 
-    for i in range(args.warmup):
-        scene.optimization_step(i % nkf)
+    stream.warm_libraries(dev)
+    stream.run_stream(scene, frames[:args.warmup], start_index=0, **cadence)
     # timed region: HIP events around the roofline kernel only (raster_bwd); every event pair costs a few
     # microseconds of stream bubble, so the full per-stage breakdown is taken in a second, untimed pass
     timer = rasterizer.StageTimer(only=("raster_bwd",))
     rasterizer.set_stage_timer(timer)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        scene.optimization_step(i % nkf)
+    timed = stream.run_stream(scene, frames[args.warmup:args.warmup + args.steps], start_index=args.warmup, **cadence)
     sync_all()
     elapsed = time.perf_counter() - t0
     stages_timed = timer.summary_ms()
-    detail = rasterizer.StageTimer()
-    rasterizer.set_stage_timer(detail)
-    for i in range(min(args.steps, 10)):
-        scene.optimization_step(i % nkf)
     rasterizer.set_stage_timer(None)
-    stages = detail.summary_ms()
+    frame_stages, stages = {}, {}
+    if n_detail:
+        # untimed: the loop's stages bracketed by device synchronisations, then the kernels of the optimisation step by HIP events
+        frame_stages = stream.run_stream(scene, frames[args.warmup + args.steps:], start_index=args.warmup + args.steps, breakdown=True,
+                                         **cadence)["stage_ms"]
+        detail = rasterizer.StageTimer()
+        rasterizer.set_stage_timer(detail)
+        for i in range(10):
+            stream.optimization_step(scene, True)
+        rasterizer.set_stage_timer(None)
+        stages = detail.summary_ms()
     stages["raster_bwd"] = stages_timed["raster_bwd"]
 
-    # workload size seen by the kernels (last step): I intersections, V visible, P pixels
+    # workload size seen by the kernels (a render of the newest keyframe): N Gaussians, I intersections, V visible, P pixels
     with torch.no_grad():
-        pkg = scene.render_from_id(0)
+        pkg = scene.render_from_id(-1)
+    N_end = int(scene.xyz.shape[0])
     I, P = rasterizer.LAST_STATS["I"], args.width * args.height
     V = int(pkg["visibility_filter"].sum())
 
-    elapsed_max, sums = multigpu.aggregate(elapsed, {"steps": float(args.steps)}, dev)  # MAX time, SUM steps
-    total_steps = sums["steps"]
+    elapsed_max, sums = multigpu.aggregate(elapsed, {"frames": float(args.steps), "steps": float(timed["steps"])}, dev)  # MAX time, SUMs
+    total_frames = sums["frames"]
 
     if rank == 0:
-        frames_per_s = total_steps / STEPS_PER_FRAME / elapsed_max
+        frames_per_s = total_frames / elapsed_max
         bwd_ms = stages["raster_bwd"]["mean_ms"]
         alg_bytes_bwd = 44.0 * I + 28.0 * P + 40.0 * V  # raster bwd
         achieved = alg_bytes_bwd / (bwd_ms * 1e-3) / 1e9
         hbm_measured = measure_hbm_copy_gbs(lib, dev)
         prof = _profile_counters(args)
+        flags = [stream.frame_flags(i, **cadence) for i in range(args.warmup, args.warmup + args.steps)]
         out = {
-            "metric": "on-the-fly frames/sec (mapper hot path; raster fwd+bwd + L1 + fused-SSIM + sparse Adam) @1M Gaussians 1080p",
+            "metric": "on-the-fly frames/sec of the mapper loop (reference definition: frames / wall-seconds, run_system.py:139-276, h3dgsv3.py:1129-1132) @1M Gaussians 1080p",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 1M-Gaussian map, 1920x1080 render, RGB+D SH3, L1+fused-SSIM+invdepth loss, sparse Adam; keyframes observe the cloud itself (stationary workload); one independent scene per GPU",
-                       "gaussians": args.gaussians, "width": args.width, "height": args.height,
-                       "steps_per_frame": STEPS_PER_FRAME, "intersections_I": I, "visible_V": V, "pixels_P": P,
+            "config": {"workload": "BASELINE configs[2]: 1M-Gaussian map, 1920x1080 render, RGB+D SH3, L1+fused-SSIM+invdepth loss, sparse Adam, "
+                                   "simple densify + LoG multi-res init; one step = one mapped FRAME of run_system.py's loop (Keyframe build, "
+                                   "rigid_transform_gs on SLAM keyframes, add_keyframe, add_new_gaussians on important frames, 20 / 10 "
+                                   "optimisation steps); frames observe the map itself plus unexplained texture; one independent scene per GPU",
+                       "gaussians_start": int(timed["gaussians_start"]), "gaussians_end": int(timed["gaussians_end"]),
+                       "width": args.width, "height": args.height, "pyr_levels": 1,
+                       "cadence": {**cadence, "use_all_frames": True, "num_key_iterations": 20, "num_common_iterations": 10},
+                       "important_frame_fraction": sum(f["is_important"] for f in flags) / len(flags),
+                       "densified_frames": sum(f["is_important"] and not f["is_test"] for f in flags),
+                       "slam_keyframes": sum(f["is_slam_keyframe"] for f in flags),
+                       "optimisation_steps": int(timed["steps"]), "steps_per_frame": timed["steps"] / args.steps,
+                       "new_gaussians_per_densified_frame": timed["gaussians_added"] / max(timed["densified_frames"], 1),
+                       "gaussians_pruned_in_timed_region": int(timed["gaussians_start"] + timed["gaussians_added"] - timed["gaussians_end"]),
+                       "intersections_I": I, "visible_V": V, "pixels_P": P, "gaussians_N": N_end,
                        "render_glue": glue, "parallelism": f"scene-per-gpu x{world}"},
-            "raster_fwd_ms": stages["raster_fwd"]["mean_ms"], "raster_bwd_ms": bwd_ms,
+            "ms_per_optimisation_step_incl_frame_overheads": elapsed_max / max(timed["steps"], 1) * 1e3,
+            "raster_fwd_ms": stages.get("raster_fwd", {}).get("mean_ms"), "raster_bwd_ms": bwd_ms,
+            "frame_stage_ms": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in frame_stages.items()},
             "stage_ms": {k: round(v["mean_ms"], 4) for k, v in stages.items()},
             "roofline": {"bound": "hbm", "kernel": "raster_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("raster_bwd_hbm_bytes"),
                          "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms,
                          "peak_measured_stream_copy": hbm_measured, "frac_of_measured_peak": achieved / hbm_measured,
                          "traffic_source": prof.get("source")},
+            "roofline_stages": roofline_stages(stages, N_end, V, I, P, args.width, args.height),
         }
         if prof.get("raster_bwd_valu_wave_insts"):
             # What actually bounds the kernel the metric prices against HBM is vector-ALU time.  Two
@@ -246,19 +283,53 @@ def main():
                 busy = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / (1024 * bwd_ms * 1e-3 * 2.4e9)
                 out["roofline_valu"]["valu_busy"] = busy
                 out["roofline_valu"]["cycles_per_valu_inst"] = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / valu
+        del scene, frames
+        torch.cuda.empty_cache()
         if not args.no_extra_configs and world == 1:
             out["other_configs"] = extra_configs(args, dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, timed["steps"] / args.steps)
         if not args.no_frontend and world == 1:
-            del scene
-            torch.cuda.empty_cache()
             out["frontend"] = frontend_summary(args, dev, cpu=not args.no_cpu_baseline)
             out["system"] = system_summary()
         if args.stage_detail:
             print(json.dumps(stages, indent=1), file=sys.stderr)
         print(json.dumps(out))
     multigpu.shutdown()
+
+
+def roofline_stages(stages, N, V, I, P, W, H):
+    """Per-stage HBM roofline of one optimisation step from SURVEY.md 8(d)'s algorithmic bytes (N Gaussians, V visible, I tile
+    intersections, P pixels, T 16x16 tiles) and the HIP-event time of the stage: {stage: {alg_bytes, ms, GBps, frac}} + the whole
+    step.  Stages SURVEY gives no formula for carry the bytes DESIGN.md section 2 states for them."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    alg = {
+        "project_fwd": 76.0 * N + 216.0 * V,                        # projection fwd + SH fwd (one kernel)
+        "binning": 36.0 * I + 4.0 * T,                              # emit + sort minimum + offsets
+        "raster_fwd": 44.0 * I + 24.0 * P,
+        "raster_bwd": 44.0 * I + 28.0 * P + 40.0 * V,
+        "project_bwd": 148.0 * N + 420.0 * V + 24.0 * 48 * V,       # projection bwd + SH bwd + the colours' Adam fused in (28 B/element
+                                                                    # in SURVEY's formula, minus the 4 B gradient that is never stored)
+        "ssim_fwd": 24.0 * P * 3, "ssim_bwd": 28.0 * P * 3,
+        "adam_multi": 28.0 * 27 * V + N,                            # the remaining 27 floats per visible Gaussian + the mask
+        "lod_params_fwd": 190.0 * N, "photometric_fwd": 64.0 * P, "photometric_bwd": 72.0 * P,
+    }
+    ms = {k: v["mean_ms"] for k, v in stages.items()}
+    if all(k in ms for k in ("bin_count", "bin_scatter", "bin_sort")):
+        ms["binning"] = ms["bin_count"] + ms["bin_scatter"] + ms["bin_sort"]
+    out = {}
+    for k, b in alg.items():
+        if k in ms and ms[k] > 0:
+            gbs = b / (ms[k] * 1e-3) / 1e9
+            out[k] = {"alg_bytes": b, "ms": round(ms[k], 4), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    counted = [k for k in out]
+    tot_b = sum(alg[k] for k in counted)
+    tot_ms = sum(v["mean_ms"] for k, v in stages.items() if k not in ("binning",))
+    if tot_ms > 0:
+        out["whole_step"] = {"alg_bytes": tot_b, "ms_sum_of_stages": round(tot_ms, 4), "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+                             "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "algorithmic bytes of the stages listed here / the sum of ALL stage times of one optimisation step"}
+    return out
 
 
 def frontend_summary(args, dev, cpu=True):
@@ -323,8 +394,8 @@ def system_summary():
 
 
 def _time_steps(scene, steps=10, warmup=3, repeats=2):
-    """Seconds per step: best of `repeats` runs of `steps` steps (a one-off allocator stall in a 10-step run otherwise
-    shows up as a 10x slower configuration)."""
+    """Seconds per optimisation step on a stationary scene: best of `repeats` runs of `steps` steps (a one-off allocator stall in
+    a 10-step run otherwise shows up as a 10x slower configuration)."""
     nkf = len(scene.keyframes)
     for i in range(warmup):
         scene.optimization_step(i % nkf)
@@ -339,38 +410,67 @@ def _time_steps(scene, steps=10, warmup=3, repeats=2):
     return best
 
 
+def _stream_fps(n, w, h, dev, use_fused, lod, args, pyr_levels=1, warm=6, timed=16, slam_hw=(384, 512)):
+    """frames/s of the mapper loop (the reference's FPS definition) on a fresh scene of this configuration: `timed` frames after
+    `warm`, the headline's cadence.  (w, h) = the MAP resolution; training renders at (w, h) / 2^(pyr_levels - 1)."""
+    from artdeco_amd import fused
+    from harness import mapper, stream
+    scene = mapper.build_synthetic_mapper(n, w, h, dev, seed=0, n_keyframes=0, targets="random", lod=lod)
+    if use_fused:
+        fused.patch_scene_model(scene)
+    cadence = dict(kf_every=args.kf_every, slam_every=args.slam_every, test_hold=args.test_hold)
+    frames = stream.synthetic_frames(scene, warm + timed, seed=0, texture=args.texture, slam_hw=slam_hw)
+    np.random.seed(0)
+    stream.warm_libraries(dev)
+    stream.run_stream(scene, frames[:warm], start_index=0, pyr_levels=pyr_levels, **cadence)
+    r = stream.run_stream(scene, frames[warm:], start_index=warm, pyr_levels=pyr_levels, **cadence)
+    res = {"frames_per_s": r["frames"] / r["seconds"], "ms_per_frame": r["seconds"] / r["frames"] * 1e3, "frames": r["frames"],
+           "optimisation_steps": r["steps"], "important_frames": r["important_frames"], "densified_frames": r["densified_frames"],
+           "gaussians_start": r["gaussians_start"], "gaussians_end": r["gaussians_end"], "gaussians_added": r["gaussians_added"]}
+    del scene, frames
+    torch.cuda.empty_cache()
+    return res
+
+
 def extra_configs(args, dev):
-    """Secondary single-GPU measurements, OUTSIDE the timed region of `value` (10 steps each): the other
-    BASELINE.json configs that fit one GPU, and the headline config with ARTDECO's render() glue left as stock
-    torch ops (what an unchanged run_system.py gets without the one-line artdeco_amd.fused patch)."""
+    """Secondary single-GPU measurements, OUTSIDE the timed region of `value`: the other BASELINE.json configs that fit one GPU,
+    each as (a) the mapper FRAME loop (`frames_per_s`, the reference's FPS definition, same cadence as the headline) and (b) the
+    bare optimisation step on a stationary scene (`ms_per_step`; `steps_only_frames_per_s` = steps/s / 10 is the UPPER BOUND
+    earlier rounds reported as frames/s: no Keyframe build, no important frame); and the headline config with ARTDECO's own torch
+    host code around the natives (what an unchanged run_system.py gets with ARTDECO_AMD_AUTOFUSE=0)."""
     from artdeco_amd import fused
     from harness import mapper
     res = {}
-    cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True, False),
-             ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True, False),
-             ("run.sh training resolution (map 1296x972, pyr_lvl 1): 1M Gaussians 648x486", 1_000_000, 648, 486, True, False),
+    # name, N, map W, map H, fused, lod, pyr_levels, stream?
+    cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True, False, 1, True),
+             ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True, False, 1, True),
+             ("run.sh geometry: 1M Gaussians, map 1296x972, --pyr_levels 2 (training renders 648x486, densification renders 1296x972)",
+              1_000_000, 1296, 972, True, False, 2, True),
              ("configs[3] 4M Gaussians 2592x1944, d_max = creation depth x LoD level (LoD culling and fading active)",
-              4_000_000, 2592, 1944, True, True),
-             ("configs[3] 4M Gaussians 2592x1944, no LoD culling (d_max = inf)", 4_000_000, 2592, 1944, True, False),
+              4_000_000, 2592, 1944, True, True, 1, True),
+             ("configs[3] 4M Gaussians 2592x1944, no LoD culling (d_max = inf)", 4_000_000, 2592, 1944, True, False, 1, False),
              (f"headline config, UNCHANGED host code: ARTDECO's torch glue, natives swapped only ({args.gaussians} Gaussians {args.width}x{args.height})",
-              args.gaussians, args.width, args.height, False, False),
-             ("north-star target 1M Gaussians 512x384, UNCHANGED host code", 1_000_000, 512, 384, False, False)]
-    for name, n, w, h, use_fused, lod in cases:
+              args.gaussians, args.width, args.height, False, False, 1, True),
+             ("north-star target 1M Gaussians 512x384, UNCHANGED host code", 1_000_000, 512, 384, False, False, 1, True)]
+    for name, n, w, h, use_fused, lod, pyr, do_stream in cases:
         try:
-            scene = mapper.build_synthetic_mapper(n, w, h, dev, seed=0, targets="render", lod=lod)
+            tw, th = w >> (pyr - 1), h >> (pyr - 1)
+            scene = mapper.build_synthetic_mapper(n, tw, th, dev, seed=0, targets="render", lod=lod)
             if use_fused:
                 fused.patch_scene_model(scene)
             dt = _time_steps(scene)
-            res[name] = {"ms_per_step": dt * 1e3, "frames_per_s": 1.0 / (dt * STEPS_PER_FRAME)}
+            res[name] = {"ms_per_step": dt * 1e3, "steps_only_frames_per_s": 1.0 / (dt * STEPS_PER_FRAME)}
             if lod:
                 with torch.no_grad():
                     pkg = scene.render_from_id(0)
-                res[name]["lod_selected_frac"] = float(scene.last_selected_frac) if hasattr(scene, "last_selected_frac") else None
                 res[name]["visible_frac"] = float(pkg["visibility_filter"].float().mean())
             del scene
             torch.cuda.empty_cache()
+            if do_stream:
+                big = n >= 4_000_000 or not use_fused
+                res[name].update(_stream_fps(n, w, h, dev, use_fused, lod, args, pyr_levels=pyr, warm=3 if big else 6, timed=8 if big else 16))
         except Exception as e:  # report, never hide
-            res[name] = {"error": repr(e)}
+            res.setdefault(name, {})["error"] = repr(e)[:300]
     return res
 
 

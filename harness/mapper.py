@@ -9,6 +9,9 @@ JUST the hot-path operator interface with the same names, argument meaning and c
   MapperScene.optimization_step(is_important)             <- SceneModel.optimization_step h3dgsv3.py:401-469
   SparseGaussianAdam.step(vis, N, gvis, Ng) / BaseAdam    <- scene/optimizers.py:17-161
   Keyframe (6D pose + t + 3x4 exposure, own BaseAdam)     <- scene/keyframe.py:103-125, 150-155, 186-191
+  StreamKeyframe (pyramids from image + point map + conf)  <- scene/keyframe.py:26-126 (what run_system.py:177-192 constructs)
+  MapperScene.add_keyframe / add_new_gaussians /
+      update_voxel / rigid_transform_gs                    <- h3dgsv3.py:981-1009, 766-940, 227-316, 956-966
 
 Every native call goes through the drop-in modules exactly as the reference's imports do
 (`gsplat.rendering.rasterization`, `fused_ssim`, `diff_gaussian_rasterization.adamUpdate*`), so what
@@ -31,6 +34,7 @@ artdeco_amd.install_dropins()
 import gsplat  # noqa: E402  (drop-in)
 from diff_gaussian_rasterization import adamUpdate, adamUpdateBasic  # noqa: E402
 from fused_ssim import fused_ssim  # noqa: E402
+from torch_scatter import scatter_max  # noqa: E402  (drop-in; h3dgsv3.py:35)
 
 
 # ------------------------------------------------------------------------------- optimisers
@@ -59,6 +63,8 @@ class BaseAdam:
 
 
 _NO_OPT = ("id", "cls_id", "d_max")
+import contextlib as _contextlib  # noqa: E402
+_NULL_CTX = _contextlib.nullcontext()
 
 
 def _add_and_prune(self, extension_tensors, valid_mask):
@@ -185,6 +191,148 @@ class Keyframe:
         self.depth_loss_weight *= self.depth_loss_weight_decay
 
 
+class StreamKeyframe(Keyframe):
+    """scene/keyframe.py:26-126: the keyframe run_system.py:177-192 builds for every mapped frame -- inverse-depth and
+    confidence maps resized to the image, `pyr_levels` average-pooled pyramids of image / inverse depth / confidence, the
+    6D pose + exposure parameters (exposure inherited from the previous keyframe) and their Adam."""
+
+    def __init__(self, image, Rt, point_map, point_conf, f, device, *, index=0, prev_kf=None, is_test=False, pyr_levels=2,
+                 lr_poses=1e-4, lr_exposure=1e-3, depth_loss_weight_init=1e-2, depth_loss_weight_decay=0.9):
+        self.device = torch.device(device)
+        self.image_pyr = [image]
+        self.is_test = is_test
+        self.width, self.height = image.shape[2], image.shape[1]
+        self.index = index
+        self.latest_invdepth = None
+        self.point_map = point_map.permute(2, 0, 1)[None]               # 1 3 H_slam W_slam
+        depth_foundation = self.point_map[:, 2:, ...]
+        idepth = torch.where(depth_foundation != 0, 1.0 / (depth_foundation + 1e-4), 1e4)
+        self.mono_depth_conf = point_conf[None, None, ...].to(torch.float32)
+        self.idepth_pyr = [F.interpolate(idepth, (self.height, self.width), mode="bilinear", align_corners=True)[0]]
+        self.idepth_conf_pyr = [F.interpolate(self.mono_depth_conf, (self.height, self.width), mode="bilinear", align_corners=True)[0]]
+        for _ in range(pyr_levels - 1):
+            self.idepth_pyr.append(F.avg_pool2d(self.idepth_pyr[-1], 2))
+            self.idepth_conf_pyr.append(F.avg_pool2d(self.idepth_conf_pyr[-1], 2))
+        self.centre = torch.tensor([(self.width - 1) / 2, (self.height - 1) / 2]).to(self.device)
+        self.f = f
+        self.depth_loss_weight = depth_loss_weight_init
+        self.depth_loss_weight_decay = depth_loss_weight_decay
+        for _ in range(pyr_levels - 1):
+            self.image_pyr.append(F.avg_pool2d(self.image_pyr[-1], 2))
+        self.pyr_lvl = pyr_levels - 1
+        self.rW2C = nn.Parameter(Rt[:3, :2].clone().contiguous())
+        self.tW2C = nn.Parameter(Rt[:3, 3].clone().contiguous())
+        exposure = torch.eye(3, 4, device=self.device) if prev_kf is None else prev_kf.exposure.clone().detach()
+        self.exposure = nn.Parameter(exposure)
+        lr_poses = 0 if index == 0 else lr_poses
+        if is_test:
+            lr_poses = 1e-4
+        params = {"rW2C": {"val": self.rW2C, "lr": lr_poses}, "tW2C": {"val": self.tW2C, "lr": lr_poses}}
+        if not is_test:
+            params["exposure"] = {"val": self.exposure, "lr": lr_exposure}
+        self.optimizer = BaseAdam(params, betas=(0.8, 0.99))
+        self.num_steps = 0
+        self.approx_centre = -Rt[:3, :3].T @ Rt[:3, 3]
+
+    def get_R(self):
+        return sixD2mtx(self.rW2C)
+
+    def get_t(self):
+        return self.tW2C
+
+    def set_Rt(self, Rt):
+        self.rW2C.data.copy_(Rt[:3, :2])
+        self.tW2C.data.copy_(Rt[:3, 3])
+        self.approx_centre = -Rt[:3, :3].T @ Rt[:3, 3]
+
+
+# Reconstruct/utils.py:93-108, 121-131, 188-216 -- the image-space helpers of add_new_gaussians
+C0 = 0.28209479177387814
+
+
+def get_lapla_norm(img, kernel, device="cuda:0"):
+    laplacian_kernel = torch.tensor([[0, 1, 0], [1, -4, 1], [0, 1, 0]], device=device, dtype=torch.float32).unsqueeze(0).unsqueeze(0)
+    laplacian_kernel = laplacian_kernel.repeat(1, img.shape[0], 1, 1)
+    laplacian = F.conv2d(img[None], laplacian_kernel, padding="same")
+    laplacian_norm = torch.linalg.vector_norm(laplacian, ord=1, dim=1, keepdim=True)
+    laplacian_norm[..., :, 0] = 0
+    laplacian_norm[..., :, -1] = 0
+    laplacian_norm[..., 0, :] = 0
+    laplacian_norm[..., -1, :] = 0
+    return F.conv2d(laplacian_norm, kernel, padding="same")[0, 0].clamp(0, 1)
+
+
+def RGB2SH(rgb):
+    return (rgb - 0.5) / C0
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def depth2points(uv, depth, f, centre):
+    xyz = torch.cat([(uv[..., :2] - centre) / f, torch.ones_like(uv[..., 0:1])], dim=-1)
+    return depth * xyz
+
+
+def sample(map, uv, width, height):
+    sampler = uv.clone()
+    sampler[..., 0] = sampler[..., 0] * (2.0 / (width - 1)) - 1.0
+    sampler[..., 1] = sampler[..., 1] * (2.0 / (height - 1)) - 1.0
+    return F.grid_sample(map, sampler, mode="bilinear", align_corners=True)
+
+
+def quaternion_to_rotation_matrix(q):
+    """kornia.geometry.conversions.quaternion_to_rotation_matrix for (w, x, y, z) [UPSTREAM kornia, a pip dependency that is
+    not in /root/reference; restated from its published definition: normalise, then the standard matrix]."""
+    q = F.normalize(q, p=2.0, dim=-1, eps=1e-12)
+    w, x, y, z = q.unbind(-1)
+    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    one = torch.ones_like(w)
+    return torch.stack([one - (tyy + tzz), txy - twz, txz + twy, txy + twz, one - (txx + tzz), tyz - twx,
+                        txz - twy, tyz + twx, one - (txx + tyy)], dim=-1).view(*q.shape[:-1], 3, 3)
+
+
+def rotation_matrix_to_quaternion(R, eps=1e-8):
+    """kornia.geometry.conversions.rotation_matrix_to_quaternion -> (w, x, y, z) [UPSTREAM kornia, restated from its published
+    definition: the four-branch form selected by the trace and the largest diagonal entry]."""
+    m = R.reshape(*R.shape[:-2], 9)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.unbind(-1)
+    trace = m00 + m11 + m22
+
+    def pos():
+        sq = torch.sqrt(trace + 1.0 + eps) * 2.0
+        return torch.stack([0.25 * sq, (m21 - m12) / sq, (m02 - m20) / sq, (m10 - m01) / sq], -1)
+
+    def c1():
+        sq = torch.sqrt(1.0 + m00 - m11 - m22 + eps) * 2.0
+        return torch.stack([(m21 - m12) / sq, 0.25 * sq, (m01 + m10) / sq, (m02 + m20) / sq], -1)
+
+    def c2():
+        sq = torch.sqrt(1.0 + m11 - m00 - m22 + eps) * 2.0
+        return torch.stack([(m02 - m20) / sq, (m01 + m10) / sq, 0.25 * sq, (m12 + m21) / sq], -1)
+
+    def c3():
+        sq = torch.sqrt(1.0 + m22 - m00 - m11 + eps) * 2.0
+        return torch.stack([(m10 - m01) / sq, (m02 + m20) / sq, (m12 + m21) / sq, 0.25 * sq], -1)
+
+    w2 = torch.where((m11 > m22)[..., None], c2(), c3())
+    w1 = torch.where(((m00 > m11) & (m00 > m22))[..., None], c1(), w2)
+    return torch.where((trace > 0)[..., None], pos(), w1)
+
+
+def update_gaussians(old_c2ws, new_c2ws, positions, quaternions):
+    """Reconstruct/utils.py:28-62: move every Gaussian by the pose update of the keyframe that created it."""
+    delta_T = torch.bmm(new_c2ws, torch.inverse(old_c2ws))
+    R, t = delta_T[:, :3, :3], delta_T[:, :3, 3]
+    rot_orig = quaternion_to_rotation_matrix(quaternions)
+    new_positions = torch.einsum("bij,bj->bi", R, positions) + t
+    return new_positions, rotation_matrix_to_quaternion(torch.bmm(R, rot_orig))
+
+
 # ------------------------------------------------------------------------------- scene
 class MapperScene:
     """Parameter dictionary + render + optimisation step of the LoD Gaussian scene model."""
@@ -192,7 +340,8 @@ class MapperScene:
     def __init__(self, width, height, fx, device, *, sh_degree=3, local_feat_dim=16, global_feat_dim=16,
                  lambda_dssim=0.2, eps2d=0.01, rad_decay=math.sqrt(5.0), scaling_reg_factor=0.0,
                  position_lr_init=5e-5, position_lr_decay=1 - 2e-5, feature_lr=5e-3, opacity_lr=0.1,
-                 scaling_lr=0.01, rotation_lr=2e-3, feat_lr=4e-3, mlp_cov_lr_init=4e-3, mlp_cov_lr_decay=1 - 2e-5):
+                 scaling_lr=0.01, rotation_lr=2e-3, feat_lr=4e-3, mlp_cov_lr_init=4e-3, mlp_cov_lr_decay=1 - 2e-5,
+                 init_proba_scaler=2.0, gs_add_ratio=1.0, voxel_size=0.1):
         self.device = torch.device(device)
         self.width, self.height = width, height
         self.tanfovx = width / (2 * fx)
@@ -214,6 +363,25 @@ class MapperScene:
         self.keyframes: list[Keyframe] = []
         self._rdk = {}
         self.local_feat_dim, self.global_feat_dim = local_feat_dim, global_feat_dim
+        # -- what add_new_gaussians / add_keyframe read (h3dgsv3.py:72-110, 195-225; run.sh / dataloaders/args.py values)
+        self.f = float(fx)
+        self.centre = torch.tensor([(width - 1) / 2, (height - 1) / 2], device=self.device)   # h3dgsv3.py:75
+        self.max_sh_degree = sh_degree
+        self.init_proba_scaler, self.gs_add_ratio, self.voxel_size = init_proba_scaler, gs_add_ratio, voxel_size
+        self.approx_cam_centres = None
+        self.sorted_frame_indices = None
+        self.cam_centres = None
+        radius = 3
+        self.disc_kernel = torch.zeros(1, 1, 2 * radius + 1, 2 * radius + 1).to(self.device)
+        y, x = torch.meshgrid(torch.arange(-radius, radius + 1), torch.arange(-radius, radius + 1), indexing="ij")
+        x, y = x.to(self.device), y.to(self.device)
+        self.disc_kernel[0, 0, torch.sqrt(x ** 2 + y ** 2) <= radius + 0.5] = 1
+        self.disc_kernel = self.disc_kernel / self.disc_kernel.sum()
+        self.lods = [1, 2, 4, 8]
+        self.uvs = dict()
+        for lod in self.lods:
+            self.uvs[lod] = torch.stack(torch.meshgrid(torch.arange(0, width // lod), torch.arange(0, height // lod), indexing="xy"),
+                                        dim=-1).float().to(self.device)
 
     # -- population ---------------------------------------------------------------------------
     def set_gaussians(self, means, quats, log_scales, opacity_logits, sh, d_max=1e3, n_voxels=None, seed=0):
@@ -226,6 +394,7 @@ class MapperScene:
         # itself, so two scenes built from one cloud would share -- and the second would get a non-leaf -- parameters)
         val = lambda t: t.detach().clone().to(dev).contiguous().requires_grad_(True)
         P = self.gaussian_params = {
+            "id": {"val": torch.zeros(N, 1, dtype=torch.long, device=dev)},   # the keyframe that created it (h3dgsv3.py:126, 910)
             "cls_id": {"val": torch.randint(0, n_vox, (N, 1), generator=g).to(dev)},
             "d_max": {"val": torch.full((N, 1), float(d_max), device=dev)},
             "xyz": {"val": val(means)},
@@ -242,7 +411,18 @@ class MapperScene:
         self.optimizer = SparseGaussianAdam({**P, **self.mlp_params}, (0.5, 0.99), lr_dict=self.lr_dict, device=dev)
 
     def add_keyframe(self, kf: Keyframe):
+        """h3dgsv3.py:981-1009 (the part that touches the device: the list of approximate camera centres and the keyframe
+        order by distance to the newest one, read back to the host)."""
         self.keyframes.append(kf)
+        centre = getattr(kf, "approx_centre", None)
+        if centre is None:
+            return
+        if self.approx_cam_centres is None:
+            self.approx_cam_centres = centre[None]
+        else:
+            self.approx_cam_centres = torch.cat([self.approx_cam_centres, centre[None]], dim=0)
+        dist_to_last = torch.linalg.vector_norm(self.approx_cam_centres - centre[None], dim=-1)
+        self.sorted_frame_indices = torch.argsort(dist_to_last).cpu()
 
     def reset_optimizer(self):
         """h3dgsv3.py:317-330: a NEW SparseGaussianAdam over the current parameters (called at the start of every finetune epoch)."""
@@ -255,6 +435,7 @@ class MapperScene:
                                             device=self.device)
 
     # -- reference-named accessors (h3dgsv3.py:332-372) --------------------------------------------
+    id = property(lambda s: s.gaussian_params["id"]["val"])
     xyz = property(lambda s: s.gaussian_params["xyz"]["val"])
     f_dc = property(lambda s: s.gaussian_params["f_dc"]["val"])
     f_rest = property(lambda s: s.gaussian_params["f_rest"]["val"])
@@ -323,8 +504,8 @@ class MapperScene:
 
     def make_dummy_ext_tensor(self):
         P = self.gaussian_params
-        keys = ("cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "local_feat", "global_feat")
-        return {k: P[k]["val"][:0].detach() for k in keys}
+        keys = ("id", "cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "local_feat", "global_feat")
+        return {k: P[k]["val"][:0].detach() for k in keys if k in P}
 
     @torch.no_grad()
     def weed_out_gaussians(self):
@@ -338,6 +519,134 @@ class MapperScene:
         visible_count = visible_count / len(self.keyframes)
         weed_mask = visible_count > self.visible_threshold
         self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
+
+    # -- update_voxel: h3dgsv3.py:227-316 (torch.unique x3, scatter_max, searchsorted, boolean-mask writes) -----------------
+    def update_voxel(self, new_xyz, xyz, cls_id, voxel_size=0.1):
+        device = new_xyz.device
+        num_new, num_orig = new_xyz.shape[0], xyz.shape[0]
+        if num_orig == 0:
+            v_min = new_xyz.min(dim=0).values
+            v_idx = torch.floor((new_xyz - v_min) / voxel_size).long()
+            v_max = v_idx.max(dim=0).values + 1
+            stride = torch.tensor([v_max[1] * v_max[2], v_max[2], 1], device=device)
+            h_new = (v_idx * stride).sum(dim=1)
+            u_hashes, u_inv = torch.unique(h_new, return_inverse=True)
+            return u_inv.unsqueeze(-1), u_hashes.shape[0]
+        cls_id_1d = cls_id.squeeze(-1)
+        max_cls = cls_id_1d.max().item()
+        all_p = torch.cat([xyz, new_xyz], dim=0)
+        min_c = all_p.min(dim=0).values
+        v_idx_all = torch.floor((all_p - min_c) / voxel_size).long()
+        v_max = v_idx_all.max(dim=0).values + 1
+        stride = torch.tensor([v_max[1] * v_max[2], v_max[2], 1], device=device)
+        h_all = (v_idx_all * stride).sum(dim=1)
+        h_orig, h_new = h_all[:num_orig], h_all[num_orig:]
+        unique_voxels, inv_idx = torch.unique(h_orig, return_inverse=True)
+        offset = max_cls + 1
+        pair_id = inv_idx * offset + cls_id_1d
+        pair_unique_ids, pair_counts = torch.unique(pair_id, return_counts=True)
+        v_indices_in_pair = pair_unique_ids // offset
+        c_labels_in_pair = pair_unique_ids % offset
+        _, max_indices = scatter_max(pair_counts, v_indices_in_pair)
+        voxel_mode_labels = c_labels_in_pair[max_indices]
+        updated_orig_cls_id = voxel_mode_labels[inv_idx].unsqueeze(-1)
+        pos = torch.searchsorted(unique_voxels, h_new)
+        pos_clamped = pos.clamp(max=unique_voxels.shape[0] - 1)
+        mask = unique_voxels[pos_clamped] == h_new
+        updated_new_cls_id = torch.zeros(num_new, dtype=torch.long, device=device)
+        if mask.any():
+            updated_new_cls_id[mask] = voxel_mode_labels[pos_clamped[mask]]
+        new_voxel_count = 0
+        if (~mask).any():
+            u_new_h, u_new_inv = torch.unique(h_new[~mask], return_inverse=True)
+            new_voxel_count = u_new_h.shape[0]
+            updated_new_cls_id[~mask] = u_new_inv + max_cls + 1
+        return updated_orig_cls_id, updated_new_cls_id.unsqueeze(-1), new_voxel_count
+
+    # -- add_new_gaussians: h3dgsv3.py:766-940, same operations in the same order ---------------------------------------------
+    @torch.no_grad()
+    def add_new_gaussians(self, keyframe_id=-1):
+        keyframe = self.keyframes[keyframe_id]
+        if keyframe.is_test:
+            return
+        dev = self.device
+        org_img = F.avg_pool2d(keyframe.image_pyr[0], 2)
+        extension_tensors = dict()
+        for lod in self.lods:
+            cur_h, cur_w = self.height // lod, self.width // lod
+            img = F.interpolate(org_img[None], (cur_h, cur_w), mode="bilinear", align_corners=True)[0]
+            init_proba = get_lapla_norm(img, self.disc_kernel, device=dev)
+            penalty = 0
+            if self.xyz.shape[0] > 0:
+                render_pkg = self.render_from_id(keyframe_id)
+                render = F.interpolate(render_pkg["render"][None], (cur_h, cur_w), mode="bilinear", align_corners=True)[0]
+                # (h3dgsv3.py:790 also resizes the inverse depth into `rendered_depth`, which nothing reads afterwards)
+                _ = 1 / F.interpolate(render_pkg["invdepth"][None], (cur_h, cur_w), mode="bilinear", align_corners=True)[0][0].clamp_min(1e-8)
+                penalty = get_lapla_norm(render, self.disc_kernel, device=dev)
+            init_proba *= self.init_proba_scaler
+            penalty *= self.init_proba_scaler
+            sample_mask = torch.rand_like(init_proba) < (init_proba - penalty) * self.gs_add_ratio
+            sampled_uv = self.uvs[lod][sample_mask]
+            sampled_depths = sample(keyframe.point_map[:, 2:], sampled_uv[None, None, ...], keyframe.width // lod, keyframe.height // lod)[0, 0, 0]
+            sampled_conf = sample(keyframe.mono_depth_conf, sampled_uv[None, None, ...], keyframe.width // lod, keyframe.height // lod)[0, 0, 0]
+            quantile_depth_min = min(1e-2, torch.quantile(keyframe.point_map[:, 2], 0.02).item())
+            valid_mask = (sampled_conf >= 0) * (sampled_depths > quantile_depth_min)
+            sample_mask[sample_mask.clone()] = valid_mask
+            sampled_uv = sampled_uv[valid_mask]
+            sampled_depths = sampled_depths[valid_mask]
+            sampled_conf = sampled_conf[valid_mask]
+            f = self.f / lod
+            centre = self.centre / lod
+            sampled_points = depth2points(sampled_uv, sampled_depths.unsqueeze(-1), f, centre)
+            sampled_points = (sampled_points - keyframe.get_t()) @ keyframe.get_R()
+            f_dc = RGB2SH(img[:, sample_mask].permute(1, 0).unsqueeze(1))
+            sampled_init_proba = init_proba[sample_mask]
+            scales = 1 / (torch.sqrt(sampled_init_proba))
+            scales.clamp_(1, self.width / 10)
+            scales.mul_(1 / self.f)
+            scales *= torch.linalg.vector_norm(sampled_points - keyframe.approx_centre[None], dim=-1)
+            scales = torch.log(lod * scales.clamp(1e-6, 1e6)).unsqueeze(-1).repeat(1, 3)
+            opacities = torch.ones(f_dc.shape[0], 1, device=dev)
+            opacities[: sampled_uv.shape[0]] *= 0.2 * sampled_conf[..., None]
+            opacities = inverse_sigmoid(opacities)
+            f_rest = torch.zeros(f_dc.shape[0], (self.max_sh_degree + 1) * (self.max_sh_degree + 1) - 1, 3, device=dev)
+            local_feats = torch.zeros((f_dc.shape[0], self.local_feat_dim), device=dev).float()
+            if len(self.xyz) > 0:
+                update_cls_ids, new_cls_ids, new_voxel_count = self.update_voxel(sampled_points, self.xyz, self.cls_id, self.voxel_size)
+                self.gaussian_params["cls_id"]["val"] = update_cls_ids
+            else:
+                new_cls_ids, new_voxel_count = self.update_voxel(sampled_points, self.xyz, self.cls_id, self.voxel_size)
+            global_feats = torch.zeros((new_voxel_count, self.global_feat_dim), device=dev)
+            rotation = torch.zeros((f_dc.shape[0], 4), device=dev)
+            rotation[:, 0] = 1
+            d_maxs = (sampled_depths.unsqueeze(-1) * lod).to(dev)
+            if self.xyz.shape[0] > 0:
+                valid_gs_mask = self.opacity[:, 0] > 0.05
+                dist = torch.linalg.vector_norm(self.xyz - keyframe.approx_centre[None], dim=-1)
+                screen_size = self.f * self.scaling.max(dim=-1)[0] / dist
+                valid_gs_mask *= screen_size < 0.5 * self.width
+            else:
+                valid_gs_mask = torch.ones(0, device=dev, dtype=torch.bool)
+            keyframe_id = len(self.keyframes) - 1 if keyframe_id == -1 else keyframe_id
+            extension_tensors[lod] = {
+                "id": torch.full((len(sampled_points), 1), keyframe_id, device=dev, dtype=torch.long), "cls_id": new_cls_ids,
+                "d_max": d_maxs, "xyz": sampled_points, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacities, "scaling": scales,
+                "rotation": rotation, "local_feat": local_feats, "global_feat": global_feats}
+        all_ext_tensors = {k: torch.concat([extension_tensors[lod][k] for lod in self.lods], dim=0) for k in extension_tensors[self.lods[0]]}
+        lock = getattr(self, "lock", None)
+        with (lock if lock is not None else _NULL_CTX):
+            self.optimizer.add_and_prune(all_ext_tensors, valid_gs_mask)
+        self.weed_out_gaussians()
+
+    # -- rigid_transform_gs: h3dgsv3.py:956-966 ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def rigid_transform_gs(self, old_c2ws, new_c2ws, cam_centres):
+        old_c2ws = old_c2ws[self.id.squeeze(-1)]
+        new_c2ws = new_c2ws[self.id.squeeze(-1)]
+        new_xyz, new_rotation = update_gaussians(old_c2ws, new_c2ws, self.xyz, self.rotation)
+        self.gaussian_params["xyz"]["val"] = new_xyz
+        self.gaussian_params["rotation"]["val"] = new_rotation
+        self.cam_centres = cam_centres
 
     def _rdk_for(self, h, w):
         key = (h, w)

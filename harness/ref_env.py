@@ -49,3 +49,52 @@ def import_scene_module(name: str = SCENE_MODULE):
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
     return importlib.import_module(name)
+
+
+class TorchNoCuda:
+    """`torch` as the reference's methods see it in this CPU-only container: a `device="cuda"` literal means the default device.
+    Bound in place of the module-level name `torch` of a reference module (monkeypatch / setattr)."""
+
+    def __getattr__(self, name):
+        import torch
+        attr = getattr(torch, name)
+        if name in ("tensor", "zeros", "ones", "full", "empty", "eye", "arange", "rand", "randn", "zeros_like", "ones_like"):
+            def factory(*a, **k):
+                if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+                    k.pop("device")
+                return attr(*a, **k)
+            return factory
+        return attr
+
+
+def cpu_natives():
+    """(rasterization, fused_ssim, adamUpdate, adamUpdateBasic, scatter_max) bound to the CPU oracles, with the reference's
+    call signatures -- what the real SceneModel / harness mirror run on when they are executed in this container."""
+    import numpy as np
+    import torch
+    from oracle import adam_oracle, gsplat_oracle, scatter_oracle, ssim_oracle
+
+    def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, render_mode, rasterize_mode, absgrad, packed,
+                      sh_degree, eps2d):
+        r, a, meta = gsplat_oracle.rasterization(means, quats, scales, opacities, colors, viewmats[0], Ks[0], width, height,
+                                                 sh_degree=sh_degree, eps2d=eps2d, grad_dtype=torch.float32)
+        return r[None], a[None], {"radii": meta["radii"][None]}
+
+    def fused_ssim(img1, img2, padding="same", train=True):
+        return ssim_oracle.fused_ssim_oracle(img1, img2, padding)
+
+    def adam_update(param, grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps, N, M):
+        lr_np = lr.detach().numpy() if torch.is_tensor(lr) else np.float32(lr)
+        p, m, v = adam_oracle.adam_update_oracle(param.detach().numpy(), grad.numpy(), exp_avg.numpy(), exp_avg_sq.numpy(),
+                                                 visible.numpy(), lr_np, b1, b2, eps, N, M)
+        param.data.copy_(torch.from_numpy(p)); exp_avg.copy_(torch.from_numpy(m)); exp_avg_sq.copy_(torch.from_numpy(v))
+
+    def adam_update_basic(param, grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
+        p, m, v = adam_oracle.adam_update_basic_oracle(param.detach().numpy(), grad.numpy(), exp_avg.numpy(), exp_avg_sq.numpy(), lr, b1, b2, eps)
+        param.data.copy_(torch.from_numpy(p)); exp_avg.copy_(torch.from_numpy(m)); exp_avg_sq.copy_(torch.from_numpy(v))
+
+    def scatter_max(src, index, *a, **k):
+        out, arg = scatter_oracle.scatter_arg(src.numpy(), index.numpy())
+        return torch.from_numpy(out), torch.from_numpy(arg)
+
+    return rasterization, fused_ssim, adam_update, adam_update_basic, scatter_max

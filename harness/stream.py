@@ -1,0 +1,187 @@
+"""The mapper's FRAME loop, as `run_system.py:143-234` runs it -- what the reference's own FPS figure measures
+(`h3dgsv3.py:1129-1132`: frames / wall-seconds of this loop).  Bench / test harness, not product.
+
+Per frame (run_system.py line numbers):
+  :162-175  the frame's image, dense point map and confidence arrive (here: synthetic, already resident on the device)
+  :177-192  Keyframe(image, Tcw, point_map, conf, ...)          -> harness.mapper.StreamKeyframe (pyramids, pose + exposure Adam)
+  :194-227  [SLAM keyframe] every keyframe's pose is re-read from the SLAM graph, old / new camera-to-world matrices are
+            collected one keyframe at a time, then scene_model.rigid_transform_gs(old, new, centres)
+  :230      scene_model.add_keyframe(kf)
+  :231-232  [important frame = mapper keyframe or test frame] scene_model.add_new_gaussians()
+  :233-234  optimization_loop(num_key_iterations = 20 if important else num_common_iterations = 10)   (run.sh:23-24)
+Keyframe choice inside optimization_step: 20 % the newest, 80 % uniform (h3dgsv3.py:406-414, --use_last_frame_proba 0.2).
+
+Frame schedule (no dataset here, so the cadence is a stated assumption): frame i is a test frame when i % test_hold == 0
+(run.sh --test_hold 8), a mapper keyframe when i % kf_every == 0, a SLAM keyframe when i % slam_every == 0; with
+--use_all_frames (run.sh:21) every frame reaches the mapper.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from harness import mapper
+
+
+def warm_libraries(dev):
+    """One-off initialisations that are not part of any frame: the first torch.linalg.inv / torch.inverse on a device creates
+    the rocSOLVER / hipBLAS handles (hundreds of milliseconds, once per process; run_system.py pays it on its first SLAM keyframe)."""
+    e = torch.eye(4, device=dev)[None].repeat(3, 1, 1)
+    torch.linalg.inv(e[0]); torch.inverse(e); torch.bmm(e, e)
+    torch.cuda.synchronize()
+
+
+def frame_flags(i: int, kf_every: int = 5, slam_every: int = 15, test_hold: int = 8):
+    is_test = test_hold > 0 and i % test_hold == 0 and i > 0
+    is_slam = i % slam_every == 0
+    is_kf_map = i % kf_every == 0 or is_slam      # a new SLAM keyframe is always a mapper keyframe (CameraTracker.py:143-148)
+    return dict(is_test=is_test, is_slam_keyframe=is_slam, is_important=is_kf_map or is_test)
+
+
+@torch.no_grad()
+def synthetic_frames(scene, n, seed=0, texture=0.05, slam_hw=(384, 512), jitter=0.01):
+    """n frames observing the scene's own cloud from jittered poses: image = render + band-limited texture (what the map does
+    not explain yet: drives add_new_gaussians), point map / confidence at the SLAM resolution from the rendered depth."""
+    dev = scene.device
+    g = torch.Generator().manual_seed(seed)
+    W, H = scene.width, scene.height
+    Hs, Ws = slam_hw
+    frames = []
+    for i in range(n):
+        Rt = torch.eye(4)
+        Rt[:3, 3] = jitter * torch.randn(3, generator=g)
+        Rt = Rt.to(dev)
+        if scene.xyz.shape[0] > 0:
+            pkg = scene.render(W, H, Rt, torch.full((3,), 0.5, device=dev))
+            img, inv = pkg["render"].clamp(0, 1), pkg["invdepth"]
+        else:
+            img, inv = torch.full((3, H, W), 0.5, device=dev), torch.full((1, H, W), 0.25, device=dev)
+        gate = F.interpolate(torch.rand(1, 1, H // 64 + 2, W // 64 + 2, generator=g).to(dev), (H, W), mode="bilinear", align_corners=True)[0]
+        noise = (torch.rand(3, H, W, generator=g) - 0.5).to(dev)
+        image = (img + texture * noise * (gate > 0.6)).clamp(0, 1).contiguous()
+        depth = 1.0 / F.interpolate(inv[None], (Hs, Ws), mode="bilinear", align_corners=True)[0, 0].clamp(1e-3, 1e3)
+        depth = torch.where(torch.isfinite(depth), depth, torch.full_like(depth, 4.0))
+        ys, xs = torch.meshgrid(torch.arange(Hs, dtype=torch.float32, device=dev), torch.arange(Ws, dtype=torch.float32, device=dev), indexing="ij")
+        fs = scene.f * Ws / W
+        point_map = torch.stack([(xs - (Ws - 1) / 2) / fs * depth, (ys - (Hs - 1) / 2) / fs * depth, depth], -1).contiguous()
+        conf = (0.4 + 0.5 * torch.rand(Hs, Ws, generator=g)).to(dev)
+        frames.append(dict(image=image, point_map=point_map, conf=conf, Rt=Rt))
+    return frames
+
+
+def make_keyframe(scene, frame, index, is_test=False, pyr_levels=1):
+    prev = scene.keyframes[-1] if scene.keyframes else None
+    f = torch.tensor([scene.f], device=scene.device)
+    return mapper.StreamKeyframe(frame["image"], frame["Rt"], frame["point_map"], frame["conf"], f, scene.device, index=index, prev_kf=prev,
+                                 is_test=is_test, pyr_levels=pyr_levels)
+
+
+@torch.no_grad()
+def slam_pose_update(scene, delta=1e-4, seed=0):
+    """run_system.py:194-227: on a SLAM keyframe every mapper keyframe's pose is re-read from the (just optimised) SLAM graph and set,
+    and the old / new camera-to-world matrices are collected keyframe by keyframe for rigid_transform_gs.  The new poses here are
+    the old ones moved by a small translation (what one global Gauss-Newton pass typically does to a converged trajectory)."""
+    dev = scene.device
+    K = len(scene.keyframes)
+    old_c2ws = torch.zeros(K, 4, 4).to(dev)
+    new_c2ws = torch.zeros(K, 4, 4).to(dev)
+    cam_centres = torch.zeros(K, 3).to(dev)
+    g = torch.Generator().manual_seed(seed)
+    for k, kf in enumerate(scene.keyframes):
+        old_Rt = kf.get_Rt().detach()
+        new_Rt = old_Rt.clone()
+        new_Rt[:3, 3] += (delta * torch.randn(3, generator=g)).to(dev)
+        kf.set_Rt(new_Rt)
+        view_matrix = kf.get_Rt().detach().transpose(0, 1)
+        centre = view_matrix.inverse()[3, :3]
+        old_c2ws[k] = torch.linalg.inv(old_Rt)
+        new_c2ws[k] = torch.linalg.inv(new_Rt)
+        cam_centres[k] = centre
+    scene.rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)
+    # the reference leaves xyz / rotation as plain tensors here (h3dgsv3.py:964-965); they become leaves again at the next
+    # add_and_prune.  The fused step reads .requires_grad of its leaves, so nothing else is needed.
+
+
+def optimization_step(scene, is_important, use_last_frame_proba=0.2):
+    """SceneModel.optimization_step's keyframe choice (h3dgsv3.py:406-414) in front of the mirror's step."""
+    n = len(scene.keyframes)
+    kid = np.random.randint(0, n) if np.random.rand() > use_last_frame_proba else -1
+    return scene.optimization_step(kid, is_important=is_important)
+
+
+class StageClock:
+    """Wall-clock per stage WITH a device synchronisation on both sides: only for the (untimed) breakdown pass."""
+
+    def __init__(self, enabled):
+        self.enabled, self.t = enabled, {}
+
+    def __call__(self, name):
+        clock = self
+
+        class _C:
+            def __enter__(self_inner):
+                if clock.enabled:
+                    torch.cuda.synchronize()
+                    self_inner.t0 = time.perf_counter()
+
+            def __exit__(self_inner, *a):
+                if clock.enabled:
+                    torch.cuda.synchronize()
+                    clock.t.setdefault(name, []).append(time.perf_counter() - self_inner.t0)
+        return _C()
+
+    def summary_ms(self, n_frames):
+        return {k: {"total_ms": 1e3 * sum(v), "calls": len(v), "ms_per_call": 1e3 * sum(v) / len(v), "ms_per_frame": 1e3 * sum(v) / max(n_frames, 1)}
+                for k, v in self.t.items()}
+
+
+def run_frame(scene, frame, index, flags, clock, *, num_key_iterations=20, num_common_iterations=10, pyr_levels=1):
+    with clock("keyframe_build"):
+        kf = make_keyframe(scene, frame, index, is_test=flags["is_test"], pyr_levels=pyr_levels)
+    if flags["is_slam_keyframe"] and index > 0 and scene.keyframes:
+        with clock("rigid_transform_gs"):
+            slam_pose_update(scene, seed=index)
+    with clock("add_keyframe"):
+        scene.add_keyframe(kf)
+    if flags["is_important"]:
+        with clock("add_new_gaussians"):
+            scene.add_new_gaussians()
+    n_it = num_key_iterations if flags["is_important"] else num_common_iterations
+    with clock("optimization_loop"):
+        for _ in range(n_it):
+            optimization_step(scene, flags["is_important"])
+    return n_it
+
+
+def run_stream(scene, frames, *, start_index=0, breakdown=False, kf_every=5, slam_every=15, test_hold=8, pyr_levels=1, **kw):
+    """Feed `frames` through the loop.  Returns dict(seconds, frames, steps, important, added, stage_ms (breakdown only))."""
+    clock = StageClock(breakdown)
+    n0 = scene.xyz.shape[0]
+    steps = important = densified = 0
+    added = [0]
+    opt = scene.optimizer
+    inner = opt.add_and_prune
+
+    def counting(ext, mask):   # rows appended by add_new_gaussians (weed_out_gaussians appends none); a host-side shape, no sync
+        added[0] += int(ext["xyz"].shape[0]) if "xyz" in ext else 0
+        return inner(ext, mask)
+    opt.add_and_prune = counting
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j, fr in enumerate(frames):
+        i = start_index + j
+        fl = frame_flags(i, kf_every, slam_every, test_hold)
+        steps += run_frame(scene, fr, len(scene.keyframes), fl, clock, pyr_levels=pyr_levels, **kw)
+        important += int(fl["is_important"])
+        densified += int(fl["is_important"] and not fl["is_test"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    opt.add_and_prune = inner
+    out = dict(seconds=dt, frames=len(frames), steps=steps, important_frames=important, densified_frames=densified,
+               gaussians_start=n0, gaussians_end=int(scene.xyz.shape[0]), gaussians_added=added[0])
+    if breakdown:
+        out["stage_ms"] = clock.summary_ms(len(frames))
+    return out

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 11
+#define ADK_ABI_VERSION 12
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -495,6 +495,47 @@ int adk_compact_plan(int64_t N, const uint8_t* keep, int64_t* n_keep, void* work
 int adk_compact_apply(int n_tensors, const void* const* src, const void* const* ext, void* const* dst,
                       const uint32_t* fill_bits, const int* words, int64_t N, int64_t E, const uint8_t* keep,
                       const int64_t* n_keep, const void* workspace, adk_stream_t stream);
+
+/* ------------------------------------------------------------ densification: the image-space chain of add_new_gaussians
+ * Replaces the torch / MIOpen operator chain SceneModel.add_new_gaussians runs per LoD level of every important frame --
+ * Reconstruct/scene/scene_models/h3dgsv3.py:775-903 with Reconstruct/utils.py:93-108 (get_lapla_norm), :121-131 (RGB2SH,
+ * inverse_sigmoid), :188-216 (depth2points, sample) -- see artdeco_amd/csrc/densify.hip.  All maps are row-major fp32.
+ *
+ * adk_densify_proba: proba [h,w] = scaler * clamp(disc (*) |sum_c Laplacian(resize(src))|, 0, 1), the whole of
+ *   `get_lapla_norm(F.interpolate(src, (h, w), bilinear, align_corners=True), disc_kernel) * init_proba_scaler` (h3dgsv3.py:781-782,
+ *   789-795) in one pass; pool2 != 0 applies F.avg_pool2d(src, 2) first (:776).  src [channels<=3, src_h, src_w]; disc [7,7] (the
+ *   scene model's disc_kernel, :209-220); img_out [channels,h,w] or NULL (the resized image; f_dc is read from it, :853). */
+int adk_densify_proba(const float* src, int channels, int src_h, int src_w, int pool2, int h, int w, const float* disc,
+                      float scaler, float* img_out, float* proba, adk_stream_t stream);
+
+/* out[0] = min(cap, torch.quantile(x, q)) on the device (h3dgsv3.py:815 reads it back with .item()): rank_below = floor(q (n-1)),
+ * weight = q (n-1) - rank_below, both computed by the caller in fp32 as torch does; exact order statistics (radix select). */
+int adk_densify_quantile(const float* x, int64_t n, int64_t rank_below, float weight, float cap, float* out, adk_stream_t stream);
+
+/* mask [h*w] (bytes) = rnd < (init_proba - penalty) * ratio  and  sample(conf) >= 0  and  sample(depth) > depth_min[0]
+ * (h3dgsv3.py:798-821); penalty may be NULL (empty map).  depth_map / conf_map [map_h, map_w] = keyframe.point_map[:, 2] /
+ * keyframe.mono_depth_conf; sample_w / sample_h = keyframe.width // lod, keyframe.height // lod (utils.py:203-216). */
+int adk_densify_select(int h, int w, const float* init_proba, const float* penalty, const float* rnd, float ratio,
+                       const float* depth_map, const float* conf_map, int map_h, int map_w, int sample_w, int sample_h,
+                       const float* depth_min, uint8_t* mask, adk_stream_t stream);
+
+/* The attributes of the selected pixels in boolean-index (row-major) order (h3dgsv3.py:847-872, 891): xyz [L,3] world points,
+ * f_dc [L,3], scaling [L,3] (log), opacity [L] (logit), d_max [L].  plan_workspace: what adk_compact_plan(h*w, mask, ...) left
+ * (its n_keep is L).  focal / centre_x / centre_y / map_width: the scene model's f, centre, width; Rt [4,4] = Keyframe.get_Rt(),
+ * approx_centre [3] (device). */
+int adk_densify_emit(int h, int w, int lod, const uint8_t* mask, const void* plan_workspace, const float* img_lod,
+                     const float* init_proba, const float* depth_map, const float* conf_map, int map_h, int map_w, int sample_w,
+                     int sample_h, float focal, float centre_x, float centre_y, int map_width, const float* Rt, const float* approx_centre,
+                     float* xyz, float* f_dc, float* scaling, float* opacity, float* d_max, adk_stream_t stream);
+
+/* valid_gs_mask of h3dgsv3.py:894-903: sigmoid(opacity_raw) > 0.05 and focal * max(exp(scaling_raw)) / |xyz - centre| < map_width / 2. */
+int adk_prune_mask(int64_t N, const float* opacity_raw, const float* scaling_raw, const float* xyz, const float* centre, float focal,
+                   int map_width, uint8_t* mask, adk_stream_t stream);
+
+/* SceneModel.rigid_transform_gs (h3dgsv3.py:956-966 -> Reconstruct/utils.py:28-62): xyz_out = R xyz + t, quat_out =
+ * quaternion(R * R(quat)) (wxyz) with (R | t) = delta[ids[i]]; delta [n_keyframes,4,4] = new_c2w @ inverse(old_c2w) per keyframe. */
+int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, const float* delta, const float* xyz, const float* quat,
+                        float* xyz_out, float* quat_out, adk_stream_t stream);
 
 #ifdef __cplusplus
 }

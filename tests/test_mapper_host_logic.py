@@ -200,7 +200,6 @@ def test_weed_out_gaussians_matches_the_reference_method(world):
         a.gaussian_params["d_max"]["val"][::3] = 0.4
     b = copy.deepcopy(a)
     b.args = types.SimpleNamespace(visible_threshold=a.visible_threshold)
-    b.id = torch.arange(b.xyz.shape[0])
     b.make_dummy_ext_tensor = types.MethodType(ref_dummy, b)
     n0 = a.xyz.shape[0]
     a.weed_out_gaussians()
