@@ -17,10 +17,6 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-os.environ["ARTDECO_AMD_AUTOFUSE"] = "0"
-# torch's CPU bilinear resize rounds differently in the vectorised body and the scalar tail of a thread's range, so its last bit
-# depends on the thread count: the goldens are generated with the thread count the tests run with (tests/conftest.py)
-torch.set_num_threads(int(os.environ.get("ADK_TEST_THREADS", "1")))
 
 from harness import mapper, ref_env  # noqa: E402
 
@@ -161,6 +157,10 @@ def run_reference(inp, seed, record):
 
 
 def main():
+    os.environ["ARTDECO_AMD_AUTOFUSE"] = "0"   # the reference's OWN methods are what is recorded (set here, not at import: the tests import this module)
+    # torch's CPU bilinear resize rounds differently in the vectorised body and the scalar tail of a thread's range, so its last bit
+    # depends on the thread count: the goldens are generated with the thread count the tests run with (tests/conftest.py)
+    torch.set_num_threads(int(os.environ.get("ADK_TEST_THREADS", "1")))
     for name, c in cases().items():
         inp = make_inputs(c)
         rec = {"lap": [], "render": [], "rand": []}
