@@ -175,11 +175,31 @@ __global__ __launch_bounds__(256) void count_isects_kernel(const int32_t* __rest
 // per slice: 16 waves share one LDS histogram (256 slices x 4 waves left most of the chip idle: 89 us -> see DESIGN)
 #define BIN_SORT_BIG 8192
 
+// Internal tiles may be WIDER than gsplat's 16x16 (round 3: one wave rasterises a 32x16 tile, so a splat costs one list entry, one
+// LDS record and -- in the backward -- one 64-lane reduction and one flush per 32x16 tile instead of per 16x16 tile).  A wide tile
+// lists exactly the Gaussians that gsplat lists for at least one of the 16x16 tiles inside it: the 16-pixel tile range is computed
+// as upstream does and then divided by the width / height factor (sx, sy = log2 of it).
+struct WideGrid { int tile_w16, tile_h16, sx, sy, wide_w, wide_h; };
+static inline WideGrid wide_grid(int width, int height, int tile_px_w, int tile_px_h) {
+    WideGrid g;
+    g.tile_w16 = (width + 15) / 16; g.tile_h16 = (height + 15) / 16;
+    g.sx = tile_px_w == 32 ? 1 : 0; g.sy = tile_px_h == 32 ? 1 : 0;
+    g.wide_w = (g.tile_w16 + (1 << g.sx) - 1) >> g.sx; g.wide_h = (g.tile_h16 + (1 << g.sy) - 1) >> g.sy;
+    return g;
+}
+__device__ __forceinline__ void tile_range_wide(float mx, float my, float rx, float ry, const WideGrid& g, int& x0, int& x1, int& y0, int& y1)
+{
+    tile_range_bin(mx, my, rx, ry, g.tile_w16, g.tile_h16, x0, x1, y0, y1);
+    const int ax = (1 << g.sx) - 1, ay = (1 << g.sy) - 1;
+    x0 >>= g.sx; x1 = (x1 + ax) >> g.sx; y0 >>= g.sy; y1 = (y1 + ay) >> g.sy;
+}
+
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec, int N,
-                                                        int tile_w, int tile_h, uint32_t* __restrict__ table /* [BIN_SLICES][n_tiles] */)
+                                                        WideGrid grid, uint32_t* __restrict__ table /* [BIN_SLICES][n_tiles] */)
 {
     extern __shared__ uint32_t hist[];
-    const int n_tiles = tile_w * tile_h;
+    const int tile_w = grid.wide_w;
+    const int n_tiles = grid.wide_w * grid.wide_h;
     for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0u;
     __syncthreads();
     const int chunk = (int)ceil_div(N, BIN_SLICES);
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* _
         const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
         const float4 a = r4[0], b = r4[1];
         int x0, x1, y0, y1;
-        tile_range_bin(a.x, a.y, a.w, b.w, tile_w, tile_h, x0, x1, y0, y1);
+        tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * tile_w + tx], 1u);
     }
@@ -256,12 +276,13 @@ __global__ __launch_bounds__(1024) void bin_tilescan_kernel(const uint32_t* __re
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ rec,
-                                                          const uint32_t* __restrict__ depth_keys, int N, int tile_w, int tile_h,
+                                                          const uint32_t* __restrict__ depth_keys, int N, WideGrid grid,
                                                           const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets,
                                                           int64_t capacity, unsigned long long* __restrict__ pairs)
 {
     extern __shared__ uint32_t cur[];
-    const int n_tiles = tile_w * tile_h;
+    const int tile_w = grid.wide_w;
+    const int n_tiles = grid.wide_w * grid.wide_h;
     const uint32_t* row = table + (int64_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) cur[t] = (uint32_t)offsets[t] + row[t];
     __syncthreads();
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t*
         const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
         const float4 a = r4[0], b = r4[1];
         int x0, x1, y0, y1;
-        tile_range_bin(a.x, a.y, a.w, b.w, tile_w, tile_h, x0, x1, y0, y1);
+        tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
         const unsigned long long key = ((unsigned long long)depth_keys[g] << 32) | (unsigned long long)(uint32_t)g;
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) {
@@ -567,32 +588,38 @@ extern "C" int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids
 // LDS the per-slice tile histogram may use (bytes): the count / scatter kernels ask for 4 B x tiles of dynamic LDS.
 #define ADK_BIN_LDS_LIMIT (128 * 1024)
 
-// 1 if adk_bin_local_* can handle this image size (tile histogram fits LDS), else the caller uses adk_bin_depth_order / adk_bin_tiles.
-extern "C" int adk_bin_local_supported(int width, int height)
-{
-    if (width <= 0 || height <= 0) return 0;
-    const int64_t n_tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
-    return n_tiles * 4 <= ADK_BIN_LDS_LIMIT ? 1 : 0;
-}
+static inline bool tile_shape_ok(int tpw, int tph) { return (tpw == 16 || tpw == 32) && (tph == 16 || tph == 32); }
 
-extern "C" int64_t adk_bin_local_workspace_bytes(int width, int height)
+// 1 if adk_bin_local_* can handle this image size (tile histogram fits LDS), else the caller uses adk_bin_depth_order / adk_bin_tiles.
+extern "C" int adk_bin_local_supported_t(int width, int height, int tile_px_w, int tile_px_h)
 {
-    if (width <= 0 || height <= 0) return ADK_EINVAL;
-    const int64_t n_tiles = (int64_t)((width + 15) / 16) * ((height + 15) / 16);
+    if (width <= 0 || height <= 0 || !tile_shape_ok(tile_px_w, tile_px_h)) return 0;
+    const adk::WideGrid g = adk::wide_grid(width, height, tile_px_w, tile_px_h);
+    return (int64_t)g.wide_w * g.wide_h * 4 <= ADK_BIN_LDS_LIMIT ? 1 : 0;
+}
+extern "C" int adk_bin_local_supported(int width, int height) { return adk_bin_local_supported_t(width, height, 16, 16); }
+
+extern "C" int64_t adk_bin_local_workspace_bytes_t(int width, int height, int tile_px_w, int tile_px_h)
+{
+    if (width <= 0 || height <= 0 || !tile_shape_ok(tile_px_w, tile_px_h)) return ADK_EINVAL;
+    const adk::WideGrid g = adk::wide_grid(width, height, tile_px_w, tile_px_h);
+    const int64_t n_tiles = (int64_t)g.wide_w * g.wide_h;
     return align256((int64_t)BIN_SLICES * n_tiles * 4) + align256(n_tiles * 4) + 256;
 }
+extern "C" int64_t adk_bin_local_workspace_bytes(int width, int height) { return adk_bin_local_workspace_bytes_t(width, height, 16, 16); }
 
-// Step 1: per-tile counts.  offsets [tile_h*tile_w] (the isect_offset_encode output) and stats [2] int64 (device):
-// stats[0] = n_isects, stats[1] = entries of the fullest tile.  The workspace is consumed by adk_bin_local_fill.
-extern "C" int adk_bin_local_count(int N, const int32_t* tiles_per_gauss, const float* rec, int width, int height, int32_t* offsets,
-                                   int64_t* stats, void* workspace, int64_t workspace_bytes, hipStream_t stream)
+// Step 1: per-tile counts.  offsets [tiles] (the isect_offset_encode output for 16x16 tiles) and stats [2] int64 (device):
+// stats[0] = n_isects, stats[1] = entries of the fullest tile.  The workspace is consumed by adk_bin_local_scatter.
+extern "C" int adk_bin_local_count_t(int N, const int32_t* tiles_per_gauss, const float* rec, int width, int height, int tile_px_w, int tile_px_h,
+                                     int32_t* offsets, int64_t* stats, void* workspace, int64_t workspace_bytes, hipStream_t stream)
 {
     using namespace adk;
     if (N < 0 || width <= 0 || height <= 0 || !offsets || !stats || !workspace) return ADK_EINVAL;
-    if (!adk_bin_local_supported(width, height)) return ADK_EUNSUPPORTED;
-    if (workspace_bytes < adk_bin_local_workspace_bytes(width, height) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
+    if (!adk_bin_local_supported_t(width, height, tile_px_w, tile_px_h)) return ADK_EUNSUPPORTED;
+    if (workspace_bytes < adk_bin_local_workspace_bytes_t(width, height, tile_px_w, tile_px_h) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
     if (N > 0 && (!tiles_per_gauss || !rec)) return ADK_EINVAL;
-    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    const WideGrid g = wide_grid(width, height, tile_px_w, tile_px_h);
+    const int n_tiles = g.wide_w * g.wide_h;
     uint32_t* table = (uint32_t*)workspace;
     uint32_t* tile_count = (uint32_t*)((char*)workspace + align256((int64_t)BIN_SLICES * n_tiles * 4));
     const size_t lds = (size_t)n_tiles * 4;
@@ -602,10 +629,15 @@ extern "C" int adk_bin_local_count(int N, const int32_t* tiles_per_gauss, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bin_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ADK_BIN_LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(bin_count_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), lds, stream, tiles_per_gauss, rec, N, tile_w, tile_h, table);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), lds, stream, tiles_per_gauss, rec, N, g, table);
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)ceil_div(n_tiles, 64)), dim3(1024), 0, stream, table, n_tiles, tile_count);
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, stream, tile_count, n_tiles, offsets, stats);
     ADK_RETURN_LAST_ERROR();
+}
+extern "C" int adk_bin_local_count(int N, const int32_t* tiles_per_gauss, const float* rec, int width, int height, int32_t* offsets,
+                                   int64_t* stats, void* workspace, int64_t workspace_bytes, hipStream_t stream)
+{
+    return adk_bin_local_count_t(N, tiles_per_gauss, rec, width, height, 16, 16, offsets, stats, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t adk_bin_local_pairs_bytes(int64_t n_isects) { return n_isects < 0 ? ADK_EINVAL : align256((n_isects > 0 ? n_isects : 1) * 8); }
@@ -613,38 +645,51 @@ extern "C" int64_t adk_bin_local_pairs_bytes(int64_t n_isects) { return n_isects
 // Step 2: every slice scatters its (depth bits << 32 | id) keys into the tiles' segments of `pairs` (capacity entries of 8 B; entries
 // beyond the capacity are dropped, so the host may launch this with an ESTIMATED capacity before it has read n_isects and repeat it in
 // the rare case the estimate was too small).  Order inside a segment is arbitrary.
+extern "C" int adk_bin_local_scatter_t(int N, int64_t capacity, const uint32_t* depth_keys, const int32_t* tiles_per_gauss, const float* rec,
+                                       int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets, const void* workspace,
+                                       int64_t workspace_bytes, void* pairs, hipStream_t stream)
+{
+    using namespace adk;
+    if (N < 0 || capacity < 0 || width <= 0 || height <= 0 || !offsets || !workspace || !tile_shape_ok(tile_px_w, tile_px_h)) return ADK_EINVAL;
+    if (N == 0 || capacity == 0) return 0;
+    if (!depth_keys || !tiles_per_gauss || !rec || !pairs) return ADK_EINVAL;
+    if (workspace_bytes < adk_bin_local_workspace_bytes_t(width, height, tile_px_w, tile_px_h) || ((uintptr_t)workspace & 255) || ((uintptr_t)pairs & 7)) return ADK_EWORKSPACE;
+    const WideGrid g = wide_grid(width, height, tile_px_w, tile_px_h);
+    const int n_tiles = g.wide_w * g.wide_h;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), (size_t)n_tiles * 4, stream, tiles_per_gauss, rec, depth_keys, N, g,
+                       (const uint32_t*)workspace, offsets, capacity, (unsigned long long*)pairs);
+    ADK_RETURN_LAST_ERROR();
+}
 extern "C" int adk_bin_local_scatter(int N, int64_t capacity, const uint32_t* depth_keys, const int32_t* tiles_per_gauss, const float* rec,
                                      int width, int height, const int32_t* offsets, const void* workspace, int64_t workspace_bytes,
                                      void* pairs, hipStream_t stream)
 {
-    using namespace adk;
-    if (N < 0 || capacity < 0 || width <= 0 || height <= 0 || !offsets || !workspace) return ADK_EINVAL;
-    if (N == 0 || capacity == 0) return 0;
-    if (!depth_keys || !tiles_per_gauss || !rec || !pairs) return ADK_EINVAL;
-    if (workspace_bytes < adk_bin_local_workspace_bytes(width, height) || ((uintptr_t)workspace & 255) || ((uintptr_t)pairs & 7)) return ADK_EWORKSPACE;
-    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_SLICES), dim3(BIN_THREADS), (size_t)n_tiles * 4, stream, tiles_per_gauss, rec, depth_keys, N, tile_w,
-                       tile_h, (const uint32_t*)workspace, offsets, capacity, (unsigned long long*)pairs);
-    ADK_RETURN_LAST_ERROR();
+    return adk_bin_local_scatter_t(N, capacity, depth_keys, tiles_per_gauss, rec, width, height, 16, 16, offsets, workspace, workspace_bytes, pairs, stream);
 }
 
 // Step 3: n_isects / max_tile = the HOST copies of stats (pairs must have held all n_isects entries).  Out: flatten_ids [I] in
 // (tile, depth, id) order, tile_ids [I] (or NULL).  max_tile must not exceed 8192 (otherwise: ADK_EUNSUPPORTED, use the global route).
-extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets, const void* pairs,
-                                  int32_t* flatten_ids, uint32_t* tile_ids, hipStream_t stream)
+extern "C" int adk_bin_local_sort_t(int64_t n_isects, int64_t max_tile, int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets,
+                                    const void* pairs, int32_t* flatten_ids, uint32_t* tile_ids, hipStream_t stream)
 {
     using namespace adk;
-    if (n_isects < 0 || width <= 0 || height <= 0 || !offsets) return ADK_EINVAL;
+    if (n_isects < 0 || width <= 0 || height <= 0 || !offsets || !tile_shape_ok(tile_px_w, tile_px_h)) return ADK_EINVAL;
     if (n_isects == 0) return 0;
     if (max_tile > BIN_SORT_BIG || n_isects >= ((int64_t)1 << 31)) return ADK_EUNSUPPORTED;
     if (!pairs || !flatten_ids) return ADK_EINVAL;
-    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    const WideGrid g = wide_grid(width, height, tile_px_w, tile_px_h);
+    const int n_tiles = g.wide_w * g.wide_h;
     hipLaunchKernelGGL(bin_tile_sort_wave_kernel, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, stream, (const unsigned long long*)pairs,
                        offsets, n_tiles, n_isects, flatten_ids, tile_ids);
     if (max_tile > BIN_SORT_WAVE)
         hipLaunchKernelGGL(bin_tile_sort_merge_kernel, dim3(n_tiles), dim3(512), 0, stream, (const unsigned long long*)pairs, offsets,
                            n_tiles, n_isects, flatten_ids, tile_ids);
     ADK_RETURN_LAST_ERROR();
+}
+extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets, const void* pairs,
+                                  int32_t* flatten_ids, uint32_t* tile_ids, hipStream_t stream)
+{
+    return adk_bin_local_sort_t(n_isects, max_tile, width, height, 16, 16, offsets, pairs, flatten_ids, tile_ids, stream);
 }
 
 // Optional (meta parity): upstream's sorted 64-bit keys, rebuilt from the tile-sorted list.

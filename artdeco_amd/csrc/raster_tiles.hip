@@ -29,6 +29,16 @@ namespace adk {
 
 #define TILE 16
 #define BATCH 256
+// How the per-quadrant cull results reach the scalar unit: one 64-bit ballot per quadrant whose bits the wave tests per splat
+// (round 2's form), or every lane keeps its own splat's quadrant hits as a bit set and the wave reads one lane's set per splat
+// (v_readlane).  Same-box A/B at 1 M / 1080p (gpurun_out/r03_ab_cull_style.txt, round 3): forward 0.2715 ms with ballots, 0.2655 with
+// the per-lane set; backward 0.567 with ballots, 0.574 with the per-lane set -- so each kernel keeps the form that won.
+#ifndef ADK_CULL_BALLOT_FWD
+#define ADK_CULL_BALLOT_FWD 0
+#endif
+#ifndef ADK_CULL_BALLOT_BWD
+#define ADK_CULL_BALLOT_BWD 1
+#endif
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
@@ -97,13 +107,19 @@ struct PixFwd {
     float best_vis; int best_idx; // MAIN_ID only
 };
 
-template <bool MAIN_ID>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void raster_fwd_kernel(
+// QX x QY quadrants of 8x8 pixels per wave: 2 x 2 = gsplat's 16x16 tile, 4 x 2 = the WIDE internal tile (32x16, round 3).  A wide
+// tile's list (raster_bin.hip, tile_range_wide) holds every Gaussian gsplat lists for one of its two 16x16 halves; a Gaussian that
+// gsplat does not list for a pixel's own 16x16 tile cannot reach alpha >= 1/255 there (its radius box bounds exactly that region),
+// and the per-quadrant test below rejects it, so every pixel composites the same splats in the same order as with 16x16 tiles:
+// the forward is bit-identical, the backward differs only in the order its sums are formed.
+template <int QX, int QY, bool MAIN_ID>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 4 ? 8 : 4, 8))) void raster_fwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     float* __restrict__ render_colors, float* __restrict__ render_alphas, float* __restrict__ final_T,
     int32_t* __restrict__ last_ids, int32_t* __restrict__ main_ids)
 {
+    constexpr int NQ = QX * QY, TPW = 8 * QX, TPH = 8 * QY;
     __shared__ float4 srec[64][3];
     const int n_tiles = tile_w * tile_h;
     const int tile = xcd_remap(blockIdx.x, n_tiles);
@@ -113,15 +129,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int range_start = offsets[tile];
     const int range_end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
 
-    PixFwd px[4];
-    float qx0[4], qy0[4];
-    bool inside[4];
+    PixFwd px[NQ];
+    bool inside[NQ];
     unsigned live = 0u; // quadrants that still have an unfinished pixel (wave-uniform)
-    unsigned long long done_m[4]; // wave-uniform lane masks (SGPR pairs): bit l = lane l's pixel of quadrant q is finished
+    unsigned long long done_m[NQ]; // wave-uniform lane masks (SGPR pairs): bit l = lane l's pixel of quadrant q is finished
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ox = tx * TILE + (q & 1) * 8, oy = ty * TILE + (q >> 1) * 8;
-        qx0[q] = (float)ox + 0.5f; qy0[q] = (float)oy + 0.5f;
+    for (int q = 0; q < NQ; ++q) {
+        const int ox = tx * TPW + (q % QX) * 8, oy = ty * TPH + (q / QX) * 8;
         const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
         PixFwd& P = px[q];
         P.o0 = P.o1 = P.o2 = P.o3 = 0.f;
@@ -131,10 +145,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (__ballot(inside[q]) != 0ull) live |= 1u << q;
     }
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
-    // pixel centre in quadrant 0; quadrant q adds (8 (q&1), 8 (q>>1)).  Register budget: 64 VGPRs, so that all
-    // tiles of a 1080p frame (8160) are resident at once (8 waves/SIMD x 1024 SIMDs) and there is no second,
-    // half-empty scheduling round.
-    const float fx0 = (float)(tx * TILE + (lane & 7)) + 0.5f, fy0 = (float)(ty * TILE + (lane >> 3)) + 0.5f;
+    // pixel centre in quadrant 0; quadrant q adds (8 (q % QX), 8 (q / QX)).  Register budget of the 16x16 form: 64 VGPRs, so that all
+    // tiles of a 1080p frame (8160) are resident at once (8 waves/SIMD x 1024 SIMDs) and there is no second, half-empty round.
+    const float fx0 = (float)(tx * TPW + (lane & 7)) + 0.5f, fy0 = (float)(ty * TPH + (lane >> 3)) + 0.5f;
+    const float tox = (float)(tx * TPW) + 0.5f, toy = (float)(ty * TPH) + 0.5f; // centre of the tile's first pixel
 
     for (int batch_start = range_start; batch_start < range_end && live; batch_start += 64) {
         const int batch_size = min(64, range_end - batch_start);
@@ -147,35 +161,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             stage_splat(srec[lane], r0, r1, rec4[3 * g + 2]);
         }
         __syncthreads();
-        // splat-parallel culling: this lane's splat against each live quadrant
-        unsigned long long mq[4];
+        // splat-parallel culling: this lane's splat against each live quadrant -> the lane's own quadrant bit set
+#if ADK_CULL_BALLOT_FWD
+        unsigned long long mq[NQ];
+#else
+        unsigned qmask = 0u;
+#endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
+#if ADK_CULL_BALLOT_FWD
             mq[q] = 0ull;
+#endif
             if ((live >> q) & 1u) {
-                const float x0 = qx0[q], x1 = x0 + 7.0f, y0 = qy0[q], y1 = y0 + 7.0f;
+                const float x0 = tox + (float)((q % QX) * 8), x1 = x0 + 7.0f, y0 = toy + (float)((q / QX) * 8), y1 = y0 + 7.0f;
                 const bool hit = have && (r0.x + r0.w >= x0) && (r0.x - r0.w <= x1) && (r0.y + r1.w >= y0) && (r0.y - r1.w <= y1) &&
                                  splat_reaches_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, x0, x1, y0, y1);
+#if ADK_CULL_BALLOT_FWD
                 mq[q] = __ballot(hit);
+#else
+                qmask |= hit ? (1u << q) : 0u;
+#endif
             }
         }
-        unsigned long long any = (mq[0] | mq[1]) | (mq[2] | mq[3]);
+#if ADK_CULL_BALLOT_FWD
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) any |= mq[q];
+#else
+        unsigned long long any = __ballot(qmask != 0u);
+#endif
         while (any) {
             const int t = __builtin_ctzll(any);
-            const unsigned long long bit = 1ull << t;
             any &= any - 1;
+#if ADK_CULL_BALLOT_FWD
+            const unsigned long long bit = 1ull << t;
+#define ADK_QHIT(q) (mq[q] & bit)
+#else
+            const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)qmask, t) & live; // wave-uniform: quadrants this splat can reach
+            if (qm == 0u) continue;
+#define ADK_QHIT(q) (qm & (1u << (q)))
+#endif
             const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
             const int idx = batch_start + t;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (mq[q] & bit) { // wave-uniform
+            for (int q = 0; q < NQ; ++q) {
+                if (ADK_QHIT(q)) { // wave-uniform
                     // Every predicate lives as a wave-uniform 64-bit lane mask (one v_cmp each, combined on the scalar unit) and is
                     // applied as the mask operand of a v_cndmask: no 0/1 materialisation, no per-lane bit tests (a per-lane `done`
                     // bit field + `bool && bool` + __ballot compiled to v_and / v_cmp / v_cndmask 0,1 / v_or / v_cmp_ne chains:
                     // 24 VALU instructions per evaluated quadrant against 19 now; measured 0.270 -> 0.243 ms).  Measured and
                     // rejected: the two state updates as plain v_movs under EXEC = contrib_m (0.254 ms: EXEC writes stall).
                     PixFwd& P = px[q];
-                    const float dx = a.x - (fx0 + (float)((q & 1) * 8)), dy = a.y - (fy0 + (float)((q >> 1) * 8));
+                    const float dx = a.x - (fx0 + (float)((q % QX) * 8)), dy = a.y - (fy0 + (float)((q / QX) * 8));
                     const float e = splat_exponent(a, cn, dx, dy);
                     const float alpha = fminf(MAX_ALPHA, __builtin_amdgcn_exp2f(e));
                     const unsigned long long m_sig = __builtin_amdgcn_ballot_w64(!(e > a.z)); // e > log2(opacity) <=> sigma < 0
@@ -189,28 +226,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(vis) : "v"(alpha * P.T), "s"(contrib_m));
                     P.o0 += col.x * vis; P.o1 += col.y * vis; P.o2 += col.z * vis; P.o3 += col.w * vis;
                     if (MAIN_ID && vis > P.best_vis) { P.best_vis = vis; P.best_idx = idx; }
-                    // cur_idx = idx, T = next_T in the contributing lanes: two plain moves under EXEC = contrib_m (the wave is
-                    // always full here: 64-thread block, only wave-uniform branches)
+                    // cur_idx = idx, T = next_T in the contributing lanes (the wave is always full here: 64-thread block, only
+                    // wave-uniform branches)
                     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.cur_idx) : "v"(idx), "s"(contrib_m));
                     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.T) : "v"(next_T), "s"(contrib_m));
                     if (term_m != 0ull) { // rare: some pixel just finished
                         done_m[q] |= term_m;
-                        if (~done_m[q] == 0ull) { // ... and it was the quadrant's last
+                        if (~done_m[q] == 0ull) { // ... and it was the quadrant's last: later splats skip it
                             live &= ~(1u << q);
+#if ADK_CULL_BALLOT_FWD
                             mq[q] = 0ull;
-                            any = ((mq[0] | mq[1]) | (mq[2] | mq[3])) & ~((bit << 1) - 1ull);
+                            any = 0ull;
+#pragma unroll
+                            for (int qq = 0; qq < NQ; ++qq) any |= mq[qq];
+                            any &= ~((bit << 1) - 1ull);
+#endif
                         }
                     }
                 }
             }
+            if (live == 0u) break;
         }
     }
 
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         if (inside[q]) {
             PixFwd& P = px[q];
-            const int pxi = tx * TILE + (q & 1) * 8 + (lane & 7), pyi = ty * TILE + (q >> 1) * 8 + (lane >> 3);
+            const int pxi = tx * TPW + (q % QX) * 8 + (lane & 7), pyi = ty * TPH + (q / QX) * 8 + (lane >> 3);
             const int64_t pix = (int64_t)pyi * W + pxi;
             render_alphas[pix] = 1.0f - P.T;
             // The backward restarts its transmittance recurrence from T_final.  Recovering it as 1 - alpha (what upstream
@@ -233,9 +276,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #define NACC 10
 __device__ __forceinline__ int acc_to_rec(int k) { return k < 3 ? k : (k < 6 ? k + 1 : k + 2); }
 
-// Per-pixel backward state (one per quadrant the lane serves).
+// Per-pixel backward state (one per quadrant the lane serves); the pixel centre is recomputed from the lane's quadrant-0 centre.
 struct PixBwd {
-    float fx, fy;        // pixel centre
     float T, bdot, C0;   // running transmittance, <buffer, v_render>, T_final*(v_alpha_out - <bg, v_render>)
     float vr0, vr1, vr2, vr3;
     int bin_final;       // index of the last splat that contributed in the forward (-1: pixel outside the image)
@@ -245,10 +287,12 @@ struct PixBwd {
 // wave against 2.6 for a plain one (and a ds_bpermute shuffle+add pair at ~21).  Cross-lane reductions are
 // therefore the most expensive thing this kernel does, and the design goal is ONE reduction per (splat,
 // tile) instead of one per (splat, 8x8 quadrant):
-//   * one wavefront per 16x16 tile; lane l owns pixel l (8x8 raster order) of EACH of the 4 quadrants;
-//   * splat-parallel culling produces four 64-bit hit masks (one per quadrant) per group of 64 staged
-//     splats; the wave walks the union and, per splat, evaluates only the quadrants whose bit is set
-//     (wave-uniform branches), summing their contributions in the same 10 registers;
+//   * one wavefront per tile of QX x QY quadrants (2 x 2 = gsplat's 16x16 tile, 4 x 2 = the wide 32x16 internal tile of round 3:
+//     26 % fewer (splat, tile) pairs on the bench cloud, hence 26 % fewer reductions / parkings / flush records);
+//     lane l owns pixel l (8x8 raster order) of EACH quadrant;
+//   * splat-parallel culling: every lane tests ITS staged splat against every quadrant and keeps the hits as a bit set in a
+//     register; the wave walks the splats that hit anything and, per splat, reads that lane's bit set into an SGPR and evaluates
+//     only those quadrants (wave-uniform branches), summing their contributions in the same 10 registers;
 //   * the 10 sums are reduced once per (splat, tile): transposing DPP butterfly inside each 16-lane row (11 DPP), the
 //     4 rows combined with v_permlane32_swap / v_permlane16_swap, and the 10 totals PARKED in an LDS table
 //     sacc[staged splat][gradient-record dword]; after the batch of 64 staged splats the table is flushed with 16
@@ -257,6 +301,7 @@ struct PixBwd {
 //     DIFFERENT records was 2x SLOWER (1.55 ms: the memory side pays per cache line touched by an instruction, not per
 //     lane), LDS ds_add_f32 for the row combine 0.85 ms.  Where the time goes (same measurements, ablations): cull test +
 //     exponent + validity 0.22, gradient arithmetic 0.21, cross-lane reduction 0.18, atomics 0.09 ms.
+template <int QX, int QY>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
@@ -264,6 +309,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_rec)
 {
+    constexpr int NQ = QX * QY, TPW = 8 * QX, TPH = 8 * QY;
     __shared__ float4 srec[64][3];
     __shared__ int sid[64];
     __shared__ float sacc[64][12]; // [staged splat][dword of its gradient record]: totals parked until the batch is flushed
@@ -291,16 +337,13 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         const int d = lane & 15;
         flush_rowbit = (d < 12 && d != 3 && d != 7) ? (1u << (lane >> 4)) : 0u;
     }
-    PixBwd px[4];
-    float qx0[4], qy0[4]; // pixel-centre origin of each quadrant
-    int quad_bin_final[4], tile_bin_final = -1;
+    PixBwd px[NQ];
+    int quad_bin_final[NQ], tile_bin_final = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ox = tx * TILE + (q & 1) * 8, oy = ty * TILE + (q >> 1) * 8;
-        qx0[q] = (float)ox + 0.5f; qy0[q] = (float)oy + 0.5f;
+    for (int q = 0; q < NQ; ++q) {
+        const int ox = tx * TPW + (q % QX) * 8, oy = ty * TPH + (q / QX) * 8;
         const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
         PixBwd& P = px[q];
-        P.fx = (float)pxi + 0.5f; P.fy = (float)pyi + 0.5f;
         P.vr0 = P.vr1 = P.vr2 = P.vr3 = 0.f; P.T = 1.f; P.bdot = 0.f; P.C0 = 0.f; P.bin_final = -1;
         if (pxi < W && pyi < H) {
             const int64_t pix = (int64_t)pyi * W + pxi;
@@ -316,6 +359,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         tile_bin_final = max(tile_bin_final, quad_bin_final[q]);
     }
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
+    const float fx0 = (float)(tx * TPW + (lane & 7)) + 0.5f, fy0 = (float)(ty * TPH + (lane >> 3)) + 0.5f;
+    const float tox = (float)(tx * TPW) + 0.5f, toy = (float)(ty * TPH) + 0.5f;
 
     // walk the tile's list back to front in groups of 64; groups entirely behind every pixel's last
     // contributor are skipped without being loaded
@@ -334,21 +379,41 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         }
         __syncthreads();
         unsigned long long touched_mask = 0ull; // staged splats whose totals were parked in sacc
-        // splat-parallel culling: this lane's splat against each quadrant
-        unsigned long long mq[4];
+        // splat-parallel culling: this lane's splat against each quadrant -> the lane's own quadrant bit set
+#if ADK_CULL_BALLOT_BWD
+        unsigned long long mq[NQ];
+#else
+        unsigned qmask = 0u;
+#endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float x0 = qx0[q], x1 = x0 + 7.0f, y0 = qy0[q], y1 = y0 + 7.0f;
+        for (int q = 0; q < NQ; ++q) {
+            const float x0 = tox + (float)((q % QX) * 8), x1 = x0 + 7.0f, y0 = toy + (float)((q / QX) * 8), y1 = y0 + 7.0f;
             const bool hit = have && (batch_end - lane <= quad_bin_final[q]) &&
                              (r0.x + r0.w >= x0) && (r0.x - r0.w <= x1) && (r0.y + r1.w >= y0) && (r0.y - r1.w <= y1) &&
                              splat_reaches_rect(r0.x, r0.y, r1.x, r1.y, r1.z, r0.z, x0, x1, y0, y1);
+#if ADK_CULL_BALLOT_BWD
             mq[q] = __ballot(hit);
+#else
+            qmask |= hit ? (1u << q) : 0u;
+#endif
         }
-        unsigned long long any = (mq[0] | mq[1]) | (mq[2] | mq[3]);
+#if ADK_CULL_BALLOT_BWD
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) any |= mq[q];
+#else
+        unsigned long long any = __ballot(qmask != 0u);
+#endif
         while (any) {
             const int t = __builtin_ctzll(any); // staged slot t holds list index batch_end - t (0 = furthest back)
             const unsigned long long bit = 1ull << t;
             any &= any - 1;
+#if ADK_CULL_BALLOT_BWD
+#define ADK_QHITB(q) (mq[q] & bit)
+#else
+            const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)qmask, t); // wave-uniform: quadrants this splat can reach
+#define ADK_QHITB(q) (qm & (1u << (q)))
+#endif
             const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
             const int idx = batch_end - t;
             float acc[NACC];
@@ -356,12 +421,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
             for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
             bool touched = false; // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (mq[q] & bit) { // wave-uniform
+            for (int q = 0; q < NQ; ++q) {
+                if (ADK_QHITB(q)) { // wave-uniform
                     PixBwd& P = px[q];
                     // Branch-free body: an invalid lane gets ov = 0 => alpha = 0, ra = 1, fac = 0 and every
                     // gradient term vanishes on its own.
-                    const float dx = a.x - P.fx, dy = a.y - P.fy;
+                    const float dx = a.x - (fx0 + (float)((q % QX) * 8)), dy = a.y - (fy0 + (float)((q / QX) * 8));
                     const float e = splat_exponent(a, cn, dx, dy);
                     float ov = __builtin_amdgcn_exp2f(e); // opacity * exp(-sigma)
                     const bool valid = (idx <= P.bin_final) && !(e > a.z) && !(ov < ALPHA_THR);
@@ -422,38 +487,61 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 
 // render_colors [H,W,4], render_alphas [H,W], final_T [H,W] (exact final transmittance, consumed by adk_raster_bwd),
 // last_ids [H,W]; backgrounds [4] or NULL; main_ids [H,W] (Gaussian id with the largest alpha*T per pixel, -1 if none) or NULL.
-extern "C" int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
-                              const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                              float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
-                              int32_t* main_ids, hipStream_t stream)
+// tile_px_w x tile_px_h: the tile shape the lists (flatten_ids / offsets) were binned for: 16x16 (gsplat's) or 32x16.
+extern "C" int adk_raster_fwd_t(int width, int height, int tile_px_w, int tile_px_h, const float* rec, const int32_t* flatten_ids,
+                                const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                                float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
+                                int32_t* main_ids, hipStream_t stream)
 {
     if (width <= 0 || height <= 0 || n_isects < 0 || n_isects >= ((int64_t)1 << 31)) return ADK_EINVAL;
     if (!offsets || !render_colors || !render_alphas || !final_T || !last_ids) return ADK_EINVAL;
     if (n_isects > 0 && (!rec || !flatten_ids)) return ADK_EINVAL;
     if (((uintptr_t)rec & 15) || ((uintptr_t)render_colors & 15)) return ADK_EINVAL;
-    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
-    if (main_ids)
-        hipLaunchKernelGGL(adk::raster_fwd_kernel<true>, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
-                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, main_ids);
-    else
-        hipLaunchKernelGGL(adk::raster_fwd_kernel<false>, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
-                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, nullptr);
+    const bool wide = tile_px_w == 32 && tile_px_h == 16;
+    if (!wide && !(tile_px_w == 16 && tile_px_h == 16)) return ADK_EUNSUPPORTED;
+    const int tile_w = (width + tile_px_w - 1) / tile_px_w, tile_h = (height + tile_px_h - 1) / tile_px_h;
+#define ADK_FWD(QX, QY, MID) hipLaunchKernelGGL((adk::raster_fwd_kernel<QX, QY, MID>), dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, \
+        width, height, rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, main_ids)
+    if (wide) { if (main_ids) ADK_FWD(4, 2, true); else ADK_FWD(4, 2, false); }
+    else { if (main_ids) ADK_FWD(2, 2, true); else ADK_FWD(2, 2, false); }
+#undef ADK_FWD
     ADK_RETURN_LAST_ERROR();
+}
+extern "C" int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
+                              const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                              float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
+                              int32_t* main_ids, hipStream_t stream)
+{
+    return adk_raster_fwd_t(width, height, 16, 16, rec, flatten_ids, offsets, n_isects, backgrounds, render_colors, render_alphas, final_T,
+                            last_ids, main_ids, stream);
 }
 
 // v_rec [N,12] must be zero-initialised by the caller; gradients are accumulated into it.
-extern "C" int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,
-                              const int32_t* offsets, int64_t n_isects, const float* backgrounds,
-                              const float* final_T, const int32_t* last_ids, const float* v_render_colors,
-                              const float* v_render_alphas, float* v_rec, hipStream_t stream)
+extern "C" int adk_raster_bwd_t(int width, int height, int tile_px_w, int tile_px_h, const float* rec, const int32_t* flatten_ids,
+                                const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                                const float* final_T, const int32_t* last_ids, const float* v_render_colors,
+                                const float* v_render_alphas, float* v_rec, hipStream_t stream)
 {
     if (width <= 0 || height <= 0 || n_isects < 0 || n_isects >= ((int64_t)1 << 31)) return ADK_EINVAL;
     if (n_isects == 0) return 0;
     if (!rec || !flatten_ids || !offsets || !final_T || !last_ids || !v_render_colors || !v_render_alphas || !v_rec) return ADK_EINVAL;
     if (((uintptr_t)rec & 15) || ((uintptr_t)v_render_colors & 15)) return ADK_EINVAL;
-    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
-    hipLaunchKernelGGL(adk::raster_bwd_kernel, dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
-                       rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors,
-                       v_render_alphas, v_rec);
+    const bool wide = tile_px_w == 32 && tile_px_h == 16;
+    if (!wide && !(tile_px_w == 16 && tile_px_h == 16)) return ADK_EUNSUPPORTED;
+    const int tile_w = (width + tile_px_w - 1) / tile_px_w, tile_h = (height + tile_px_h - 1) / tile_px_h;
+    if (wide)
+        hipLaunchKernelGGL((adk::raster_bwd_kernel<4, 2>), dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
+    else
+        hipLaunchKernelGGL((adk::raster_bwd_kernel<2, 2>), dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
     ADK_RETURN_LAST_ERROR();
+}
+extern "C" int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,
+                              const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                              const float* final_T, const int32_t* last_ids, const float* v_render_colors,
+                              const float* v_render_alphas, float* v_rec, hipStream_t stream)
+{
+    return adk_raster_bwd_t(width, height, 16, 16, rec, flatten_ids, offsets, n_isects, backgrounds, final_T, last_ids, v_render_colors,
+                            v_render_alphas, v_rec, stream);
 }

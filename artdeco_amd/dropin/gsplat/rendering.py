@@ -12,7 +12,35 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
+from artdeco_amd import rasterizer as _rasterizer
 from artdeco_amd.rasterizer import render_camera
+
+
+class _Meta(dict):
+    """gsplat's meta dictionary.  `flatten_ids` / `isect_offsets` are upstream's 16x16-tile lists; when the render used the wider
+    internal tiles (artdeco_amd.rasterizer.default_tile_px) they are built on first access from the finished projection --
+    ARTDECO itself only reads `radii` (h3dgsv3.py:689) and never pays for them."""
+
+    def __init__(self, *a, lazy=None, **k):
+        super().__init__(*a, **k)
+        self._lazy = lazy
+
+    def _materialise(self):
+        if self._lazy is not None:
+            fn, self._lazy = self._lazy, None
+            flat, offs = fn()
+            dict.__setitem__(self, "flatten_ids", flat)
+            dict.__setitem__(self, "isect_offsets", offs)
+
+    def __getitem__(self, key):
+        if key in ("flatten_ids", "isect_offsets"):
+            self._materialise()
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        if key in ("flatten_ids", "isect_offsets"):
+            self._materialise()
+        return super().get(key, default)
 
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 
@@ -91,16 +119,27 @@ def rasterization(
 
     rec = torch.stack([o[3] for o in outs])       # [C,N,12] packed splat records
     dch = 8 if depth_only else 11
-    meta = {
+    # the lists in the outputs are gsplat's when they were asked for or when the internal tiles are 16x16 anyway
+    gsplat_lists = want_isect_ids or _rasterizer.LAST_STATS.get("tile_px") == (16, 16)
+    meta = _Meta({
         "camera_ids": None, "gaussian_ids": None,
         "radii": torch.stack([o[2] for o in outs]),
         "means2d": rec[..., 0:2], "depths": rec[..., dch], "conics": rec[..., 4:7],
         "opacities": opacities[None].expand(C, -1),
         "tile_width": (width + 15) // 16, "tile_height": (height + 15) // 16,
         "tiles_per_gauss": torch.stack([o[4] for o in outs]),
-        "flatten_ids": torch.cat([o[5] + c * N for c, o in enumerate(outs)]) if C > 1 else outs[0][5],
-        "isect_offsets": torch.stack([o[6] for o in outs]),
         "isect_ids": (torch.cat([o[7] for o in outs]) if C > 1 else outs[0][7]) if want_isect_ids else None,
         "width": width, "height": height, "tile_size": 16, "n_cameras": C,
-    }
+    })
+    if gsplat_lists:
+        meta["flatten_ids"] = torch.cat([o[5] + c * N for c, o in enumerate(outs)]) if C > 1 else outs[0][5]
+        meta["isect_offsets"] = torch.stack([o[6] for o in outs])
+    else:
+        def build():
+            per = [_rasterizer.gsplat_tile_lists(o[3], o[11], o[4], width, height) for o in outs]
+            flat = torch.cat([p[0] + c * N for c, p in enumerate(per)]) if C > 1 else per[0][0]
+            return flat, torch.stack([p[1] for p in per])
+        dict.__setitem__(meta, "flatten_ids", None)
+        dict.__setitem__(meta, "isect_offsets", None)
+        meta._lazy = build
     return render, alphas, meta

@@ -85,6 +85,7 @@ class RasterConfig:
     want_isect_ids: bool = False
     inv_depth: bool = False      # depth channel holds 1/z (GaussianRasterizer adapter)
     want_main_ids: bool = False  # per-pixel id of the dominant Gaussian (GaussianRasterizer adapter)
+    tile_px: tuple = (16, 16)    # INTERNAL tile shape of the lists / tile kernels: (16, 16) = gsplat's, (32, 16) = wide (same pixels, fewer pairs)
 
 
 class _Workspace:
@@ -166,10 +167,10 @@ def _empty_rounded(n: int, **kw) -> torch.Tensor:
     return torch.empty(cap, **kw)[:n]
 
 
-def _isect_capacity_guess(dev: torch.device, N: int, W: int, H: int) -> int:
+def _isect_capacity_guess(dev: torch.device, N: int, W: int, H: int, tpw: int = 16) -> int:
     """Capacity (entries) for the scatter that is launched before n_isects is known: 1.25 x the previous call at the same
     resolution, or 0 on the first call (the scatter then runs after the wait)."""
-    prev = _CAPACITY_HINT.get((dev.index, W, H))
+    prev = _CAPACITY_HINT.get((dev.index, W, H, tpw))
     return 0 if prev is None else ((int(prev * 1.25) + _GRAIN - 1) // _GRAIN) * _GRAIN
 
 
@@ -197,7 +198,7 @@ def _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids, t
     _lib.check(rc, "adk_bin_depth_order")
     count_ready.synchronize()  # the one host wait of the pipeline (sizes the list)
     n_isects = int(host_count[0])
-    LAST_STATS.update(N=N, I=n_isects, width=W, height=H)
+    LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(16, 16), tiles_per_gauss=tiles_per_gauss)
 
     flatten_ids = _empty_rounded(n_isects, **i32)
     tile_ids = _empty_rounded(n_isects, **i32)
@@ -210,6 +211,78 @@ def _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids, t
                                tile_ids.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(), stream)
     _lib.check(rc, "adk_bin_tiles")
     return flatten_ids, tile_ids, offsets, n_isects
+
+
+def _bin_lists(lib, cfg, tile_px, want_tile_ids, N, W, H, rec, depth_keys, gauss_ids, tiles_per_gauss, dev, stream, i32, stats=True):
+    """(flatten_ids, tile_ids | None, offsets, n_isects, tile_px_w, tile_px_h): every (Gaussian, tile) pair in (tile, depth, id) order for
+    internal tiles of `tile_px`; the shape actually used comes back (the global route only produces gsplat's 16x16 lists)."""
+    tpw, tph = tile_px
+    use_local = bool(lib.adk_bin_local_supported_t(W, H, tpw, tph)) and os.environ.get("ADK_BIN_LOCAL", "1") != "0"
+    if not use_local:
+        tpw, tph = 16, 16                                   # the global route produces gsplat's 16x16 lists only
+    tile_w, tile_h = (W + tpw - 1) // tpw, (H + tph - 1) // tph
+    flatten_ids = tile_ids = offsets = None
+    if use_local:
+        # TILE-LOCAL route: counting sort by tile + one in-LDS sort per tile (raster_bin.hip).  The host needs n_isects
+        # (it sizes flatten_ids) and the fullest tile (it picks the sort kernels); both arrive with one pinned copy, and
+        # the scatter -- which only needs a CAPACITY -- is launched before the host waits, so the stream stays busy.
+        offsets = torch.empty(tile_h, tile_w, **i32)
+        stats_dev = torch.empty(2, dtype=torch.int64, device=dev)
+        table = torch.empty(int(lib.adk_bin_local_workspace_bytes_t(W, H, tpw, tph)) + 256, dtype=torch.uint8, device=dev)
+        tbase = (table.data_ptr() + 255) & ~255
+        tbytes = table.numel() - (tbase - table.data_ptr())
+        with _stage("bin_count"):
+            rc = lib.adk_bin_local_count_t(N, tiles_per_gauss.data_ptr(), rec.data_ptr(), W, H, tpw, tph, offsets.data_ptr(),
+                                           stats_dev.data_ptr(), tbase, tbytes, stream)
+        _lib.check(rc, "adk_bin_local_count")
+        host_count, count_ready = _count_slot(dev)
+        host_count.copy_(stats_dev, non_blocking=True)
+        count_ready.record()
+        guess = _isect_capacity_guess(dev, N, W, H, tpw)
+        pairs = torch.empty(guess, dtype=torch.int64, device=dev)  # guess is a multiple of 2^20: a stable size class
+        if guess > 0:
+            with _stage("bin_scatter"):
+                rc = lib.adk_bin_local_scatter_t(N, guess, depth_keys.data_ptr(), tiles_per_gauss.data_ptr(), rec.data_ptr(),
+                                                 W, H, tpw, tph, offsets.data_ptr(), tbase, tbytes, pairs.data_ptr(), stream)
+            _lib.check(rc, "adk_bin_local_scatter")
+        count_ready.synchronize()  # the one host wait of the pipeline
+        n_isects, max_tile = int(host_count[0]), int(host_count[1])
+        _CAPACITY_HINT[(dev.index, W, H, tpw)] = n_isects   # keyed on the image only: one entry per resolution however the map grows
+        if max_tile > 8192:
+            use_local = False      # a tile list too long for the in-LDS sort: global route below (16x16 lists)
+            tpw, tph = 16, 16
+        else:
+            if n_isects > pairs.numel():   # the estimate was too small (first call / the map grew by > 25 %): scatter again
+                pairs = _empty_rounded(n_isects, dtype=torch.int64, device=dev)
+                rc = lib.adk_bin_local_scatter_t(N, n_isects, depth_keys.data_ptr(), tiles_per_gauss.data_ptr(), rec.data_ptr(),
+                                                 W, H, tpw, tph, offsets.data_ptr(), tbase, tbytes, pairs.data_ptr(), stream)
+                _lib.check(rc, "adk_bin_local_scatter")
+            if stats:
+                LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(tpw, tph), tiles_per_gauss=tiles_per_gauss)
+            flatten_ids = _empty_rounded(n_isects, **i32)
+            tile_ids = _empty_rounded(n_isects, **i32) if want_tile_ids else None
+            with _stage("bin_sort"):
+                rc = lib.adk_bin_local_sort_t(n_isects, max_tile, W, H, tpw, tph, offsets.data_ptr(), pairs.data_ptr(),
+                                              flatten_ids.data_ptr(), _lib.ptr(tile_ids), stream)
+            _lib.check(rc, "adk_bin_local_sort")
+    if not use_local:
+        flatten_ids, tile_ids, offsets, n_isects = _bin_global(lib, cfg, N, W, H, (W + 15) // 16, (H + 15) // 16, rec, depth_keys, gauss_ids,
+                                                               tiles_per_gauss, dev, stream, i32)
+    return flatten_ids, tile_ids, offsets, n_isects, tpw, tph
+
+
+def gsplat_tile_lists(rec, depth_keys, tiles_per_gauss, width, height):
+    """(flatten_ids, isect_offsets [tile_h, tile_w]) for gsplat's own 16x16 tiles from a finished projection: what upstream's meta
+    carries under those names.  The drop-in computes them on first access when the render itself used wider internal tiles."""
+    lib = _lib.load()
+    dev, N = rec.device, rec.shape[0]
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        i32 = dict(dtype=torch.int32, device=dev)
+        gauss_ids = torch.arange(N, **i32)
+        flat, _t, offs, _n, _w, _h = _bin_lists(lib, None, (16, 16), False, N, width, height, rec, depth_keys, gauss_ids, tiles_per_gauss, dev,
+                                                stream, i32, stats=False)
+    return flat, offs
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -229,7 +302,6 @@ class RasterizeGaussians(torch.autograd.Function):
         dev = means.device
         N = means.shape[0]
         W, H = cfg.width, cfg.height
-        tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
         means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
         opacities = _f32c(opacities, "opacities")
         colors_c = _f32c(colors, "colors") if colors is not None else None
@@ -259,76 +331,40 @@ class RasterizeGaussians(torch.autograd.Function):
             final_T = torch.empty(H, W, dtype=torch.float32, device=dev)   # exact T_final for the backward
             last_ids = torch.empty(H, W, **i32)
             main_ids = torch.empty(H, W, **i32) if cfg.want_main_ids else None
-            use_local = bool(lib.adk_bin_local_supported(W, H)) and os.environ.get("ADK_BIN_LOCAL", "1") != "0"
-            flatten_ids = tile_ids = offsets = None
-            if use_local:
-                # TILE-LOCAL route: counting sort by tile + one in-LDS sort per tile (raster_bin.hip).  The host needs n_isects
-                # (it sizes flatten_ids) and the fullest tile (it picks the sort kernels); both arrive with one pinned copy, and
-                # the scatter -- which only needs a CAPACITY -- is launched before the host waits, so the stream stays busy.
-                offsets = torch.empty(tile_h, tile_w, **i32)
-                stats_dev = torch.empty(2, dtype=torch.int64, device=dev)
-                table = torch.empty(int(lib.adk_bin_local_workspace_bytes(W, H)) + 256, dtype=torch.uint8, device=dev)
-                tbase = (table.data_ptr() + 255) & ~255
-                tbytes = table.numel() - (tbase - table.data_ptr())
-                with _stage("bin_count"):
-                    rc = lib.adk_bin_local_count(N, tiles_per_gauss.data_ptr(), rec.data_ptr(), W, H, offsets.data_ptr(),
-                                                 stats_dev.data_ptr(), tbase, tbytes, stream)
-                _lib.check(rc, "adk_bin_local_count")
-                host_count, count_ready = _count_slot(dev)
-                host_count.copy_(stats_dev, non_blocking=True)
-                count_ready.record()
-                guess = _isect_capacity_guess(dev, N, W, H)
-                pairs = torch.empty(guess, dtype=torch.int64, device=dev)  # guess is a multiple of 2^20: a stable size class
-                if guess > 0:
-                    with _stage("bin_scatter"):
-                        rc = lib.adk_bin_local_scatter(N, guess, depth_keys.data_ptr(), tiles_per_gauss.data_ptr(), rec.data_ptr(),
-                                                       W, H, offsets.data_ptr(), tbase, tbytes, pairs.data_ptr(), stream)
-                    _lib.check(rc, "adk_bin_local_scatter")
-                count_ready.synchronize()  # the one host wait of the pipeline
-                n_isects, max_tile = int(host_count[0]), int(host_count[1])
-                _CAPACITY_HINT[(dev.index, W, H)] = n_isects   # keyed on the image only: one entry per resolution however the map grows
-                if max_tile > 8192:
-                    use_local = False      # a tile list too long for the in-LDS sort: global route below
-                else:
-                    if n_isects > pairs.numel():   # the estimate was too small (first call / the map grew by > 25 %): scatter again
-                        pairs = _empty_rounded(n_isects, dtype=torch.int64, device=dev)
-                        rc = lib.adk_bin_local_scatter(N, n_isects, depth_keys.data_ptr(), tiles_per_gauss.data_ptr(), rec.data_ptr(),
-                                                       W, H, offsets.data_ptr(), tbase, tbytes, pairs.data_ptr(), stream)
-                        _lib.check(rc, "adk_bin_local_scatter")
-                    LAST_STATS.update(N=N, I=n_isects, width=W, height=H)
-                    flatten_ids = _empty_rounded(n_isects, **i32)
-                    tile_ids = _empty_rounded(n_isects, **i32) if cfg.want_isect_ids else None
-                    with _stage("bin_sort"):
-                        rc = lib.adk_bin_local_sort(n_isects, max_tile, W, H, offsets.data_ptr(), pairs.data_ptr(), flatten_ids.data_ptr(),
-                                                    _lib.ptr(tile_ids), stream)
-                    _lib.check(rc, "adk_bin_local_sort")
-            if not use_local:
-                flatten_ids, tile_ids, offsets, n_isects = _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids,
-                                                                       tiles_per_gauss, dev, stream, i32)
+            flatten_ids, tile_ids, offsets, n_isects, tpw, tph = _bin_lists(lib, cfg, cfg.tile_px, cfg.want_isect_ids, N, W, H, rec, depth_keys,
+                                                                            gauss_ids, tiles_per_gauss, dev, stream, i32)
 
             with _stage("raster_fwd"):
-              rc = lib.adk_raster_fwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
-                                    _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(), final_T.data_ptr(),
-                                    last_ids.data_ptr(), _lib.ptr(main_ids), stream)
+              rc = lib.adk_raster_fwd_t(W, H, tpw, tph, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), n_isects,
+                                      _lib.ptr(bg), render_colors.data_ptr(), render_alphas.data_ptr(), final_T.data_ptr(),
+                                      last_ids.data_ptr(), _lib.ptr(main_ids), stream)
             _lib.check(rc, "adk_raster_fwd")
 
+            # what the caller sees as gsplat's lists: the internal ones when they ARE 16x16, else (only on request) a second,
+            # 16x16 binning of the same projection; the tile kernels and the backward keep using the internal lists
             isect_ids = torch.empty(0, dtype=torch.int64, device=dev)
+            pub_flat, pub_offsets = flatten_ids, offsets
             if cfg.want_isect_ids:
-                isect_ids = _empty_rounded(n_isects, dtype=torch.int64, device=dev)
-                rc = lib.adk_bin_make_isect_ids(n_isects, tile_ids.data_ptr(), flatten_ids.data_ptr(),
+                n_pub = n_isects
+                if (tpw, tph) != (16, 16):
+                    pub_flat, tile_ids, pub_offsets, n_pub, _w, _h = _bin_lists(lib, cfg, (16, 16), True, N, W, H, rec, depth_keys, gauss_ids,
+                                                                               tiles_per_gauss, dev, stream, i32, stats=False)
+                isect_ids = _empty_rounded(n_pub, dtype=torch.int64, device=dev)
+                rc = lib.adk_bin_make_isect_ids(n_pub, tile_ids.data_ptr(), pub_flat.data_ptr(),
                                                 depth_keys.data_ptr(), isect_ids.data_ptr(), stream)
                 _lib.check(rc, "adk_bin_make_isect_ids")
 
         ctx.set_materialize_grads(False)  # no zero tensors for the eight non-differentiable by-products
         ctx.cfg = cfg
         ctx.n_isects = n_isects
+        ctx.tile_px = (tpw, tph)
         ctx.has_bg = bg is not None
         ctx.has_rest = rest_c is not None
         ctx.save_for_backward(means, quats, scales, colors_c if colors_c is not None else means.new_empty(0),
                               rest_c if rest_c is not None else means.new_empty(0), viewmat, K, bg if bg is not None else means.new_empty(0), rec, radii, flatten_ids,
                               offsets, final_T, last_ids)
-        aux = (radii, rec, tiles_per_gauss, flatten_ids, offsets, isect_ids, last_ids,
-               main_ids if main_ids is not None else torch.empty(0, **i32), final_T)
+        aux = (radii, rec, tiles_per_gauss, pub_flat, pub_offsets, isect_ids, last_ids,
+               main_ids if main_ids is not None else torch.empty(0, **i32), final_T, depth_keys)
         ctx.mark_non_differentiable(*aux)
         return (render_colors, render_alphas) + aux
 
@@ -348,7 +384,7 @@ class RasterizeGaussians(torch.autograd.Function):
             v_alphas = (v_alphas if v_alphas is not None else torch.zeros(H, W, 1, device=dev)).contiguous()
             v_rec = torch.zeros(N, 12, dtype=torch.float32, device=dev)
             with _stage("raster_bwd"):
-              rc = lib.adk_raster_bwd(W, H, rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), ctx.n_isects,
+              rc = lib.adk_raster_bwd_t(W, H, ctx.tile_px[0], ctx.tile_px[1], rec.data_ptr(), flatten_ids.data_ptr(), offsets.data_ptr(), ctx.n_isects,
                                     bg.data_ptr() if ctx.has_bg else None, final_T.data_ptr(),
                                     last_ids.data_ptr(), v_colors.data_ptr(), v_alphas.data_ptr(), v_rec.data_ptr(),
                                     stream)
@@ -414,8 +450,18 @@ def _cam_grad_reset(buf, rc: int) -> None:
         buf.zero_()
 
 
+def default_tile_px() -> tuple:
+    """Internal tile shape: ADK_TILE_SHAPE = "16x16" (default: gsplat's own tiles) or "32x16" (one wave per 32x16 tile: 26 % fewer
+    (splat, tile) pairs to list, stage, reduce and flush, per-pixel results unchanged -- built and measured in round 3: the
+    backward's VALU instructions fall by 8 %, but 4 080 waves of 138 VGPRs leave half as many waves resident and the kernels
+    run 30 % SLOWER at 1 M / 1080p; profiles/r03_wide_tiles.txt).  `flatten_ids` / `isect_offsets` / `isect_ids` as upstream
+    defines them (16x16) are produced separately when the internal shape differs and a caller asks for them."""
+    v = os.environ.get("ADK_TILE_SHAPE", "16x16").lower()
+    return (32, 16) if v == "32x16" else (16, 16)
+
+
 def camera_config(colors, width, height, *, sh_degree, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
-                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None):
+                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None, tile_px=None):
     """(RasterConfig, colours, sh_rest) of one render_camera call: the argument checks and the colour mode."""
     if depth_only:
         mode, K_sh, deg, cols = _COLOR_DEPTH, 0, 0, None
@@ -439,20 +485,21 @@ def camera_config(colors, width, height, *, sh_degree, eps2d=0.3, near_plane=0.0
             raise NotImplementedError(f"post-activation colours must be [N,3], got {tuple(colors.shape)}")
         mode, K_sh, deg, cols = _COLOR_RGB, 0, 0, colors
     cfg = RasterConfig(int(width), int(height), deg, K_sh, mode, float(eps2d), float(near_plane),
-                       float(far_plane), float(radius_clip), bool(want_isect_ids), bool(inv_depth), bool(want_main_ids))
+                       float(far_plane), float(radius_clip), bool(want_isect_ids), bool(inv_depth), bool(want_main_ids),
+                       tuple(tile_px) if tile_px is not None else default_tile_px())
     return cfg, cols, sh_rest
 
 
 def render_camera(means, quats, scales, opacities, colors, viewmat, K, width, height, *, sh_degree,
                   eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, backgrounds=None,
-                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None):
+                  depth_only=False, want_isect_ids=False, inv_depth=False, want_main_ids=False, sh_rest=None, tile_px=None):
     """One camera.  colors: SH coefficients [N,K,3] when sh_degree is not None, else RGB [N,3]
     (ignored when depth_only).  sh_rest: optional [N,K-1,3] -- then `colors` is band 0 only
     ([N,1,3], ARTDECO's f_dc) and no concatenation is materialised.  backgrounds: [4] or None."""
     cfg, cols, sh_rest = camera_config(colors, width, height, sh_degree=sh_degree, eps2d=eps2d, near_plane=near_plane,
                                        far_plane=far_plane, radius_clip=radius_clip, depth_only=depth_only,
                                        want_isect_ids=want_isect_ids, inv_depth=inv_depth, want_main_ids=want_main_ids,
-                                       sh_rest=sh_rest)
+                                       sh_rest=sh_rest, tile_px=tile_px)
     return RasterizeGaussians.apply(means, quats, scales, opacities, cols, sh_rest, viewmat, K, backgrounds, cfg)
 
 

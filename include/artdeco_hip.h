@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 12
+#define ADK_ABI_VERSION 13
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -202,6 +202,18 @@ int adk_bin_local_scatter(int N, int64_t capacity, const uint32_t* depth_keys, c
                           const void* workspace, int64_t workspace_bytes, void* pairs, adk_stream_t stream);
 int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets,
                        const void* pairs, int32_t* flatten_ids, uint32_t* tile_ids, adk_stream_t stream);
+/* The same three steps for an INTERNAL tile shape tile_px_w x tile_px_h in {16x16, 32x16, 32x32}: a wider tile lists every Gaussian
+ * gsplat lists for one of the 16x16 tiles inside it, in the same (depth, id) order; offsets has one entry per internal tile.
+ * (`adk_bin_local_*` without the suffix = 16x16 = gsplat's isect_tiles / isect_offset_encode outputs.) */
+int adk_bin_local_supported_t(int width, int height, int tile_px_w, int tile_px_h);
+int64_t adk_bin_local_workspace_bytes_t(int width, int height, int tile_px_w, int tile_px_h);
+int adk_bin_local_count_t(int N, const int32_t* tiles_per_gauss, const float* rec, int width, int height, int tile_px_w, int tile_px_h,
+                          int32_t* offsets, int64_t* stats, void* workspace, int64_t workspace_bytes, adk_stream_t stream);
+int adk_bin_local_scatter_t(int N, int64_t capacity, const uint32_t* depth_keys, const int32_t* tiles_per_gauss, const float* rec,
+                            int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets, const void* workspace,
+                            int64_t workspace_bytes, void* pairs, adk_stream_t stream);
+int adk_bin_local_sort_t(int64_t n_isects, int64_t max_tile, int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets,
+                         const void* pairs, int32_t* flatten_ids, uint32_t* tile_ids, adk_stream_t stream);
 /* Optional: rebuild upstream's sorted int64 isect_ids for meta['isect_ids']. */
 int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int32_t* flatten_ids,
                            const uint32_t* depth_keys, int64_t* isect_ids, adk_stream_t stream);
@@ -215,6 +227,17 @@ int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatt
                    const int32_t* offsets, int64_t n_isects, const float* backgrounds,
                    float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
                    int32_t* main_ids, adk_stream_t stream);
+
+/* adk_raster_fwd / adk_raster_bwd on lists binned for an internal tile of tile_px_w x tile_px_h (16x16 or 32x16): per pixel the same
+ * splats are composited in the same order, so the forward is bit-identical to the 16x16 form; one wave serves the whole internal tile. */
+int adk_raster_fwd_t(int width, int height, int tile_px_w, int tile_px_h, const float* rec, const int32_t* flatten_ids,
+                     const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                     float* render_colors, float* render_alphas, float* final_T, int32_t* last_ids,
+                     int32_t* main_ids, adk_stream_t stream);
+int adk_raster_bwd_t(int width, int height, int tile_px_w, int tile_px_h, const float* rec, const int32_t* flatten_ids,
+                     const int32_t* offsets, int64_t n_isects, const float* backgrounds,
+                     const float* final_T, const int32_t* last_ids, const float* v_render_colors,
+                     const float* v_render_alphas, float* v_rec, adk_stream_t stream);
 
 /* Replaces rasterize_to_pixels bwd: accumulates into v_rec [N,12] (caller zero-fills it). */
 int adk_raster_bwd(int width, int height, const float* rec, const int32_t* flatten_ids,

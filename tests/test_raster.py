@@ -244,7 +244,7 @@ def test_binning_routes_agree_and_survive_a_wrong_capacity_guess(dev, monkeypatc
     ref = _binning_outputs(_run_hip(sc, dev)[2])
     assert ref["flatten_ids"].size > (1 << 21)
     monkeypatch.setenv("ADK_BIN_LOCAL", "1")
-    key = (torch.device(dev).index or 0, N, W, H)
+    key = (torch.device(dev).index or 0, W, H, 16)   # the 16x16 lists these outputs are compared on
     for hint in (None, 10, 3 * ref["flatten_ids"].size):
         rasterizer._CAPACITY_HINT.pop(key, None)
         if hint is not None:
@@ -414,3 +414,34 @@ def test_gaussian_rasterizer_adapter(dev):
     assert bool((mid[ao[..., 0] == 0] == -1).all()) and int(mid.max()) < N
     (color.sum() + invdepth.sum()).backward()
     assert bool(torch.isfinite(means.grad).all()) and float(means.grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,W,H,seed", [(20_000, 250, 187, 0), (300_000, 1000, 530, 1), (1_000_000, 1920, 1080, 2), (1_000_000, 512, 384, 3)])
+def test_wide_internal_tiles_composite_the_same_pixels(N, W, H, seed, dev, monkeypatch):
+    """Round 3: one wave can rasterise a 32x16 INTERNAL tile (ADK_TILE_SHAPE=32x16) instead of gsplat's 16x16.  Every pixel must
+    composite the same splats in the same order: the forward outputs are BIT-IDENTICAL to the 16x16 form (ragged right / bottom
+    edges, odd tile counts and the long-list sort path included), the gradients differ only by the order of their sums, the
+    lists handed out as gsplat's are the same 16x16 lists, and the wide form lists fewer (splat, tile) pairs."""
+    from artdeco_amd import rasterizer
+    sc = dict(_scene(N, W, H, seed), viewmat=_tilted_viewmat(seed))
+    g = torch.Generator().manual_seed(seed)
+    wgt = torch.randn(H, W, 4, generator=g).to(dev)
+    res = {}
+    for shape in ("16x16", "32x16"):
+        monkeypatch.setenv("ADK_TILE_SHAPE", shape)
+        r, a, meta, leaves = _run_hip(sc, dev, requires_grad=True)
+        res[shape] = dict(r=r.detach().clone(), a=a.detach().clone(), I=rasterizer.LAST_STATS["I"], tile_px=rasterizer.LAST_STATS["tile_px"],
+                          flat=meta["flatten_ids"].clone(), off=meta["isect_offsets"].clone(), ids=meta["isect_ids"].clone())
+        ((r[0] * wgt).sum() + a.sum()).backward()
+        res[shape]["grads"] = {k: v.grad.detach().clone() for k, v in leaves.items()}
+    a16, a32 = res["16x16"], res["32x16"]
+    long_lists = (N, W, H) == (1_000_000, 512, 384)   # 32x16 lists beyond 8192 entries: that frame goes to the global route (16x16)
+    assert a16["tile_px"] == (16, 16) and a32["tile_px"] == ((16, 16) if long_lists else (32, 16))
+    assert torch.equal(a16["r"], a32["r"]) and torch.equal(a16["a"], a32["a"])
+    assert torch.equal(a16["flat"], a32["flat"]) and torch.equal(a16["off"], a32["off"]) and torch.equal(a16["ids"], a32["ids"])
+    assert long_lists or a32["I"] < 0.9 * a16["I"]
+    for k, g16 in a16["grads"].items():
+        g32 = a32["grads"][k]
+        rel = float((g32 - g16).norm() / g16.norm().clamp_min(1e-30))
+        assert rel <= 2e-5, (k, rel)
