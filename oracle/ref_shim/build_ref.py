@@ -7,6 +7,14 @@ What it builds (outputs only under oracle/_ref/, which is git-ignored but travel
                                      /root/reference/Reconstruct/submodules/simple-knn/simple_knn.cu  (C ABI: ref_knn*)
   oracle/_ref/ref_matching.so        iter_proj_cuda / refine_matches_cuda of
                                      /root/reference/VSLAM/backend/src/matching_kernels.cu             (pybind11 module)
+  oracle/_ref/ref_gn.so              gauss_newton_points_cuda / _rays_cuda / _calib_cuda of
+                                     /root/reference/VSLAM/backend/src/gn_kernels.cu                   (pybind11 module)
+                                     -- the three accumulate kernels, the pose retraction and the host-side SparseBlock
+                                     assembly / solve, with oracle/ref_shim/include/eigen_host_shim.h standing in for Eigen
+                                     (dense fp64 LL^T for SimplicialLLT) and `torch::kCUDA` reading `torch::kCPU`.  One more
+                                     mechanical edit here: gn_kernels.cu's warpReduce (:36-43) relies on the implicit lock step
+                                     of a warp; `__syncwarp();` is inserted after each of its six statements so that the fiber
+                                     model executes them step by step for all 32 lanes, as the hardware does.
 
 The reference sources are compiled from where they lie: the only edit is mechanical and done in memory by this script --
 `kernel<<<grid, block>>>(args)` (not C++) becomes `shim::launch(grid, block, [&]{ kernel(args); })` -- and the result is
@@ -37,6 +45,7 @@ REF = os.environ.get("ARTDECO_REFERENCE", "/root/reference")
 KNN_DIR = os.path.join(REF, "Reconstruct", "submodules", "simple-knn")
 KNN_SRC = os.path.join(KNN_DIR, "simple_knn.cu")
 MATCH_SRC = os.path.join(REF, "VSLAM", "backend", "src", "matching_kernels.cu")
+GN_SRC = os.path.join(REF, "VSLAM", "backend", "src", "gn_kernels.cu")
 
 _LAUNCH = re.compile(r"<<\s*<")
 _CLOSE = re.compile(r">>\s*>")
@@ -131,6 +140,36 @@ PYBIND11_MODULE(ref_matching, m) {
 '''
 
 
+GN_MAIN = r'''
+#include <torch/extension.h>
+// torch::linalg::linalg_norm (gn_kernels.cu:802) of the C++ frontend's torch/linalg.h, which this wheel does not ship: the same ATen op
+namespace torch { namespace linalg {
+inline at::Tensor linalg_norm(const at::Tensor& x, std::optional<c10::Scalar> ord, at::OptionalIntArrayRef dim, bool keepdim,
+                              std::optional<at::ScalarType> dtype) { return at::linalg_norm(x, ord, dim, keepdim, dtype); }
+} }
+namespace torch { template <typename T> struct RestrictPtrTraits { typedef T* __restrict__ PtrType; }; }
+// the reference moves the solver's results "to the device" (gn_kernels.cu:123-149); in this host build the device is the CPU
+#define kCUDA kCPU
+#include "gn_kernels.gen.cpp"
+// the entry points /root/reference/VSLAM/backend/src/gn.cpp:3-82 forwards to (its CHECK_INPUT guards demand CUDA tensors)
+PYBIND11_MODULE(ref_gn, m) {
+    m.def("gauss_newton_points", &gauss_newton_points_cuda);
+    m.def("gauss_newton_rays", &gauss_newton_rays_cuda);
+    m.def("gauss_newton_calib", &gauss_newton_calib_cuda);
+}
+'''
+
+_WARP_STEP = re.compile(r"^(\s*sdata\[tid\] \+= sdata\[tid \+ +\d+\];)\s*$", re.M)
+
+
+def explicit_warp_steps(src: str) -> str:
+    """`__syncwarp();` after every statement of warpReduce (gn_kernels.cu:36-43): the warp-synchronous lock step made explicit."""
+    out, n = _WARP_STEP.subn(r"\1 __syncwarp();", src)
+    if n != 6:
+        raise RuntimeError(f"gn_kernels.cu: expected the six steps of warpReduce, found {n}")
+    return out
+
+
 def _run(cmd):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -138,7 +177,7 @@ def _run(cmd):
 
 
 def targets():
-    return {"knn": os.path.join(OUT, "libref_knn.so"), "matching": os.path.join(OUT, "ref_matching.so")}
+    return {"knn": os.path.join(OUT, "libref_knn.so"), "matching": os.path.join(OUT, "ref_matching.so"), "gn": os.path.join(OUT, "ref_gn.so")}
 
 
 def available() -> bool:
@@ -147,10 +186,11 @@ def available() -> bool:
 
 def build(force: bool = False) -> bool:
     """Returns True when oracle/_ref is usable afterwards (built now or earlier)."""
-    if not (os.path.exists(KNN_SRC) and os.path.exists(MATCH_SRC)):
+    if not (os.path.exists(KNN_SRC) and os.path.exists(MATCH_SRC) and os.path.exists(GN_SRC)):
         return available()   # GPU box: /root/reference is absent, the prebuilt files travelled with the snapshot
     t = targets()
-    newest_in = max(os.path.getmtime(p) for p in (KNN_SRC, MATCH_SRC, __file__, os.path.join(HERE, "include", "cuda_host_shim.h")))
+    newest_in = max(os.path.getmtime(p) for p in (KNN_SRC, MATCH_SRC, GN_SRC, __file__, os.path.join(HERE, "include", "cuda_host_shim.h"),
+                                                  os.path.join(HERE, "include", "eigen_host_shim.h")))
     if not force and available() and min(os.path.getmtime(p) for p in t.values()) >= newest_in:
         return True
     os.makedirs(GEN, exist_ok=True)
@@ -172,6 +212,16 @@ def build(force: bool = False) -> bool:
     cmd = common + ["-DTORCH_EXTENSION_NAME=ref_matching", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
     cmd += ["-isystem" + p for p in ce.include_paths()] + ["-isystem" + sysconfig.get_paths()["include"]]
     cmd += [os.path.join(GEN, "ref_matching_main.cpp"), "-o", t["matching"], "-L" + tlib, "-Wl,-rpath," + tlib,
+            "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
+    _run(cmd)
+
+    with open(os.path.join(GEN, "gn_kernels.gen.cpp"), "w") as f:
+        f.write(rewrite_launches(explicit_warp_steps(open(GN_SRC).read())))
+    with open(os.path.join(GEN, "ref_gn_main.cpp"), "w") as f:
+        f.write(GN_MAIN)
+    cmd = common + ["-DTORCH_EXTENSION_NAME=ref_gn", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += ["-isystem" + p for p in ce.include_paths()] + ["-isystem" + sysconfig.get_paths()["include"]]
+    cmd += [os.path.join(GEN, "ref_gn_main.cpp"), "-o", t["gn"], "-L" + tlib, "-Wl,-rpath," + tlib,
             "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
     _run(cmd)
     return True

@@ -50,11 +50,16 @@ inline unsigned max(int a, unsigned b) { return max((unsigned)a, b); }
 
 namespace shim {
 
+// A fiber is RUNNABLE, parked at the block barrier (__syncthreads) or parked at a warp barrier (__syncwarp: the explicit form of the
+// warp-synchronous lock step some reference kernels rely on implicitly -- gn_kernels.cu's warpReduce).  The block barrier opens when
+// every live fiber has reached it; a warp barrier opens when every live lane of that warp is parked (at either kind of barrier).
+enum FiberState : char { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WARP = 2, DONE = 3 };
+
 struct Fibers {
     static constexpr size_t STACK = 256 * 1024;
     std::vector<ucontext_t> ctx;
     std::vector<char> stacks;
-    std::vector<char> done;
+    std::vector<char> state;
     ucontext_t main;
     int cur = 0;
     void (*body)(void*) = nullptr;
@@ -64,11 +69,12 @@ static Fibers g_f;
 
 static void fiber_entry() {
     g_f.body(g_f.arg);
-    g_f.done[g_f.cur] = 1;
+    g_f.state[g_f.cur] = DONE;
     swapcontext(&g_f.ctx[g_f.cur], &g_f.main);
 }
 
-inline void syncthreads() { swapcontext(&g_f.ctx[g_f.cur], &g_f.main); }
+inline void syncthreads() { g_f.state[g_f.cur] = WAIT_BLOCK; swapcontext(&g_f.ctx[g_f.cur], &g_f.main); }
+inline void syncwarp() { g_f.state[g_f.cur] = WAIT_WARP; swapcontext(&g_f.ctx[g_f.cur], &g_f.main); }
 
 inline dim3 to_dim3(dim3 d) { return d; }
 inline dim3 to_dim3(long long n) { return dim3((unsigned)n); }
@@ -76,7 +82,7 @@ inline dim3 to_dim3(long long n) { return dim3((unsigned)n); }
 template <class F> static void launch(dim3 grid, dim3 block, F f) {
     const int nt = (int)(block.x * block.y * block.z);
     gridDim = grid; blockDim = block;
-    g_f.ctx.resize(nt); g_f.done.assign(nt, 0);
+    g_f.ctx.resize(nt); g_f.state.assign(nt, RUNNABLE);
     if (g_f.stacks.size() < (size_t)nt * Fibers::STACK) g_f.stacks.resize((size_t)nt * Fibers::STACK);
     g_f.body = [](void* p) { (*static_cast<F*>(p))(); };
     g_f.arg = &f;
@@ -88,24 +94,42 @@ template <class F> static void launch(dim3 grid, dim3 block, F f) {
             g_f.ctx[t].uc_stack.ss_size = Fibers::STACK;
             g_f.ctx[t].uc_link = nullptr;
             makecontext(&g_f.ctx[t], fiber_entry, 0);
-            g_f.done[t] = 0;
+            g_f.state[t] = RUNNABLE;
         }
-        int alive = nt;
-        while (alive > 0) {            // one round = every live thread runs to its next barrier (or to its end)
-            alive = 0;
-            for (int t = 0; t < nt; ++t) {
-                if (g_f.done[t]) continue;
+        for (;;) {
+            int live = 0;
+            for (int t = 0; t < nt; ++t) {     // every runnable thread runs to its next barrier (or to its end), in thread order
+                if (g_f.state[t] != RUNNABLE) { live += g_f.state[t] != DONE; continue; }
                 g_f.cur = t;
                 threadIdx = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
                 swapcontext(&g_f.main, &g_f.ctx[t]);
-                if (!g_f.done[t]) ++alive;
+                live += g_f.state[t] != DONE;
             }
+            if (live == 0) break;
+            bool opened = false;
+            for (int w0 = 0; w0 < nt; w0 += 32) {   // warp barriers
+                bool all_parked = true, any_warp = false;
+                for (int t = w0; t < std::min(nt, w0 + 32); ++t) {
+                    all_parked = all_parked && g_f.state[t] != RUNNABLE;
+                    any_warp = any_warp || g_f.state[t] == WAIT_WARP;
+                }
+                if (all_parked && any_warp) {
+                    for (int t = w0; t < std::min(nt, w0 + 32); ++t) if (g_f.state[t] == WAIT_WARP) g_f.state[t] = RUNNABLE;
+                    opened = true;
+                }
+            }
+            if (opened) continue;
+            bool all_block = true;                  // the block barrier: every live thread is there
+            for (int t = 0; t < nt; ++t) all_block = all_block && (g_f.state[t] == WAIT_BLOCK || g_f.state[t] == DONE);
+            if (!all_block) { std::fprintf(stderr, "cuda_host_shim: deadlock (threads parked at different barriers)\n"); std::abort(); }
+            for (int t = 0; t < nt; ++t) if (g_f.state[t] == WAIT_BLOCK) g_f.state[t] = RUNNABLE;
         }
     }
 }
 
 } // namespace shim
 
+#define __syncwarp() shim::syncwarp()
 #define __syncthreads() shim::syncthreads()
 
 // ---- the slice of the CUDA runtime / thrust / cub / cooperative-groups API the two files use ----

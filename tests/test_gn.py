@@ -70,6 +70,58 @@ def _factor_rows(kind, T, c, e, prm):
     return G._rows(kind, P, c["Xs"][0][ind].astype(np.float64), ind, valid, q, prm)
 
 
+# ------------------------------------------------------------------------------------------ pinned to the reference's own gn_kernels.cu
+def _ref_cases():
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden_gn_ref as M
+    return M, np.load(os.path.join(GOLDEN, "ref_gn.npz"))
+
+
+def _ref_prm(kind, g):
+    return _calib_prm(g) if kind == "calib" else dict(PRM)
+
+
+REF_CASES = ("points_a", "points_b", "rays_a", "rays_b", "calib_a")
+
+
+@pytest.mark.parametrize("name", REF_CASES)
+def test_oracle_matches_the_references_own_solver_on_multi_factor_graphs(name):
+    """tests/golden/ref_gn.npz = outputs of the REFERENCE's gn_kernels.cu compiled for the host (oracle/_ref/ref_gn.so,
+    make_golden_gn_ref.py): multi-factor graphs, all three factor kinds incl. `points`, outliers, non-contiguous keyframe ids.
+    The first Gauss-Newton step (every factor's blocks, their assembly, the fixed first pose, the solve, the retraction) and
+    the poses after the 10-iteration call of global_opt.py."""
+    M, d = _ref_cases()
+    kind, g, T0 = M.cases()[name]
+    assert float(d[name + "_in_sum"]) == float(g["Xs"].astype(np.float64).sum() + T0.astype(np.float64).sum())
+    prm = _ref_prm(kind, g)
+    T = T0.astype(np.float32).copy()
+    dx = G.gauss_newton(kind, T, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx"], g["valid"], g["Q"], prm, 1, 1e-8)
+    assert np.abs(dx - d[name + "_dx1"]).max() <= 2e-4 * np.abs(d[name + "_dx1"]).max(), np.abs(dx - d[name + "_dx1"]).max()
+    assert np.abs(T - d[name + "_T1"]).max() <= 2e-5
+    T = T0.astype(np.float32).copy()
+    dx = G.gauss_newton(kind, T, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx"], g["valid"], g["Q"], prm, 10, 1e-8)
+    assert np.abs(T - d[name + "_T10"]).max() <= 2e-5, np.abs(T - d[name + "_T10"]).max()
+    assert np.abs(dx - d[name + "_dx10"]).max() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REF_CASES)
+def test_hip_matches_the_references_own_solver_on_multi_factor_graphs(name, dev):
+    M, d = _ref_cases()
+    kind, g, T0 = M.cases()[name]
+    prm = _ref_prm(kind, g)
+    T1, (dx1,) = _run_hip(kind, T0.astype(np.float32).copy(), g, prm, dev, max_iter=1)
+    assert np.abs(dx1 - d[name + "_dx1"]).max() <= 2e-4 * np.abs(d[name + "_dx1"]).max(), np.abs(dx1 - d[name + "_dx1"]).max()
+    assert np.abs(T1 - d[name + "_T1"]).max() <= 2e-5
+    T10, (dx10,) = _run_hip(kind, T0.astype(np.float32).copy(), g, prm, dev, max_iter=10)
+    assert np.array_equal(T10[0], T0.astype(np.float32)[0])
+    assert np.abs(T10 - d[name + "_T10"]).max() <= 2e-5, np.abs(T10 - d[name + "_T10"]).max()
+    assert np.abs(dx10 - d[name + "_dx10"]).max() <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------ CPU: the oracle itself
 @pytest.mark.parametrize("kind", KINDS)
 def test_oracle_jacobians_match_finite_differences(kind):
