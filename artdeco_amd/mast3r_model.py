@@ -293,9 +293,14 @@ class DPTOutputAdapter(nn.Module):
         H, W = image_size
         nh, nw = H // self.P, W // self.P
         wd = self.head[0].weight.dtype
-        layers = [tokens[h].to(wd) for h in self.hooks]
+        # The hook tokens are the RAW residual stream of decoder levels 6 and 9 (un-normalised; real checkpoints carry outlier
+        # channels there): they are never narrowed.  The 1x1 convolution that reads them (act_postprocess[i][0], 1.7 GFLOP per
+        # head) stays in the tokens' precision -- to_inference_dtype leaves it fp32 -- and only ITS output enters the fp16 part.
+        layers = [tokens[h] for h in self.hooks]
         layers = [l.transpose(1, 2).reshape(l.shape[0], l.shape[2], nh, nw) for l in layers]
-        layers = [self.act_postprocess[i](l) for i, l in enumerate(layers)]
+        first = [self.act_postprocess[i][0] for i in range(len(layers))]
+        layers = [f(l.to(f.weight.dtype)).to(wd) for f, l in zip(first, layers)]
+        layers = [self.act_postprocess[i][1:](l) for i, l in enumerate(layers)]
         layers = [self.scratch.layer_rn[i](l) for i, l in enumerate(layers)]
         p4 = self.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]]
         p3 = self.scratch.refinenet3(p4, layers[2])
@@ -540,14 +545,27 @@ class AsymmetricMASt3R(nn.Module):
             # the reference's heads run "in fp32" (dust3r/model.py:205) -- under the same allow_tf32 setting, which applies to
             # their convolutions and Linear layers as well (cudnn.allow_tf32 defaults to True): the same operand narrowing
             for head in (self.downstream_head1, self.downstream_head2):
+                raw_readers = {id(seq[0]) for seq in head.dpt.act_postprocess}   # read the un-normalised residual stream: stay fp32
                 for m in head.modules():
-                    if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+                    if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)) and id(m) not in raw_readers:
                         m.to(dtype)
                 # the DPT adapter's inputs are token-major [B, N, C] activations viewed as [B, C, h, w], i.e. ALREADY channels-last
                 # in memory: with channels-last weights MIOpen picks NHWC kernels and the layout transposes around every
                 # convolution disappear (tracked frame 8.09 -> 7.71 ms)
                 head.dpt.to(memory_format=torch.channels_last)
         return self
+
+    @staticmethod
+    def outputs_finite(*results) -> torch.Tensor:
+        """0-dim bool tensor on the device (no host sync): every value of the given head outputs is finite.  The narrowed modes
+        keep fp16 GEMM outputs inside the trunk (|x| <= 65504); a caller that runs real checkpoints reads this flag once per
+        batch of frames and re-runs the offending frame with to_inference_dtype(torch.float32)."""
+        ok = None
+        for r in results:
+            for v in r.values():
+                f = torch.isfinite(v).all()
+                ok = f if ok is None else ok & f
+        return ok
 
     @torch.inference_mode()
     def forward(self, view1, view2):

@@ -64,7 +64,7 @@ def pair_match(net, img1, img2, autocast_dtype):
     return p1, valid
 
 
-def tracking_frame_match(net, img_f, kf_feat, kf_pos):
+def tracking_frame_match(net, img_f, kf_feat, kf_pos, with_heads=False):
     """What the frontend does per TRACKED frame: mast3r_match_asymmetric with the keyframe's embedding cached
     (VSLAM/CameraTracker.py:59-61 passes embeddings_j = self.last_embedding; utils_mast3r.py:116-141): ONE encode, the
     decoder, both heads, iter_proj + refine_matches."""
@@ -87,6 +87,8 @@ def tracking_frame_match(net, img_f, kf_feat, kf_pos):
         p_init = torch.stack((lin % w, lin // w), -1)[None].float().contiguous()
         p1, valid = msb.iter_proj(rays_g, pts, p_init, 10, 1e-8, 1e-6)
         (p1,) = msb.refine_matches(D11.half().contiguous(), D21.reshape(b, h * w, -1).half().contiguous(), p1.long(), 4, 5)
+    if with_heads:
+        return p1, valid, {"X11": X11, "X21": X21, "D11": D11, "D21": D21, "C11": r1["conf"], "C21": r2["conf"]}
     return p1, valid
 
 
@@ -123,16 +125,22 @@ def tracking_frame_bench(net, img_f, img_k, iters, use_graph=True):
                 tracking_frame_match(net, img_f, kf_feat, kf_pos)
             torch.cuda.current_stream().wait_stream(side)
             with torch.cuda.graph(graph):
-                captured = tracking_frame_match(net, img_f, kf_feat, kf_pos)
-            ref = tracking_frame_match(net, img_f, kf_feat, kf_pos)
-            ref2 = tracking_frame_match(net, img_f, kf_feat, kf_pos)
+                captured = tracking_frame_match(net, img_f, kf_feat, kf_pos, with_heads=True)
+            ref = tracking_frame_match(net, img_f, kf_feat, kf_pos, with_heads=True)
+            ref = (ref[0], ref[1], {k: v.clone() for k, v in ref[2].items()})
+            ref2 = tracking_frame_match(net, img_f, kf_feat, kf_pos, with_heads=True)
             graph.replay()
             torch.cuda.synchronize()
-            same = lambda a, b: float((a[0] == b[0]).all(-1).float().mean())
             dt = timed(graph.replay)
-            # random-init weights give near-random descriptors, so the match argmax amplifies the run-to-run rounding differences
-            # of hipBLASLt's split-K kernels: the replay must agree with eager as well as eager agrees with itself
-            out.update(ms_per_frame_graph=dt * 1e3, graph_matches_identical_to_eager=same(captured, ref), eager_matches_identical_to_eager=same(ref, ref2))
+            # Does the replayed graph compute what eager execution computes (two side streams, ~700 captured launches)?  Compared
+            # on the heads' OUTPUTS -- 3-D points, descriptors, confidences -- as max |replay - eager| / max |eager|, next to the
+            # same figure for eager vs eager (hipBLASLt's split-K kernels are not run-to-run deterministic).  (Round 2 compared the
+            # match indices: with random-init weights 74 % of the argmax matches flip between two eager runs, which hid nothing
+            # but would also have hidden a capture-ordering bug.)
+            dev_of = lambda a, b: max(float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max().clamp_min(1e-30)) for k in b)
+            out.update(ms_per_frame_graph=dt * 1e3, graph_vs_eager_max_rel=dev_of(captured[2], ref[2]), eager_vs_eager_max_rel=dev_of(ref2[2], ref[2]),
+                       graph_replay_matches_eager=bool(dev_of(captured[2], ref[2]) <= 1e-3),
+                       outputs_finite=bool(net.outputs_finite(captured[2])))
         except Exception as e:
             out["graph_error"] = repr(e)[:200]
     out.update(ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, launch="hipGraph replay" if "ms_per_frame_graph" in out else "eager")

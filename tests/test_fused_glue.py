@@ -25,16 +25,50 @@ def _grads(sc):
     return out
 
 
+def _capture_rasteriser_inputs(monkeypatch):
+    """Record the arguments of the UNFUSED path's gsplat.rendering.rasterization call (harness.mapper binds the drop-in)."""
+    import types
+    from harness import mapper
+    real = mapper.gsplat.rendering.rasterization
+    seen = []
+
+    def spy(**kw):
+        seen.append({k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
+        return real(**kw)
+    monkeypatch.setattr(mapper, "gsplat", types.SimpleNamespace(rendering=types.SimpleNamespace(rasterization=spy)))
+    return seen
+
+
+def _knife_pixels(args):
+    """Oracle-identified knife-edge pixels of one rasteriser call (oracle/gsplat_oracle.py extras["knife"]: a reached splat within
+    5e-4 relative of the alpha >= 1/255, alpha <= 0.999, sigma >= 0 or T (1 - alpha) <= 1e-4 decision): the only pixels on which two
+    evaluations whose inputs differ by an ulp may blend different splat sets."""
+    from oracle import gsplat_oracle as go
+    ex = {}
+    go.rasterization(args["means"], args["quats"], args["scales"], args["opacities"], args["colors"], args["viewmats"][0], args["Ks"][0],
+                     args["width"], args["height"], sh_degree=args["sh_degree"], eps2d=args["eps2d"], extras=ex)
+    return ex["knife"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("lod", [False, True])
-def test_fused_render_matches_unfused(lod, dev):
+def test_fused_render_matches_unfused(lod, dev, monkeypatch):
+    """North-star criterion, no outlier allowance: every pixel that the ORACLE does not place on a knife edge agrees to 1e-4 of the
+    largest value, and the gradients of a loss over exactly those pixels agree to rel_l2 1e-4 (knife-edge pixels leave the loss on
+    both sides, as in tests/test_raster.py: the two paths hand the rasteriser parameters that differ by an ulp, and only there
+    may a skip / clamp / terminate decision fall differently)."""
     from artdeco_amd import fused
     sc = _scene(dev, lod=lod)
     kf = sc.keyframes[0]
     V = kf.get_Rt().detach()
     bg = torch.tensor([0.3, 0.1, 0.7], device=dev)
-    w = torch.randn(3, sc.height, sc.width, device=dev)
-    wd = torch.randn(1, sc.height, sc.width, device=dev)
+    seen = _capture_rasteriser_inputs(monkeypatch)
+    with torch.no_grad():
+        sc.render(sc.width, sc.height, V, bg)
+    keep = (~_knife_pixels(seen[-1])).to(dev)
+    assert float(keep.float().mean()) > 0.9
+    w = torch.randn(3, sc.height, sc.width, device=dev) * keep
+    wd = torch.randn(1, sc.height, sc.width, device=dev) * keep
 
     def run():
         for v in sc.gaussian_params.values():
@@ -51,11 +85,12 @@ def test_fused_render_matches_unfused(lod, dev):
     assert torch.equal(pkg_f["visibility_filter"], pkg_u["visibility_filter"])
     assert torch.equal(pkg_f["global_visibility_filter"], pkg_u["global_visibility_filter"])
     err = (pkg_f["render"] - pkg_u["render"]).abs()
-    assert float((err <= 1e-4).float().mean()) >= 0.999 and float(err.max()) < 2e-2
+    assert float((err * keep).max()) <= 1e-4 * float(pkg_u["render"].abs().max())
+    assert float(err.max()) < 2e-2                      # a knife-edge pixel moves by at most one splat's contribution
     for k in g_u:
         a, b = g_f[k].double(), g_u[k].double()
         rel = float((a - b).norm() / (b.norm() + 1e-30))
-        assert rel <= 2e-3, (k, rel)
+        assert rel <= 1e-4, (k, rel)
 
 
 def _sync_state(src, dst):
@@ -81,7 +116,7 @@ def _sync_state(src, dst):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("reg", [0.0, 0.05])
-def test_fused_optimization_step_gradients_match_unfused(reg, dev):
+def test_fused_optimization_step_gradients_match_unfused(reg, dev, monkeypatch):
     """Full optimisation steps (render, loss, backward, pose Adam, sparse Adam) with and without the fused glue FROM THE SAME
     STATE: the loss and every GRADIENT agree at fp32 tolerance.  Gradients are compared before the optimiser touches
     them (Adam with eps = 1e-15 and no bias correction turns rounding noise into steps of ~5 lr, so parameters are the wrong
@@ -93,6 +128,7 @@ def test_fused_optimization_step_gradients_match_unfused(reg, dev):
     a, b = _scene(dev, N=8000, seed=3), _scene(dev, N=8000, seed=3)
     a.scaling_reg_factor = b.scaling_reg_factor = reg
     assert fused.patch_scene_model(b)
+    seen = _capture_rasteriser_inputs(monkeypatch)      # of the unfused scene `a` (the fused one calls the rasteriser directly)
     keys = ("xyz", "scaling", "rotation", "opacity", "local_feat", "global_feat")
     for i in range(3):
         _sync_state(a, b)
@@ -118,26 +154,23 @@ def test_fused_optimization_step_gradients_match_unfused(reg, dev):
         # hipBLASLt does not pick the same kernel for the unfused mlp_cov GEMM in every process: in roughly one process in ten a
         # pixel sits on the alpha >= 1/255 (or T <= 1e-4) decision of one splat, the two paths blend a different splat set there,
         # and every Gaussian behind it on that pixel sees a different transmittance (tools/lab/grad_noise.py: the difference then
-        # jumps to exactly 2.9e-5 or 4.0e-4 -- the same two values in every such run -- while scenes through the same path still
-        # repeat to 1e-7).  Such a step is recognised by what it looks like -- the BULK of the rows still agrees to 1e-5 (a wrong
-        # factor anywhere in the glue would move every row), a small set of rows carries the difference -- and is then held to
-        # 2e-3 instead of 2e-4.
+        # jumps to 2.9e-5 or 4.0e-4).  Whether THIS step is such a step is decided by the oracle, not by the size of the error:
+        # the pixels on which the two paths' rendered inverse depth disagrees must all be pixels the oracle places on a knife edge
+        # (extras["knife"], evaluated on the unfused path's own rasteriser inputs); only then -- a decision really fell
+        # differently, on a pixel where it may -- is the step held to 2e-3 instead of 2e-4.
         def rel_of(x, y):
             return float((x - y).norm() / (x.norm() + 1e-30))
 
-        def bulk_agrees(x, y):
-            x2, y2 = x.reshape(x.shape[0], -1), y.reshape(y.shape[0], -1)
-            rows = (x2 - y2).norm(dim=1) / (x2.norm(dim=1) + 1e-30)
-            live = x2.norm(dim=1) > 0
-            return float(rows[live].median()) <= 1e-5 and float((rows[live] > 1e-3).double().mean()) <= 0.05
-
+        inv_a, inv_b = a.keyframes[i % 2].latest_invdepth, b.keyframes[i % 2].latest_invdepth
+        da, db = torch.nan_to_num(1.0 / inv_a, posinf=0.0), torch.nan_to_num(1.0 / inv_b, posinf=0.0)
+        flipped = ((da - db).abs() > 1e-4 * float(da.abs().max()))[0]
+        knife = bool(flipped.any())
+        if knife:
+            on_edge = _knife_pixels(seen[-1]).to(dev)
+            assert bool((flipped & ~on_edge).sum() == 0), (i, "the two paths disagree on pixels that are not on a knife edge")
         per_gauss = {k: (grads["a"][k].double(), grads["b"][k].double()) for k in keys}
         per_gauss.update({k: (a.optimizer.params[k]["exp_avg"].double(), b.optimizer.params[k]["exp_avg"].double()) for k in ("f_dc", "f_rest")})
-        knife = any(rel_of(x, y) > 2e-4 for x, y in per_gauss.values())
-        tol = 2e-4
-        if knife:
-            assert all(bulk_agrees(x, y) for k, (x, y) in per_gauss.items() if k != "global_feat"), (i, "difference is not confined to a few rows")
-            tol = 2e-3
+        tol = 2e-3 if knife else 2e-4
         for k, (x, y) in per_gauss.items():
             assert rel_of(x, y) <= tol, (i, k, rel_of(x, y), knife)
         for k in ["mlp." + n for n, _ in a.mlp_cov.named_parameters()]:
