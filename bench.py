@@ -382,11 +382,11 @@ def frontend_summary(args, dev, cpu=True):
 
 
 def system_summary():
-    """Mapper and frontend as two processes on this one GPU (bench_system.py, 120 tracked frames): min of the two rates."""
+    """Mapper, frontend and backend as three processes on this one GPU (bench_system.py, 120 tracked frames): min of the three rates."""
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_system.py"), "--frames", "120", "--alone-seconds", "2"],
-                           capture_output=True, text=True, timeout=600)
+                           capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         return json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
     except Exception as e:

@@ -1,15 +1,20 @@
 #!/usr/bin/env python
-"""Mapper and frontend SHARING one MI355X -- the thing "on-the-fly frames/sec" actually is (BASELINE metric; run.sh:17-20 puts
---device_frontend, --device_backend and --device_mapper on the same GPU, run_system.py:99-110 starts them as separate processes).
+"""Mapper, frontend AND backend sharing one MI355X -- the thing "on-the-fly frames/sec" actually is (BASELINE metric; run.sh:17-20
+puts --device_frontend, --device_backend and --device_mapper on the same GPU, run_system.py:99-110 starts them as separate processes).
 
-Two processes on cuda:0, started together:
-  mapper    the bench.py step (1 M Gaussians, 512x384 -- the north-star target configuration -- fused glue), 10 optimisation
-            steps per frame (run.sh --num_common_iterations 10);
-  frontend  one tracked frame per iteration: 1 MASt3R ViT-L encode (keyframe embedding cached) + decoder + 2 heads + iter_proj +
-            refine_matches as one hipGraph replay, then the Sim(3) tracker (adk_track_frame), TF32-class precision
-            (bench_frontend.py --dtype tf32eq).
-Each is first timed ALONE (the other process idles at a barrier), then both run concurrently for the same number of frontend frames (default 300, BASELINE configs[1]);
-the system rate is min(frontend frames/s, mapper frames/s) under contention.  Prints one JSON line.
+Three processes on cuda:0, started together:
+  mapper    run_system.py's frame loop (harness/stream.py: Keyframe build, rigid_transform_gs on SLAM keyframes, add_keyframe,
+            add_new_gaussians on important frames, 20 / 10 optimisation steps) on 1 M Gaussians at 512x384 (the north-star
+            configuration), fused host paths; rate = frames / wall (the reference's FPS definition, h3dgsv3.py:1129-1132);
+  frontend  VSLAM/Frontend.py:55-124 per frame: one tracked frame = 1 MASt3R ViT-L encode (keyframe embedding cached) + decoder +
+            2 heads + iter_proj + refine_matches as one hipGraph replay, then the Sim(3) tracker (adk_track_frame), TF32-class;
+  backend   VSLAM/Backend.py:42-115 per frame with --use_all_frames: the SECOND mast3r_match_asymmetric of the frame against the last
+            keyframe (style 2, :99-115: the same tracked-frame graph) and, on SLAM keyframes (every --slam-every frames, style 1 ->
+            gloabla_optimization :196-265), a symmetric re-match (two more decoder + head passes) and gauss_newton_rays over the
+            keyframe graph (16 keyframes, 512x384 points per factor, 10 iterations).
+Each is first timed ALONE (the others idle at a barrier), then all run concurrently until the frontend has produced --frames frames;
+the system rate is the minimum of the three rates under contention.  `--cu-mask A B`: HSA_CU_MASK for the frontend / backend processes
+(e.g. "0:0-63"), the A/B of confining the two 768-token workloads to a slice of the chip.  Prints one JSON line.
 
     python bench_system.py [--frames 300] [--gaussians 1000000] [--width 512] [--height 384]
 """
@@ -25,45 +30,41 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.multiprocessing as mp
 
-STEPS_PER_FRAME = 10
-ROUNDS = ("mapper_alone", "frontend_alone", "together")
+ROUNDS = ("mapper_alone", "frontend_alone", "backend_alone", "together")
 
 
 def mapper_proc(args, barrier, stop, out_q):
+    import numpy as np
     import artdeco_amd
     artdeco_amd.install_dropins()
     from artdeco_amd import fused
-    from harness import mapper
+    from harness import mapper, stream
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=0, targets="render")
+    scene = mapper.build_synthetic_mapper(args.gaussians, args.width, args.height, dev, seed=0, n_keyframes=0, targets="random")
     fused.patch_scene_model(scene)
     fused.freeze_gc()
-    nkf = len(scene.keyframes)
-    for i in range(10):
-        scene.optimization_step(i % nkf)
-    torch.cuda.synchronize()
+    cadence = dict(kf_every=5, slam_every=args.slam_every, test_hold=8)
+    frames = stream.synthetic_frames(scene, 48, seed=0, texture=0.05)       # recycled: the loop only reads them
+    np.random.seed(0)
+    stream.warm_libraries(dev)
+    stream.run_stream(scene, frames[:8], start_index=0, **cadence)
+    idx = 8
     for phase in ROUNDS:
         barrier.wait()
-        if phase != "frontend_alone":
-            steps, t0 = 0, time.perf_counter()
+        if phase in ("mapper_alone", "together"):
+            n, t0 = 0, time.perf_counter()
             while (time.perf_counter() - t0 < args.alone_seconds) if phase == "mapper_alone" else (not stop.is_set()):
-                scene.optimization_step(steps % nkf)
-                steps += 1
-                if steps % 20 == 0:
-                    torch.cuda.synchronize()   # keep the launch queue bounded, as the real loop's per-frame host work does
-            torch.cuda.synchronize()
-            out_q.put(("mapper", phase, steps, time.perf_counter() - t0))
+                stream.run_stream(scene, [frames[idx % len(frames)]], start_index=idx, **cadence)   # synchronises once per frame
+                idx += 1
+                n += 1
+            out_q.put(("mapper", phase, n, time.perf_counter() - t0))
         barrier.wait()
 
 
-def frontend_proc(args, barrier, stop, out_q):
-    import artdeco_amd
-    artdeco_amd.install_dropins()
+def _frontend_graph(dev):
     import bench_frontend as BF
     from artdeco_amd.mast3r_model import vit_large
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
     torch.manual_seed(0)
     net = vit_large().to(dev).eval().to_inference_dtype(torch.float16, fp32_stream=True, heads=True)
     img_f = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
@@ -80,13 +81,25 @@ def frontend_proc(args, barrier, stop, out_q):
     torch.cuda.current_stream().wait_stream(side)
     with torch.cuda.graph(graph):
         BF.tracking_frame_match(net, img_f, kf_feat, kf_pos)
+    return net, graph, (img_f, kf_feat, kf_pos)
+
+
+def frontend_proc(args, barrier, stop, out_q):
+    if args.cu_mask and args.cu_mask[0] != "-":
+        os.environ["HSA_CU_MASK"] = args.cu_mask[0]
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    import bench_frontend as BF
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net, graph, _ = _frontend_graph(dev)
     track = BF.make_tracker_step(dev)
     for _ in range(3):
         graph.replay(); track()
     torch.cuda.synchronize()
     for phase in ROUNDS:
         barrier.wait()
-        if phase != "mapper_alone":
+        if phase in ("frontend_alone", "together"):
             n = args.frames if phase == "together" else max(args.frames // 3, 50)
             t0 = time.perf_counter()
             for _ in range(n):
@@ -100,6 +113,50 @@ def frontend_proc(args, barrier, stop, out_q):
         barrier.wait()
 
 
+def backend_proc(args, barrier, stop, out_q):
+    if args.cu_mask and args.cu_mask[1] != "-":
+        os.environ["HSA_CU_MASK"] = args.cu_mask[1]
+    import numpy as np
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    import bench_frontend as BF
+    import mast3r_slam_backends as B
+    from artdeco_amd import synthetic as S
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    net, graph, (img_f, kf_feat, kf_pos) = _frontend_graph(dev)
+    g = S.keyframe_graph(num_poses=16, n=512 * 384, seed=0, extra_edges=12, coherent=True)
+    T0 = S.perturb_poses(g["T_gt"], np.random.default_rng(1), 0.01)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Xs, Cs, ii, jj, idx, valid, Q = t(g["Xs"]), t(g["Cs"]), t(g["ii"]), t(g["jj"]), t(g["idx"]), t(g["valid"]), t(g["Q"])
+    T0d = t(T0)
+
+    def slam_keyframe():
+        # gloabla_optimization: symmetric re-match against the previous keyframe (both embeddings cached: two decoder + head +
+        # matching passes), then the global Gauss-Newton over the keyframe graph
+        with torch.inference_mode():
+            for _ in range(2):
+                BF.tracking_frame_match(net, img_f, kf_feat, kf_pos)
+        B.gauss_newton_rays(T0d.clone(), Xs, Cs, ii, jj, idx, valid, Q, 0.003, 10.0, 0.0, 1.5, 10, 1e-8)
+
+    for _ in range(2):
+        graph.replay(); slam_keyframe()
+    torch.cuda.synchronize()
+    for phase in ROUNDS:
+        barrier.wait()
+        if phase in ("backend_alone", "together"):
+            n, t0 = 0, time.perf_counter()
+            limit = max(args.frames // 3, 50)
+            while (n < limit) if phase == "backend_alone" else (not stop.is_set()):
+                graph.replay()                                   # style 2: the frame's second asymmetric match
+                if n % args.slam_every == 0:
+                    slam_keyframe()                              # style 1
+                torch.cuda.synchronize()                         # the result goes to the mapper through a host queue (Backend.py:147)
+                n += 1
+            out_q.put(("backend", phase, n, time.perf_counter() - t0))
+        barrier.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=300)
@@ -107,35 +164,37 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--alone-seconds", type=float, default=3.0)
+    ap.add_argument("--slam-every", type=int, default=15)
+    ap.add_argument("--cu-mask", nargs=2, default=None, metavar=("FRONTEND", "BACKEND"),
+                    help='HSA_CU_MASK for the frontend and backend processes, e.g. "0:0-63" "0:64-127"; "-" leaves one unmasked')
     args = ap.parse_args()
     ctx = mp.get_context("spawn")
-    barrier, stop, q = ctx.Barrier(3), ctx.Event(), ctx.Queue()
-    procs = [ctx.Process(target=mapper_proc, args=(args, barrier, stop, q)), ctx.Process(target=frontend_proc, args=(args, barrier, stop, q))]
+    barrier, stop, q = ctx.Barrier(4), ctx.Event(), ctx.Queue()
+    procs = [ctx.Process(target=f, args=(args, barrier, stop, q)) for f in (mapper_proc, frontend_proc, backend_proc)]
     for p in procs:
         p.start()
     res = {}
     for phase in ROUNDS:
         barrier.wait()
-        for _ in range(2 if phase == "together" else 1):
-            who, ph, n, dt = q.get(timeout=1200)
+        for _ in range(3 if phase == "together" else 1):
+            who, ph, n, dt = q.get(timeout=1800)
             res[(who, ph)] = (n, dt)
         barrier.wait()
     for p in procs:
         p.join(timeout=120)
-    m_n, m_dt = res[("mapper", "together")]
-    f_n, f_dt = res[("frontend", "together")]
-    mapper_fps = m_n / STEPS_PER_FRAME / m_dt
-    frontend_fps = f_n / f_dt
-    out = {"metric": "on-the-fly frames/sec with mapper and frontend sharing one MI355X (min of the two rates under contention)",
-           "value": min(mapper_fps, frontend_fps), "unit": "frames/s", "n_gpus": 1, "data": "synthetic, random-init MASt3R weights",
-           "config": {"workload": f"{args.frames} tracked frames; mapper {args.gaussians} Gaussians {args.width}x{args.height}, {STEPS_PER_FRAME} steps/frame; "
-                                  "frontend MASt3R ViT-L 512x384 tracked frame (TF32-class) + Sim(3) tracker; two processes, same device"},
-           "together": {"mapper_frames_per_s": mapper_fps, "mapper_ms_per_step": m_dt / m_n * 1e3, "frontend_frames_per_s": frontend_fps,
-                        "frontend_ms_per_frame": f_dt / f_n * 1e3},
-           "alone": {"mapper_frames_per_s": res[("mapper", "mapper_alone")][0] / STEPS_PER_FRAME / res[("mapper", "mapper_alone")][1],
-                     "frontend_frames_per_s": res[("frontend", "frontend_alone")][0] / res[("frontend", "frontend_alone")][1]}}
-    out["slowdown_under_contention"] = {"mapper": out["alone"]["mapper_frames_per_s"] / mapper_fps,
-                                        "frontend": out["alone"]["frontend_frames_per_s"] / frontend_fps}
+    rate = lambda who, ph: res[(who, ph)][0] / res[(who, ph)][1]
+    tog = {w: rate(w, "together") for w in ("mapper", "frontend", "backend")}
+    alone = {w: rate(w, w + "_alone") for w in ("mapper", "frontend", "backend")}
+    out = {"metric": "on-the-fly frames/sec with mapper, frontend and backend sharing one MI355X (min of the three rates under contention)",
+           "value": min(tog.values()), "unit": "frames/s", "n_gpus": 1, "data": "synthetic, random-init MASt3R weights",
+           "config": {"workload": f"{args.frames} tracked frames; mapper: run_system.py's frame loop on {args.gaussians} Gaussians {args.width}x{args.height} "
+                                  f"(20 / 10 iterations, add_new_gaussians on important frames); frontend: MASt3R ViT-L 512x384 tracked frame (TF32-class) + "
+                                  f"Sim(3) tracker; backend: the frame's second asymmetric match + on every {args.slam_every}th frame a symmetric re-match and "
+                                  "gauss_newton_rays over a 16-keyframe graph; three processes, same device",
+                      "cu_mask": args.cu_mask},
+           "together_frames_per_s": tog, "alone_frames_per_s": alone,
+           "slowdown_under_contention": {w: alone[w] / tog[w] for w in tog},
+           "together_ms_per_frame": {w: 1e3 / v for w, v in tog.items()}}
     print(json.dumps(out))
 
 
