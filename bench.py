@@ -80,6 +80,21 @@ def self_launch(args):
     os.execve(sys.executable, cmd, env)
 
 
+def pin_rank_cpus(local_rank, local_world):
+    """One scene per GPU means one Python host loop per GPU (plus, in the full system, a frontend and a backend process each): give
+    every rank its own equal share of the node's cores so that eight host loops do not migrate over each other (the
+    host, not xGMI, is the scaling risk).  A no-op for a single rank or where the affinity call is unavailable."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per >= 1:
+            os.sched_setaffinity(0, cpus[local_rank * per:(local_rank + 1) * per])
+    except OSError:
+        pass
+
+
 def cpu_dry_run(args, rank, world):
     """The N > 1 control path on CPU (gloo): rendezvous, barrier, K timed `steps`, MAX / SUM all-reduce, one JSON line."""
     from artdeco_amd import multigpu
@@ -170,6 +185,7 @@ def main():
     if args.cpu_dry_run:
         return cpu_dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from artdeco_amd import _lib, multigpu, rasterizer
@@ -442,7 +458,9 @@ def extra_configs(args, dev):
     from harness import mapper
     res = {}
     # name, N, map W, map H, fused, lod, pyr_levels, stream?
-    cases = [("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True, False, 1, True),
+    cases = [(f"headline cloud in RASTER order (the order add_new_gaussians appends in; SURVEY 8d's cloud is in random order): {args.gaussians} Gaussians "
+              f"{args.width}x{args.height}, optimisation step only", args.gaussians, args.width, args.height, True, "raster", 1, False),
+             ("configs[1] 200k Gaussians 512x384", 200_000, 512, 384, True, False, 1, True),
              ("north-star target 1M Gaussians 512x384", 1_000_000, 512, 384, True, False, 1, True),
              ("run.sh geometry: 1M Gaussians, map 1296x972, --pyr_levels 2 (training renders 648x486, densification renders 1296x972)",
               1_000_000, 1296, 972, True, False, 2, True),
@@ -455,7 +473,9 @@ def extra_configs(args, dev):
     for name, n, w, h, use_fused, lod, pyr, do_stream in cases:
         try:
             tw, th = w >> (pyr - 1), h >> (pyr - 1)
-            scene = mapper.build_synthetic_mapper(n, tw, th, dev, seed=0, targets="render", lod=lod)
+            raster = lod == "raster"
+            lod = bool(lod) and not raster
+            scene = mapper.build_synthetic_mapper(n, tw, th, dev, seed=0, targets="render", lod=lod, order="raster" if raster else "random")
             if use_fused:
                 fused.patch_scene_model(scene)
             dt = _time_steps(scene)

@@ -707,7 +707,7 @@ def synthetic_cloud(N, width, height, seed=0, sh_k=16, z_range=(2.0, 6.0), sigma
     return dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, fx=fx)
 
 
-def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random", lod=False):
+def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random", lod=False, order="random"):
     """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height).
     targets: "random" = uniform-noise keyframe images (every parameter gets a large gradient: what the parity tests
     want); "render" = each keyframe observes the cloud itself (its own render and inverse depth), i.e. a converged map,
@@ -720,6 +720,16 @@ def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targ
     `dist < 2 d_max` and is culled, another ~25 % is faded by the alpha ratio (h3dgsv3.py:628-639); with lod=False d_max is
     1e3 and the LoD logic never triggers (the SURVEY 8(d) statistics, used for the headline)."""
     c = synthetic_cloud(N, width, height, seed)
+    if order == "raster":
+        # the order add_new_gaussians appends in: image raster order of the creating view (boolean-mask indexing of the pixel grid,
+        # h3dgsv3.py:800).  SURVEY 8(d)'s cloud is in RANDOM order, the worst case for every kernel that scatters by screen position.
+        m, fx_ = c["means"], c["fx"]
+        px = (fx_ * m[:, 0] / m[:, 2] + width / 2).clamp(0, width - 1).long()
+        py = (fx_ * m[:, 1] / m[:, 2] + height / 2).clamp(0, height - 1).long()
+        perm = torch.argsort(py * width + px)
+        c = {k: (v[perm] if torch.is_tensor(v) else v) for k, v in c.items()}
+    elif order != "random":
+        raise ValueError("order must be 'random' or 'raster'")
     torch.manual_seed(seed)  # nn.Linear's default init draws from the global generator
     scene = MapperScene(width, height, c["fx"], device)
     # Features start at zero (h3dgsv3.py:873-877), so mlp_cov initially outputs its last bias.

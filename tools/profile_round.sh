@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 12 --warmup 4 --no-extra-configs --no-cpu-baseline --no-frontend"
+BENCH="python $ROOT/bench.py --steps 12 --warmup 6 --no-extra-configs --no-cpu-baseline --no-frontend"   # 12 mapped FRAMES (~160 optimisation steps)
 python "$ROOT/bench.py" > "$OUT/${TAG}_bench_full.json" 2> "$OUT/${TAG}_bench_full.err"
 rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o b -- $BENCH > /tmp/pk.log 2>&1
 cp /tmp/pk/b_kernel_stats.csv "$OUT/${TAG}_step_kernel_stats.csv"
