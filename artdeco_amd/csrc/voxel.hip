@@ -53,11 +53,15 @@ __global__ __launch_bounds__(256) void vox_min_kernel(const float* __restrict__ 
         for (int c = 0; c < 3; ++c) k[c] = min(k[c], (uint32_t)__shfl_xor((int)k[c], o, 64));
         mc = max(mc, (long long)__shfl_xor(mc, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) atomicMin(bounds + c, k[c]);
-        if (N > 0) atomicMax(max_cls, mc);
-    }
+    // one set of same-address device atomics per WORKGROUP, not per wave (8192 waves x 4 atomics on 4 addresses took 0.38 ms of
+    // the 1.1 ms call, profiles/r03_step_kernel_stats.csv)
+    __shared__ uint32_t sk[4][3];
+    __shared__ long long smc[4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sk[wv][0] = k[0]; sk[wv][1] = k[1]; sk[wv][2] = k[2]; smc[wv] = mc; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(bounds + threadIdx.x, min(min(sk[0][threadIdx.x], sk[1][threadIdx.x]), min(sk[2][threadIdx.x], sk[3][threadIdx.x])));
+    if (threadIdx.x == 3 && N > 0) atomicMax(max_cls, max(max(smc[0], smc[1]), max(smc[2], smc[3])));
 }
 
 // `vs` is the divisor when recip == 0 (torch's CPU kernel for tensor / python-float: a true division -- what the goldens of
@@ -82,9 +86,11 @@ __global__ __launch_bounds__(256) void vox_imax_kernel(const float* __restrict__
     for (int o = 32; o >= 1; o >>= 1)
 #pragma unroll
         for (int c = 0; c < 3; ++c) m[c] = max(m[c], (unsigned long long)__shfl_xor((long long)m[c], o, 64));
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) atomicMax(imax + c, m[c]);
+    __shared__ unsigned long long sm[4][3];   // one set of atomics per workgroup (see vox_min_kernel)
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[wv][0] = m[0]; sm[wv][1] = m[1]; sm[wv][2] = m[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMax(imax + threadIdx.x, max(max(sm[0][threadIdx.x], sm[1][threadIdx.x]), max(sm[2][threadIdx.x], sm[3][threadIdx.x])));
 }
 
 __global__ void vox_finish_bounds_kernel(const uint32_t* bounds, const unsigned long long* imax, const long long* max_cls, int64_t N,
@@ -315,7 +321,8 @@ extern "C" int adk_voxel_bounds(const float* xyz, int64_t N, const float* new_xy
     uint32_t* bounds = (uint32_t*)workspace;
     unsigned long long* imax = (unsigned long long*)((char*)workspace + 16);
     long long* max_cls = (long long*)((char*)workspace + 48);
-    const int g = adk::stream_grid(N + M, 256);
+    int g = adk::stream_grid(N + M, 256);
+    if (g > 512) g = 512;   // 2 workgroups per CU read 12 MB in a few microseconds; the tail of the kernel is its same-address atomics
     hipLaunchKernelGGL(adk::vox_init_kernel, dim3(1), dim3(64), 0, stream, bounds, imax, max_cls);
     hipLaunchKernelGGL(adk::vox_min_kernel, dim3(g), dim3(256), 0, stream, xyz, N, new_xyz, M, cls_id, bounds, max_cls);
     hipLaunchKernelGGL(adk::vox_imax_kernel, dim3(g), dim3(256), 0, stream, xyz, N, new_xyz, M, vs_arg, use_reciprocal, bounds, imax);

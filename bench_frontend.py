@@ -139,7 +139,9 @@ def tracking_frame_bench(net, img_f, img_k, iters, use_graph=True):
             # but would also have hidden a capture-ordering bug.)
             dev_of = lambda a, b: max(float((a[k].float() - b[k].float()).abs().max() / b[k].float().abs().max().clamp_min(1e-30)) for k in b)
             out.update(ms_per_frame_graph=dt * 1e3, graph_vs_eager_max_rel=dev_of(captured[2], ref[2]), eager_vs_eager_max_rel=dev_of(ref2[2], ref[2]),
-                       graph_replay_matches_eager=bool(dev_of(captured[2], ref[2]) <= 1e-3),
+                       # two EAGER runs already differ by ~1e-3 of the largest value (split-K reductions in a different order, amplified by
+                       # the exp() of the heads on random-init weights); a capture-ordering bug would show as O(1)
+                       graph_replay_matches_eager=bool(dev_of(captured[2], ref[2]) <= max(3e-3, 3.0 * dev_of(ref2[2], ref[2]))),
                        outputs_finite=bool(net.outputs_finite(captured[2])))
         except Exception as e:
             out["graph_error"] = repr(e)[:200]
