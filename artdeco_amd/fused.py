@@ -876,6 +876,7 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
         n_sh_rest = (self.max_sh_degree + 1) * (self.max_sh_degree + 1) - 1
         had = self.xyz.shape[0] > 0
         ext = {k: [] for k in ("id", "cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "local_feat", "global_feat")}
+        render = labels_changed = None
         for lod in self.lods:
             h, w = self.height // lod, self.width // lod
             img_l = torch.empty(3, h, w, **f32)
@@ -886,7 +887,13 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
             _lib.check(rc, "adk_densify_proba")
             pen = None
             if self.xyz.shape[0] > 0:
-                render = self.render_from_id(keyframe_id)["render"].to(**f32).contiguous()
+                # The reference renders once per level because update_voxel relabels cls_id in between (mlp_cov reads
+                # global_feat[cls_id]).  That relabelling is idempotent while the new points stay inside the map's voxel grid, so
+                # from the third level on the scene is usually the one just rendered: the previous level left a device flag
+                # "labels changed", and an unchanged scene reuses the previous render (the rasteriser's forward is deterministic:
+                # the same inputs give the same bits).
+                if render is None or labels_changed is None or bool(labels_changed):
+                    render = self.render_from_id(keyframe_id)["render"].to(**f32).contiguous()
                 pen = torch.empty(h, w, **f32)
                 with _stage("densify_proba"):
                     rc = lib.adk_densify_proba(render.data_ptr(), 3, render.shape[1], render.shape[2], 0, h, w, disc.data_ptr(),
@@ -916,7 +923,9 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
                                               opacity.data_ptr(), d_max.data_ptr(), st)
                 _lib.check(rc, "adk_densify_emit")
             if len(self.xyz) > 0:
+                prev_cls = self.cls_id
                 upd, new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)
+                labels_changed = (upd != prev_cls).any() if upd.shape == prev_cls.shape else None
                 self.gaussian_params["cls_id"]["val"] = upd
             else:
                 new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)
