@@ -10,8 +10,8 @@ JUST the hot-path operator interface with the same names, argument meaning and c
   SparseGaussianAdam.step(vis, N, gvis, Ng) / BaseAdam    <- scene/optimizers.py:17-161
   Keyframe (6D pose + t + 3x4 exposure, own BaseAdam)     <- scene/keyframe.py:103-125, 150-155, 186-191
   StreamKeyframe (pyramids from image + point map + conf)  <- scene/keyframe.py:26-126 (what run_system.py:177-192 constructs)
-  MapperScene.add_keyframe / add_new_gaussians /
-      update_voxel / rigid_transform_gs                    <- h3dgsv3.py:981-1009, 766-940, 227-316, 956-966
+  MapperScene.add_keyframe / rigid_transform_gs            <- h3dgsv3.py:981-1009, 956-966
+  MapperScene.add_new_gaussians / update_voxel             <- h3dgsv3.py:766-940, 227-316 (harness/densify_mirror.py)
 
 Every native call goes through the drop-in modules exactly as the reference's imports do
 (`gsplat.rendering.rasterization`, `fused_ssim`, `diff_gaussian_rasterization.adamUpdate*`), so what
@@ -63,8 +63,6 @@ class BaseAdam:
 
 
 _NO_OPT = ("id", "cls_id", "d_max")
-import contextlib as _contextlib  # noqa: E402
-_NULL_CTX = _contextlib.nullcontext()
 
 
 def _add_and_prune(self, extension_tensors, valid_mask):
@@ -244,42 +242,6 @@ class StreamKeyframe(Keyframe):
         self.rW2C.data.copy_(Rt[:3, :2])
         self.tW2C.data.copy_(Rt[:3, 3])
         self.approx_centre = -Rt[:3, :3].T @ Rt[:3, 3]
-
-
-# Reconstruct/utils.py:93-108, 121-131, 188-216 -- the image-space helpers of add_new_gaussians
-C0 = 0.28209479177387814
-
-
-def get_lapla_norm(img, kernel, device="cuda:0"):
-    laplacian_kernel = torch.tensor([[0, 1, 0], [1, -4, 1], [0, 1, 0]], device=device, dtype=torch.float32).unsqueeze(0).unsqueeze(0)
-    laplacian_kernel = laplacian_kernel.repeat(1, img.shape[0], 1, 1)
-    laplacian = F.conv2d(img[None], laplacian_kernel, padding="same")
-    laplacian_norm = torch.linalg.vector_norm(laplacian, ord=1, dim=1, keepdim=True)
-    laplacian_norm[..., :, 0] = 0
-    laplacian_norm[..., :, -1] = 0
-    laplacian_norm[..., 0, :] = 0
-    laplacian_norm[..., -1, :] = 0
-    return F.conv2d(laplacian_norm, kernel, padding="same")[0, 0].clamp(0, 1)
-
-
-def RGB2SH(rgb):
-    return (rgb - 0.5) / C0
-
-
-def inverse_sigmoid(x):
-    return torch.log(x / (1 - x))
-
-
-def depth2points(uv, depth, f, centre):
-    xyz = torch.cat([(uv[..., :2] - centre) / f, torch.ones_like(uv[..., 0:1])], dim=-1)
-    return depth * xyz
-
-
-def sample(map, uv, width, height):
-    sampler = uv.clone()
-    sampler[..., 0] = sampler[..., 0] * (2.0 / (width - 1)) - 1.0
-    sampler[..., 1] = sampler[..., 1] * (2.0 / (height - 1)) - 1.0
-    return F.grid_sample(map, sampler, mode="bilinear", align_corners=True)
 
 
 def quaternion_to_rotation_matrix(q):
@@ -520,123 +482,15 @@ class MapperScene:
         weed_mask = visible_count > self.visible_threshold
         self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
 
-    # -- update_voxel: h3dgsv3.py:227-316 (torch.unique x3, scatter_max, searchsorted, boolean-mask writes) -----------------
+    # -- densification (harness/densify_mirror.py): update_voxel h3dgsv3.py:227-316, add_new_gaussians :766-940 ------------------
     def update_voxel(self, new_xyz, xyz, cls_id, voxel_size=0.1):
-        device = new_xyz.device
-        num_new, num_orig = new_xyz.shape[0], xyz.shape[0]
-        if num_orig == 0:
-            v_min = new_xyz.min(dim=0).values
-            v_idx = torch.floor((new_xyz - v_min) / voxel_size).long()
-            v_max = v_idx.max(dim=0).values + 1
-            stride = torch.tensor([v_max[1] * v_max[2], v_max[2], 1], device=device)
-            h_new = (v_idx * stride).sum(dim=1)
-            u_hashes, u_inv = torch.unique(h_new, return_inverse=True)
-            return u_inv.unsqueeze(-1), u_hashes.shape[0]
-        cls_id_1d = cls_id.squeeze(-1)
-        max_cls = cls_id_1d.max().item()
-        all_p = torch.cat([xyz, new_xyz], dim=0)
-        min_c = all_p.min(dim=0).values
-        v_idx_all = torch.floor((all_p - min_c) / voxel_size).long()
-        v_max = v_idx_all.max(dim=0).values + 1
-        stride = torch.tensor([v_max[1] * v_max[2], v_max[2], 1], device=device)
-        h_all = (v_idx_all * stride).sum(dim=1)
-        h_orig, h_new = h_all[:num_orig], h_all[num_orig:]
-        unique_voxels, inv_idx = torch.unique(h_orig, return_inverse=True)
-        offset = max_cls + 1
-        pair_id = inv_idx * offset + cls_id_1d
-        pair_unique_ids, pair_counts = torch.unique(pair_id, return_counts=True)
-        v_indices_in_pair = pair_unique_ids // offset
-        c_labels_in_pair = pair_unique_ids % offset
-        _, max_indices = scatter_max(pair_counts, v_indices_in_pair)
-        voxel_mode_labels = c_labels_in_pair[max_indices]
-        updated_orig_cls_id = voxel_mode_labels[inv_idx].unsqueeze(-1)
-        pos = torch.searchsorted(unique_voxels, h_new)
-        pos_clamped = pos.clamp(max=unique_voxels.shape[0] - 1)
-        mask = unique_voxels[pos_clamped] == h_new
-        updated_new_cls_id = torch.zeros(num_new, dtype=torch.long, device=device)
-        if mask.any():
-            updated_new_cls_id[mask] = voxel_mode_labels[pos_clamped[mask]]
-        new_voxel_count = 0
-        if (~mask).any():
-            u_new_h, u_new_inv = torch.unique(h_new[~mask], return_inverse=True)
-            new_voxel_count = u_new_h.shape[0]
-            updated_new_cls_id[~mask] = u_new_inv + max_cls + 1
-        return updated_orig_cls_id, updated_new_cls_id.unsqueeze(-1), new_voxel_count
+        from harness import densify_mirror
+        return densify_mirror.voxel_labels(new_xyz, xyz, cls_id, voxel_size, scatter_max)
 
-    # -- add_new_gaussians: h3dgsv3.py:766-940, same operations in the same order ---------------------------------------------
     @torch.no_grad()
     def add_new_gaussians(self, keyframe_id=-1):
-        keyframe = self.keyframes[keyframe_id]
-        if keyframe.is_test:
-            return
-        dev = self.device
-        org_img = F.avg_pool2d(keyframe.image_pyr[0], 2)
-        extension_tensors = dict()
-        for lod in self.lods:
-            cur_h, cur_w = self.height // lod, self.width // lod
-            img = F.interpolate(org_img[None], (cur_h, cur_w), mode="bilinear", align_corners=True)[0]
-            init_proba = get_lapla_norm(img, self.disc_kernel, device=dev)
-            penalty = 0
-            if self.xyz.shape[0] > 0:
-                render_pkg = self.render_from_id(keyframe_id)
-                render = F.interpolate(render_pkg["render"][None], (cur_h, cur_w), mode="bilinear", align_corners=True)[0]
-                # (h3dgsv3.py:790 also resizes the inverse depth into `rendered_depth`, which nothing reads afterwards)
-                _ = 1 / F.interpolate(render_pkg["invdepth"][None], (cur_h, cur_w), mode="bilinear", align_corners=True)[0][0].clamp_min(1e-8)
-                penalty = get_lapla_norm(render, self.disc_kernel, device=dev)
-            init_proba *= self.init_proba_scaler
-            penalty *= self.init_proba_scaler
-            sample_mask = torch.rand_like(init_proba) < (init_proba - penalty) * self.gs_add_ratio
-            sampled_uv = self.uvs[lod][sample_mask]
-            sampled_depths = sample(keyframe.point_map[:, 2:], sampled_uv[None, None, ...], keyframe.width // lod, keyframe.height // lod)[0, 0, 0]
-            sampled_conf = sample(keyframe.mono_depth_conf, sampled_uv[None, None, ...], keyframe.width // lod, keyframe.height // lod)[0, 0, 0]
-            quantile_depth_min = min(1e-2, torch.quantile(keyframe.point_map[:, 2], 0.02).item())
-            valid_mask = (sampled_conf >= 0) * (sampled_depths > quantile_depth_min)
-            sample_mask[sample_mask.clone()] = valid_mask
-            sampled_uv = sampled_uv[valid_mask]
-            sampled_depths = sampled_depths[valid_mask]
-            sampled_conf = sampled_conf[valid_mask]
-            f = self.f / lod
-            centre = self.centre / lod
-            sampled_points = depth2points(sampled_uv, sampled_depths.unsqueeze(-1), f, centre)
-            sampled_points = (sampled_points - keyframe.get_t()) @ keyframe.get_R()
-            f_dc = RGB2SH(img[:, sample_mask].permute(1, 0).unsqueeze(1))
-            sampled_init_proba = init_proba[sample_mask]
-            scales = 1 / (torch.sqrt(sampled_init_proba))
-            scales.clamp_(1, self.width / 10)
-            scales.mul_(1 / self.f)
-            scales *= torch.linalg.vector_norm(sampled_points - keyframe.approx_centre[None], dim=-1)
-            scales = torch.log(lod * scales.clamp(1e-6, 1e6)).unsqueeze(-1).repeat(1, 3)
-            opacities = torch.ones(f_dc.shape[0], 1, device=dev)
-            opacities[: sampled_uv.shape[0]] *= 0.2 * sampled_conf[..., None]
-            opacities = inverse_sigmoid(opacities)
-            f_rest = torch.zeros(f_dc.shape[0], (self.max_sh_degree + 1) * (self.max_sh_degree + 1) - 1, 3, device=dev)
-            local_feats = torch.zeros((f_dc.shape[0], self.local_feat_dim), device=dev).float()
-            if len(self.xyz) > 0:
-                update_cls_ids, new_cls_ids, new_voxel_count = self.update_voxel(sampled_points, self.xyz, self.cls_id, self.voxel_size)
-                self.gaussian_params["cls_id"]["val"] = update_cls_ids
-            else:
-                new_cls_ids, new_voxel_count = self.update_voxel(sampled_points, self.xyz, self.cls_id, self.voxel_size)
-            global_feats = torch.zeros((new_voxel_count, self.global_feat_dim), device=dev)
-            rotation = torch.zeros((f_dc.shape[0], 4), device=dev)
-            rotation[:, 0] = 1
-            d_maxs = (sampled_depths.unsqueeze(-1) * lod).to(dev)
-            if self.xyz.shape[0] > 0:
-                valid_gs_mask = self.opacity[:, 0] > 0.05
-                dist = torch.linalg.vector_norm(self.xyz - keyframe.approx_centre[None], dim=-1)
-                screen_size = self.f * self.scaling.max(dim=-1)[0] / dist
-                valid_gs_mask *= screen_size < 0.5 * self.width
-            else:
-                valid_gs_mask = torch.ones(0, device=dev, dtype=torch.bool)
-            keyframe_id = len(self.keyframes) - 1 if keyframe_id == -1 else keyframe_id
-            extension_tensors[lod] = {
-                "id": torch.full((len(sampled_points), 1), keyframe_id, device=dev, dtype=torch.long), "cls_id": new_cls_ids,
-                "d_max": d_maxs, "xyz": sampled_points, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacities, "scaling": scales,
-                "rotation": rotation, "local_feat": local_feats, "global_feat": global_feats}
-        all_ext_tensors = {k: torch.concat([extension_tensors[lod][k] for lod in self.lods], dim=0) for k in extension_tensors[self.lods[0]]}
-        lock = getattr(self, "lock", None)
-        with (lock if lock is not None else _NULL_CTX):
-            self.optimizer.add_and_prune(all_ext_tensors, valid_gs_mask)
-        self.weed_out_gaussians()
+        from harness import densify_mirror
+        return densify_mirror.densify_from_keyframe(self, keyframe_id)
 
     # -- rigid_transform_gs: h3dgsv3.py:956-966 ---------------------------------------------------------------------------------
     @torch.no_grad()
