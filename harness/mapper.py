@@ -189,47 +189,47 @@ class Keyframe:
         self.depth_loss_weight *= self.depth_loss_weight_decay
 
 
+def _pyramid(base, levels):
+    out = [base]
+    for _ in range(levels - 1):
+        out.append(F.avg_pool2d(out[-1], 2))
+    return out
+
+
 class StreamKeyframe(Keyframe):
-    """scene/keyframe.py:26-126: the keyframe run_system.py:177-192 builds for every mapped frame -- inverse-depth and
-    confidence maps resized to the image, `pyr_levels` average-pooled pyramids of image / inverse depth / confidence, the
-    6D pose + exposure parameters (exposure inherited from the previous keyframe) and their Adam."""
+    """What run_system.py:177-192 constructs for every mapped frame (scene/keyframe.py:26-126): the frame's image, the inverse depth
+    and confidence of its dense point map brought to the image size (bilinear, align_corners), `pyr_levels` 2x2-average pyramids of
+    all three, the 6D pose + exposure parameters (exposure inherited from the previous keyframe) and their Adam (no pose learning
+    rate for the first keyframe, a fixed one for test frames, which carry no exposure parameter)."""
 
     def __init__(self, image, Rt, point_map, point_conf, f, device, *, index=0, prev_kf=None, is_test=False, pyr_levels=2,
                  lr_poses=1e-4, lr_exposure=1e-3, depth_loss_weight_init=1e-2, depth_loss_weight_decay=0.9):
         self.device = torch.device(device)
-        self.image_pyr = [image]
-        self.is_test = is_test
-        self.width, self.height = image.shape[2], image.shape[1]
-        self.index = index
+        self.is_test, self.index, self.f = is_test, index, f
+        self.height, self.width = image.shape[1], image.shape[2]
         self.latest_invdepth = None
-        self.point_map = point_map.permute(2, 0, 1)[None]               # 1 3 H_slam W_slam
-        depth_foundation = self.point_map[:, 2:, ...]
-        idepth = torch.where(depth_foundation != 0, 1.0 / (depth_foundation + 1e-4), 1e4)
-        self.mono_depth_conf = point_conf[None, None, ...].to(torch.float32)
-        self.idepth_pyr = [F.interpolate(idepth, (self.height, self.width), mode="bilinear", align_corners=True)[0]]
-        self.idepth_conf_pyr = [F.interpolate(self.mono_depth_conf, (self.height, self.width), mode="bilinear", align_corners=True)[0]]
-        for _ in range(pyr_levels - 1):
-            self.idepth_pyr.append(F.avg_pool2d(self.idepth_pyr[-1], 2))
-            self.idepth_conf_pyr.append(F.avg_pool2d(self.idepth_conf_pyr[-1], 2))
-        self.centre = torch.tensor([(self.width - 1) / 2, (self.height - 1) / 2]).to(self.device)
-        self.f = f
-        self.depth_loss_weight = depth_loss_weight_init
-        self.depth_loss_weight_decay = depth_loss_weight_decay
-        for _ in range(pyr_levels - 1):
-            self.image_pyr.append(F.avg_pool2d(self.image_pyr[-1], 2))
+        self.num_steps = 0
+        self.depth_loss_weight, self.depth_loss_weight_decay = depth_loss_weight_init, depth_loss_weight_decay
+        # dense geometry from the SLAM side, at ITS resolution
+        self.point_map = point_map.permute(2, 0, 1)[None]                                   # [1,3,Hs,Ws]
+        z = self.point_map[:, 2:, ...]
+        self.mono_depth_conf = point_conf[None, None, ...].to(torch.float32)                # [1,1,Hs,Ws]
+        inverse_z = torch.where(z != 0, 1.0 / (z + 1e-4), 1e4)
+        to_image = lambda m: F.interpolate(m, (self.height, self.width), mode="bilinear", align_corners=True)[0]
+        self.idepth_pyr = _pyramid(to_image(inverse_z), pyr_levels)
+        self.idepth_conf_pyr = _pyramid(to_image(self.mono_depth_conf), pyr_levels)
+        self.image_pyr = _pyramid(image, pyr_levels)
         self.pyr_lvl = pyr_levels - 1
+        self.centre = torch.tensor([(self.width - 1) / 2, (self.height - 1) / 2]).to(self.device)
+        # optimisable state
         self.rW2C = nn.Parameter(Rt[:3, :2].clone().contiguous())
         self.tW2C = nn.Parameter(Rt[:3, 3].clone().contiguous())
-        exposure = torch.eye(3, 4, device=self.device) if prev_kf is None else prev_kf.exposure.clone().detach()
-        self.exposure = nn.Parameter(exposure)
-        lr_poses = 0 if index == 0 else lr_poses
-        if is_test:
-            lr_poses = 1e-4
-        params = {"rW2C": {"val": self.rW2C, "lr": lr_poses}, "tW2C": {"val": self.tW2C, "lr": lr_poses}}
+        self.exposure = nn.Parameter(torch.eye(3, 4, device=self.device) if prev_kf is None else prev_kf.exposure.clone().detach())
+        pose_lr = 1e-4 if is_test else (0 if index == 0 else lr_poses)
+        params = {"rW2C": {"val": self.rW2C, "lr": pose_lr}, "tW2C": {"val": self.tW2C, "lr": pose_lr}}
         if not is_test:
             params["exposure"] = {"val": self.exposure, "lr": lr_exposure}
         self.optimizer = BaseAdam(params, betas=(0.8, 0.99))
-        self.num_steps = 0
         self.approx_centre = -Rt[:3, :3].T @ Rt[:3, 3]
 
     def get_R(self):
