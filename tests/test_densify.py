@@ -337,3 +337,35 @@ def test_prune_mask_matches_the_torch_expression(lib, dev):
                               centre.data_ptr(), float(sc.f), int(sc.width), out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     assert 0.05 < float(ref.float().mean()) < 0.95
     assert float((out != ref).float().mean()) <= 1e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not mounted")
+def test_stream_keyframe_is_the_references_keyframe(monkeypatch):
+    """harness.mapper.StreamKeyframe against the reference's own Keyframe class (scene/keyframe.py:26-126) on the same inputs: image /
+    inverse-depth / confidence pyramids, centre, pose parameters, exposure inheritance, the pose learning-rate rules."""
+    from harness import mapper, ref_env
+    monkeypatch.setenv("ARTDECO_AMD_AUTOFUSE", "0")
+    ref_env.import_scene_module()
+    kf_mod = sys.modules["Reconstruct.scene.keyframe"]
+    inp = G.make_inputs(CASES["densify_ragged"])
+    args = G.ref_args()
+    f = torch.tensor([inp["fx"]])
+    prev_r = prev_m = None
+    for idx, is_test in ((0, False), (1, False), (2, True)):
+        r = kf_mod.Keyframe(inp["image"].clone(), f"k{idx}", is_test, inp["Rt"], idx, idx, 0, 0, False, f, args, prev_kf=prev_r,
+                            point_map=inp["point_map"].clone(), point_conf=inp["conf"].clone(), device_mapper="cpu")
+        m = mapper.StreamKeyframe(inp["image"].clone(), inp["Rt"], inp["point_map"].clone(), inp["conf"].clone(), f, "cpu", index=idx,
+                                  prev_kf=prev_m, is_test=is_test, pyr_levels=args.pyr_levels)
+        for name in ("image_pyr", "idepth_pyr", "idepth_conf_pyr"):
+            a, b = getattr(r, name), getattr(m, name)
+            assert len(a) == len(b) == args.pyr_levels
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), name
+        assert torch.equal(r.centre, m.centre) and torch.equal(r.approx_centre, m.approx_centre) and r.pyr_lvl == m.pyr_lvl
+        assert torch.equal(r.point_map, m.point_map) and torch.equal(r.mono_depth_conf, m.mono_depth_conf)
+        assert torch.equal(r.rW2C, m.rW2C) and torch.equal(r.tW2C, m.tW2C) and torch.equal(r.exposure, m.exposure)
+        assert set(r.optimizer.params) == set(m.optimizer.params)
+        assert all(r.optimizer.params[k]["lr"] == m.optimizer.params[k]["lr"] for k in r.optimizer.params)
+        assert r.optimizer.betas == m.optimizer.betas and r.depth_loss_weight == m.depth_loss_weight
+        with torch.no_grad():     # a trained exposure must be inherited by the next keyframe on both sides
+            r.exposure.add_(0.01 * (idx + 1)); m.exposure.add_(0.01 * (idx + 1))
+        prev_r, prev_m = r, m
