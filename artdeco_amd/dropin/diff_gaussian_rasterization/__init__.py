@@ -60,7 +60,7 @@ def adamUpdate(param, param_grad, exp_avg, exp_avg_sq, visible, lr, b1, b2, eps,
         raise ValueError(f"adamUpdate: lr has {lr.numel()} elements; expected 1, N or N*M")
     grad = param_grad.contiguous()
     lib = _lib.load()
-    with torch.cuda.device(param.device):
+    with _lib.on_device(param.device):
         rc = lib.adk_adam_update(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                  visible.data_ptr(), lr.data_ptr(), lr.numel(), float(b1), float(b2), float(eps),
                                  N, M, _lib.stream_of(param))
@@ -72,7 +72,7 @@ _tls = threading.local()
 
 def _launch_basic(param, grad, exp_avg, exp_avg_sq, lr, b1, b2, eps):
     lib = _lib.load()
-    with torch.cuda.device(param.device):
+    with _lib.on_device(param.device):
         rc = lib.adk_adam_update_basic(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                        float(lr), float(b1), float(b2), float(eps), param.numel(),
                                        _lib.stream_of(param))

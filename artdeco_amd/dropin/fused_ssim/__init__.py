@@ -34,7 +34,7 @@ def _images(img1: torch.Tensor, img2: torch.Tensor):
 def _forward(a: torch.Tensor, b: torch.Tensor, C1: float, C2: float, train: bool):
     lib = _lib.load()
     B, CH, H, W = a.shape
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         ssim_map = torch.empty_like(a)
         dmaps = tuple(torch.empty_like(a) for _ in range(3)) if train else (None, None, None)
         rc = lib.adk_fused_ssim_fwd(a.data_ptr(), b.data_ptr(), B, CH, H, W, float(C1), float(C2), ssim_map.data_ptr(),
@@ -46,7 +46,7 @@ def _forward(a: torch.Tensor, b: torch.Tensor, C1: float, C2: float, train: bool
 def _backward(a, b, dmaps, dL_dmap, dL_scalar: float):
     lib = _lib.load()
     B, CH, H, W = a.shape
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         out = torch.empty_like(a)
         rc = lib.adk_fused_ssim_bwd(a.data_ptr(), b.data_ptr(), _lib.ptr(dL_dmap), float(dL_scalar), dmaps[0].data_ptr(),
                                     dmaps[1].data_ptr(), dmaps[2].data_ptr(), B, CH, H, W, out.data_ptr(), _lib.stream_of(a))

@@ -51,7 +51,7 @@ class FusedLodParams(torch.autograd.Function):
         L, G, Hd = local_feat.shape[1], global_feat.shape[1], W1.shape[0]
         if W1.shape != (Hd, G + L) or W2.shape != (7, Hd):
             raise ValueError("mlp_cov must be Linear(G+L, G+L) -> ReLU -> Linear(G+L, 7)")
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             opac = torch.empty(N, dtype=torch.float32, device=dev)
             scale = torch.empty(N, 3, dtype=torch.float32, device=dev)
             quat = torch.empty(N, 4, dtype=torch.float32, device=dev)
@@ -77,7 +77,7 @@ class FusedLodParams(torch.autograd.Function):
         L, G, Hd = ctx.dims
         dev, N = xyz.device, xyz.shape[0]
         z = lambda t, ref: (torch.zeros_like(ref) if t is None else t.contiguous())
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             v_opac = z(v_opac, opacity_raw.view(-1))
             v_scale, v_quat = z(v_scale, scaling_raw), z(v_quat, rotation)
             if (v_xyz_through is not None and v_xyz_through.dtype == torch.float32 and v_xyz_through.is_contiguous()
@@ -136,7 +136,7 @@ def visibility_masks(radii: torch.Tensor, cls_id: torch.Tensor, n_vox: int):
     """visible_mask / global_visible_mask of h3dgsv3.py:695-698 in one kernel (no index_put, no host sync)."""
     lib = _lib.load()
     dev, N = radii.device, radii.shape[0]
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         vis = torch.empty(N, dtype=torch.bool, device=dev)
         gvis = torch.empty(n_vox, dtype=torch.bool, device=dev)
         cls = cls_id.view(-1)
@@ -198,7 +198,7 @@ class ExposureClamp(torch.autograd.Function):
         _lib.require_cuda(E, img)
         Ec, ic = E.detach().contiguous().float(), img.detach().contiguous().float()
         P = ic.numel() // 3
-        with torch.cuda.device(ic.device):
+        with _lib.on_device(ic.device):
             out = torch.empty_like(ic)
             with _stage("exposure_fwd"):
                 rc = lib.adk_exposure_fwd(Ec.data_ptr(), ic.data_ptr(), P, out.data_ptr(), _lib.stream_of(ic))
@@ -211,7 +211,7 @@ class ExposureClamp(torch.autograd.Function):
         lib = _lib.load()
         Ec, ic = ctx.saved_tensors
         P = ic.numel() // 3
-        with torch.cuda.device(ic.device):
+        with _lib.on_device(ic.device):
             v_out = v_out.contiguous()
             v_img = torch.empty_like(ic)
             v_E = torch.zeros(3, 4, dtype=torch.float32, device=ic.device)
@@ -307,9 +307,9 @@ def fused_optimizer_step(self, visibility, N, global_visibility, N_global, extra
                 I64(*[(e[5].numel() if e[5] is not None else 0) for e in part]), F32(*[e[6] for e in part]),
                 F32(*[e[7] for e in part]), F32(*[e[8] for e in part]), I64(*[e[9] for e in part]), I64(*[e[10] for e in part]),
                 F32(*[e[11] for e in part]), F32(*[e[12] for e in part]), F32(*[e[13] for e in part]))
-        with torch.no_grad(), torch.cuda.device(dev):
+        with torch.no_grad(), _lib.on_device(dev):
             with _stage("adam_multi"):
-                rc = lib.adk_adam_update_multi_betas(*args, torch.cuda.current_stream(dev).cuda_stream)
+                rc = lib.adk_adam_update_multi_betas(*args, _lib.raw_stream(dev))
         _lib.check(rc, "adk_adam_update_multi_betas")
     # per-row lr tensors (finetune path, h3dgsv3.py:1240-1247) keep the reference's torch decay
     for key, pd in self.params.items():
@@ -330,7 +330,7 @@ class PoseRt(torch.autograd.Function):
         lib = _lib.load()
         _lib.require_cuda(r6, t)
         r6c, tc = r6.detach().contiguous().float(), t.detach().contiguous().float()
-        with torch.cuda.device(r6c.device):
+        with _lib.on_device(r6c.device):
             Rt = torch.empty(4, 4, dtype=torch.float32, device=r6c.device)
             rc = lib.adk_pose6d_fwd(r6c.data_ptr(), tc.data_ptr(), Rt.data_ptr(), _lib.stream_of(r6c))
         _lib.check(rc, "adk_pose6d_fwd")
@@ -344,7 +344,7 @@ class PoseRt(torch.autograd.Function):
             return None, None
         lib = _lib.load()
         (r6c,) = ctx.saved_tensors
-        with torch.cuda.device(r6c.device):
+        with _lib.on_device(r6c.device):
             v_Rt = v_Rt.contiguous().float()
             v_r6, v_t = torch.empty_like(r6c), torch.empty(3, dtype=torch.float32, device=r6c.device)
             rc = lib.adk_pose6d_bwd(r6c.data_ptr(), v_Rt.data_ptr(), v_r6.data_ptr(), v_t.data_ptr(), _lib.stream_of(r6c))
@@ -373,7 +373,7 @@ class FusedMapperLoss(torch.autograd.Function):
             raise ValueError("FusedMapperLoss: gt [3,H,W], mono_idepth [1,H,W], rdk [H,W], exposure [3,4] expected")
         mo = 1 if mask_outliers else 0
         lam, wd = float(lambda_dssim), float(depth_weight)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _lib.stream_of(colors4)
             image = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             gt_used = torch.empty(3, H, W, dtype=torch.float32, device=dev) if mo else gt
@@ -413,7 +413,7 @@ class FusedMapperLoss(torch.autograd.Function):
         colors4, alphas, E, bg, gt, mono, rdk, image, gt_used, dm = ctx.saved_tensors
         H, W, lam, wd, mo, e_shape = ctx.cfg
         dev = colors4.device
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _lib.stream_of(colors4)
             v_loss = v_loss.detach().reshape(1).float().contiguous()
             v_img = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -702,8 +702,8 @@ def fused_add_and_prune(self, extension_tensors, valid_mask):
         if key in self.lr_dict:
             bits = struct.unpack("<I", struct.pack("<f", float(self.lr_dict[key]["lr_init"])))[0]
             jobs.append((param, "lr", param["lr"], None, bits, False, e_key))
-    with torch.cuda.device(dev):
-        st = torch.cuda.current_stream(dev).cuda_stream
+    with _lib.on_device(dev):
+        st = _lib.raw_stream(dev)
         ws = torch.empty(int(lib.adk_compact_workspace_bytes(N)), dtype=torch.uint8, device=dev)
         n_keep_dev = torch.empty(1, dtype=torch.int64, device=dev)
         _lib.check(lib.adk_compact_plan(N, mask.data_ptr(), n_keep_dev.data_ptr(), ws.data_ptr(), ws.numel(), st), "adk_compact_plan")
@@ -748,7 +748,7 @@ def lod_visible_count(xyz, d_max, keyframes, device):
     """counts [N] int32: in how many keyframes each Gaussian is within its LoD range (h3dgsv3.py:943-950), one launch."""
     lib = _lib.load()
     N, n_kf = xyz.shape[0], len(keyframes)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         counts = torch.zeros(N, dtype=torch.int32, device=device)
         if N == 0 or n_kf == 0:
             return counts
@@ -756,7 +756,7 @@ def lod_visible_count(xyz, d_max, keyframes, device):
         t = torch.stack([kf.tW2C.detach().to(device, non_blocking=True) for kf in keyframes]).float().contiguous()
         xyz_c, dm = xyz.detach().float().contiguous(), d_max.detach().float().contiguous()
         rc = lib.adk_lod_visible_count(N, xyz_c.data_ptr(), dm.data_ptr(), n_kf, r6.data_ptr(), t.data_ptr(), counts.data_ptr(),
-                                       torch.cuda.current_stream(device).cuda_stream)
+                                       _lib.raw_stream(device))
     _lib.check(rc, "adk_lod_visible_count")
     return counts
 
@@ -787,8 +787,8 @@ def update_voxel_device(new_xyz: torch.Tensor, xyz: torch.Tensor, cls_id: torch.
     f = lambda t: t.detach().to(dev, torch.float32).contiguous()
     nx_, ox_ = f(new_xyz), (f(xyz) if N else None)
     cls = cls_id.detach().reshape(-1).to(dev, torch.int64).contiguous() if N else None
-    with torch.cuda.device(dev):
-        st = torch.cuda.current_stream(dev).cuda_stream
+    with _lib.on_device(dev):
+        st = _lib.raw_stream(dev)
         minc = torch.empty(3, dtype=torch.float32, device=dev)
         info = torch.empty(4, dtype=torch.int64, device=dev)
         small = torch.empty(64, dtype=torch.uint8, device=dev)
@@ -857,8 +857,8 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
     ratio = float(getattr(args, "gs_add_ratio"))
     voxel_size = float(getattr(args, "voxel_size"))
     L_dim, G_dim = int(getattr(args, "local_feat_dim")), int(getattr(args, "global_feat_dim"))
-    with torch.cuda.device(dev):
-        st = torch.cuda.current_stream(dev).cuda_stream
+    with _lib.on_device(dev):
+        st = _lib.raw_stream(dev)
         f32 = dict(dtype=torch.float32, device=dev)
         img0 = img0.contiguous()
         H0, W0 = img0.shape[1], img0.shape[2]
@@ -967,13 +967,13 @@ def fused_rigid_transform_gs(self, old_c2ws, new_c2ws, cam_centres):
         return self._unfused_rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)
     lib = _lib.load()
     dev = xyz.device
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         delta = torch.bmm(new_c2ws.float(), torch.inverse(old_c2ws.float())).contiguous()
         N, K = xyz.shape[0], delta.shape[0]
         new_xyz, new_rot = torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, 4, dtype=torch.float32, device=dev)
         rc = lib.adk_rigid_transform(N, ids.reshape(-1).contiguous().data_ptr(), K, delta.data_ptr(), xyz.detach().contiguous().data_ptr(),
                                      rot.detach().contiguous().data_ptr(), new_xyz.data_ptr(), new_rot.data_ptr(),
-                                     torch.cuda.current_stream(dev).cuda_stream)
+                                     _lib.raw_stream(dev))
     _lib.check(rc, "adk_rigid_transform")
     self.gaussian_params["xyz"]["val"] = new_xyz
     self.gaussian_params["rotation"]["val"] = new_rot

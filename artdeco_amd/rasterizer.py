@@ -96,7 +96,7 @@ class _Workspace:
         self._lock = threading.Lock()
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        key = (device.index, _lib.raw_stream(device))
         with self._lock:
             buf = self._buf.get(key)
             if buf is None or buf.numel() < nbytes:
@@ -276,8 +276,8 @@ def gsplat_tile_lists(rec, depth_keys, tiles_per_gauss, width, height):
     carries under those names.  The drop-in computes them on first access when the render itself used wider internal tiles."""
     lib = _lib.load()
     dev, N = rec.device, rec.shape[0]
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev).cuda_stream
+    with _lib.on_device(dev):
+        stream = _lib.raw_stream(dev)
         i32 = dict(dtype=torch.int32, device=dev)
         gauss_ids = torch.arange(N, **i32)
         flat, _t, offs, _n, _w, _h = _bin_lists(lib, None, (16, 16), False, N, width, height, rec, depth_keys, gauss_ids, tiles_per_gauss, dev,
@@ -308,8 +308,8 @@ class RasterizeGaussians(torch.autograd.Function):
         rest_c = _f32c(sh_rest, "sh_rest") if sh_rest is not None else None
         viewmat, K = _f32c(viewmat, "viewmats"), _f32c(K, "Ks")
         bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _lib.on_device(dev):
+            stream = _lib.raw_stream(dev)
             i32 = dict(dtype=torch.int32, device=dev)
             rec = torch.empty(N, 12, dtype=torch.float32, device=dev)
             radii = torch.empty(N, 2, **i32)
@@ -378,8 +378,8 @@ class RasterizeGaussians(torch.autograd.Function):
         N = means.shape[0]
         W, H = cfg.width, cfg.height
         needs = ctx.needs_input_grad
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
+        with _lib.on_device(dev):
+            stream = _lib.raw_stream(dev)
             v_colors = (v_colors if v_colors is not None else torch.zeros(H, W, 4, device=dev)).contiguous()
             v_alphas = (v_alphas if v_alphas is not None else torch.zeros(H, W, 1, device=dev)).contiguous()
             v_rec = torch.zeros(N, 12, dtype=torch.float32, device=dev)
