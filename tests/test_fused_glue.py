@@ -163,7 +163,9 @@ def test_fused_optimization_step_gradients_match_unfused(reg, dev, monkeypatch):
 
         inv_a, inv_b = a.keyframes[i % 2].latest_invdepth, b.keyframes[i % 2].latest_invdepth
         da, db = torch.nan_to_num(1.0 / inv_a, posinf=0.0), torch.nan_to_num(1.0 / inv_b, posinf=0.0)
-        flipped = ((da - db).abs() > 1e-4 * float(da.abs().max()))[0]
+        # a flipped splat moves the pixel's accumulated depth by alpha T z >= (1/255) T z; two evaluations of the SAME decisions agree
+        # to ~1e-6 here (depths <= 6), so 1e-5 separates the two down to T ~ 1e-3, below which the splat's gradient share is nil
+        flipped = ((da - db).abs() > 1e-5)[0]
         knife = bool(flipped.any())
         if knife:
             on_edge = _knife_pixels(seen[-1]).to(dev)
