@@ -1,0 +1,37 @@
+"""bench.py's accounting and the frame schedule of harness/stream.py (CPU; the numbers themselves are measured on the GPU box)."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_frame_schedule_is_the_stated_cadence():
+    from harness import stream
+    fl = [stream.frame_flags(i, kf_every=5, slam_every=15, test_hold=8) for i in range(120)]
+    assert [i for i, f in enumerate(fl) if f["is_slam_keyframe"]] == list(range(0, 120, 15))
+    assert [i for i, f in enumerate(fl) if f["is_test"]] == list(range(8, 120, 8))                    # frame 0 is never a test frame
+    important = {i for i, f in enumerate(fl) if f["is_important"]}
+    assert important == set(range(0, 120, 5)) | set(range(8, 120, 8))                                # mapper keyframes (incl. SLAM ones) + test frames
+    assert all(f["is_important"] for f in fl if f["is_slam_keyframe"])                               # CameraTracker.py:143-148
+    assert 0.30 <= len(important) / 120 <= 0.36
+
+
+def test_roofline_stages_follow_the_survey_formulas():
+    bench = importlib.import_module("bench")
+    N, V, I, P, W, H = 1_000_000, 900_000, 3_700_000, 1920 * 1080, 1920, 1080
+    st = {k: {"mean_ms": v} for k, v in dict(project_fwd=0.06, bin_count=0.03, bin_scatter=0.07, bin_sort=0.04, raster_fwd=0.25, raster_bwd=0.56,
+                                             project_bwd=0.24, ssim_fwd=0.05, ssim_bwd=0.06, adam_multi=0.14, lod_params_fwd=0.06,
+                                             lod_params_bwd=0.16, photometric_fwd=0.02, photometric_bwd=0.05, photometric_loss=0.01).items()}
+    r = bench.roofline_stages(st, N, V, I, P, W, H)
+    assert r["raster_bwd"]["alg_bytes"] == 44.0 * I + 28.0 * P + 40.0 * V
+    assert r["raster_fwd"]["alg_bytes"] == 44.0 * I + 24.0 * P
+    assert r["binning"]["alg_bytes"] == 36.0 * I + 4.0 * (120 * 68) and abs(r["binning"]["ms"] - 0.14) < 1e-9
+    assert r["project_fwd"]["alg_bytes"] == 76.0 * N + 216.0 * V
+    assert r["ssim_fwd"]["alg_bytes"] == 24.0 * P * 3 and r["ssim_bwd"]["alg_bytes"] == 28.0 * P * 3
+    for k, v in r.items():
+        if k != "whole_step":
+            assert abs(v["frac"] - v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3, k
+    total_ms = sum(v["mean_ms"] for v in st.values())
+    assert abs(r["whole_step"]["ms_sum_of_stages"] - total_ms) < 1e-3                                # every stage's time, also those without a formula

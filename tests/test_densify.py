@@ -255,15 +255,17 @@ def test_fused_add_new_gaussians_matches_the_reference(name, lib, dev, monkeypat
 
 
 @pytest.mark.gpu
-def test_fused_add_new_gaussians_vs_torch_chain_at_map_size(lib, dev):
-    """200 k Gaussians, 648x486 (what run.sh trains on), the keyframe's image = the render plus texture: ARTDECO's operator chain
-    (the mirror, torch on the same GPU) and the HIP path under the same RNG stream select the same pixels up to knife edges."""
+@pytest.mark.parametrize("N,W,H", [(200_000, 648, 486), (1_000_000, 1920, 1080)])
+def test_fused_add_new_gaussians_vs_torch_chain_at_map_size(N, W, H, lib, dev):
+    """200 k Gaussians at 648x486 (what run.sh trains on) and BASELINE configs[2]'s 1 M at 1920x1080; the keyframe's image = the
+    render plus texture: ARTDECO's operator chain (the mirror, torch on the same GPU) and the HIP path under the same RNG stream
+    select the same pixels up to knife edges."""
     import time
     from artdeco_amd import fused
     from harness import mapper, stream
     res = {}
     for mode in ("torch", "hip"):
-        sc = mapper.build_synthetic_mapper(200_000, 648, 486, dev, seed=0, n_keyframes=0, targets="random", lod=True)
+        sc = mapper.build_synthetic_mapper(N, W, H, dev, seed=0, n_keyframes=0, targets="random", lod=True)
         fused.patch_scene_model(sc)
         if mode == "torch":     # ARTDECO's own body on the fused render / update_voxel / add_and_prune
             sc.add_new_gaussians = sc._unfused_add_new_gaussians
@@ -280,9 +282,9 @@ def test_fused_add_new_gaussians_vs_torch_chain_at_map_size(lib, dev):
         torch.cuda.synchronize()
         res[mode] = dict(ms=(time.perf_counter() - t0) * 1e3, n_new=cap[0][0], ext=cap[0][1], mask=cap[0][2], final=sc.xyz.shape[0])
     a, b = res["torch"], res["hip"]
-    print(f"add_new_gaussians at 200k / 648x486: torch chain {a['ms']:.1f} ms, HIP {b['ms']:.1f} ms; new Gaussians {a['n_new']} / {b['n_new']}")
+    print(f"add_new_gaussians at {N} / {W}x{H}: torch chain {a['ms']:.1f} ms, HIP {b['ms']:.1f} ms; new Gaussians {a['n_new']} / {b['n_new']}")
     assert a["n_new"] > 2000
-    assert abs(a["n_new"] - b["n_new"]) <= max(2, int(1e-4 * (648 * 486 * 85 // 64)))       # >= 99.99 % of the pixels agree
+    assert abs(a["n_new"] - b["n_new"]) <= max(2, int(1e-4 * (W * H * 85 // 64)))       # >= 99.99 % of the pixels agree
     assert float((a["mask"] != b["mask"]).float().mean()) <= 1e-4
     if a["n_new"] == b["n_new"]:
         for k in ("xyz", "f_dc", "scaling", "opacity", "d_max"):
