@@ -112,18 +112,29 @@ struct PixFwd {
 // gsplat does not list for a pixel's own 16x16 tile cannot reach alpha >= 1/255 there (its radius box bounds exactly that region),
 // and the per-quadrant test below rejects it, so every pixel composites the same splats in the same order as with 16x16 tiles:
 // the forward is bit-identical, the backward differs only in the order its sums are formed.
-template <int QX, int QY, bool MAIN_ID>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 4 ? 8 : 4, 8))) void raster_fwd_kernel(
+//
+// SUB: the wave serves ONE 8x8 quadrant (QX = 1) or one 16x8 half (QX = 2) of a 16x16 list tile -- four / two independent single-wave
+// workgroups per tile, each walking the tile's list on its own.  For frames with fewer tiles than the chip has SIMDs (512x384: 768,
+// 648x486: 1271, against 1024) the one-wave-per-tile form leaves SIMDs empty and the rest with a single, latency-bound wave; more waves per
+// tile fill the chip and shorten every wave's serial chain to its own hits (split_parts below picks the form from the tile count).
+// Per-pixel arithmetic and order are unchanged: bit-identical output in every form.
+template <int QX, int QY, bool MAIN_ID, bool SUB = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 4 : 8, 8))) void raster_fwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     float* __restrict__ render_colors, float* __restrict__ render_alphas, float* __restrict__ final_T,
     int32_t* __restrict__ last_ids, int32_t* __restrict__ main_ids)
 {
-    constexpr int NQ = QX * QY, TPW = 8 * QX, TPH = 8 * QY;
+    static_assert(!SUB || (QX <= 2 && QY == 1), "SUB: a wave serves one quadrant or one 16x8 half of a 16x16 list tile");
+    constexpr int NQ = QX * QY, TPW = SUB ? 16 : 8 * QX, TPH = SUB ? 16 : 8 * QY;
+    constexpr int PARTS = SUB ? 4 / NQ : 1, PCOLS = SUB ? 2 / QX : 1; // footprints per list tile, and per row of it
     __shared__ float4 srec[64][3];
     const int n_tiles = tile_w * tile_h;
-    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    // SUB: the parts of a tile are consecutive in the remapped order, i.e. on the same XCD (they read the same records)
+    const int vtile = xcd_remap(blockIdx.x, PARTS * n_tiles);
+    const int tile = vtile / PARTS, part = vtile % PARTS;
     const int tx = tile % tile_w, ty = tile / tile_w;
+    const int px0 = tx * TPW + (part % PCOLS) * 8 * QX, py0 = ty * TPH + (part / PCOLS) * 8 * QY; // first pixel of the footprint
     const int lane = threadIdx.x;
 
     const int range_start = offsets[tile];
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 4
     unsigned long long done_m[NQ]; // wave-uniform lane masks (SGPR pairs): bit l = lane l's pixel of quadrant q is finished
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int ox = tx * TPW + (q % QX) * 8, oy = ty * TPH + (q / QX) * 8;
+        const int ox = px0 + (q % QX) * 8, oy = py0 + (q / QX) * 8;
         const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
         PixFwd& P = px[q];
         P.o0 = P.o1 = P.o2 = P.o3 = 0.f;
@@ -147,8 +158,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 4
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
     // pixel centre in quadrant 0; quadrant q adds (8 (q % QX), 8 (q / QX)).  Register budget of the 16x16 form: 64 VGPRs, so that all
     // tiles of a 1080p frame (8160) are resident at once (8 waves/SIMD x 1024 SIMDs) and there is no second, half-empty round.
-    const float fx0 = (float)(tx * TPW + (lane & 7)) + 0.5f, fy0 = (float)(ty * TPH + (lane >> 3)) + 0.5f;
-    const float tox = (float)(tx * TPW) + 0.5f, toy = (float)(ty * TPH) + 0.5f; // centre of the tile's first pixel
+    const float fx0 = (float)(px0 + (lane & 7)) + 0.5f, fy0 = (float)(py0 + (lane >> 3)) + 0.5f;
+    const float tox = (float)px0 + 0.5f, toy = (float)py0 + 0.5f; // centre of the footprint's first pixel
 
     for (int batch_start = range_start; batch_start < range_end && live; batch_start += 64) {
         const int batch_size = min(64, range_end - batch_start);
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 4
     for (int q = 0; q < NQ; ++q) {
         if (inside[q]) {
             PixFwd& P = px[q];
-            const int pxi = tx * TPW + (q % QX) * 8 + (lane & 7), pyi = ty * TPH + (q / QX) * 8 + (lane >> 3);
+            const int pxi = px0 + (q % QX) * 8 + (lane & 7), pyi = py0 + (q / QX) * 8 + (lane >> 3);
             const int64_t pix = (int64_t)pyi * W + pxi;
             render_alphas[pix] = 1.0f - P.T;
             // The backward restarts its transmittance recurrence from T_final.  Recovering it as 1 - alpha (what upstream
@@ -301,7 +312,10 @@ struct PixBwd {
 //     DIFFERENT records was 2x SLOWER (1.55 ms: the memory side pays per cache line touched by an instruction, not per
 //     lane), LDS ds_add_f32 for the row combine 0.85 ms.  Where the time goes (same measurements, ablations): cull test +
 //     exponent + validity 0.22, gradient arithmetic 0.21, cross-lane reduction 0.18, atomics 0.09 ms.
-template <int QX, int QY>
+// SUB: one wave per 8x8 quadrant / 16x8 half of a 16x16 list tile, as in the forward -- for frames with few tiles.  A splat then costs one
+// reduction and one parked record per PART it contributes to instead of per tile: more total work, spread over more waves on a chip that
+// was mostly idle (the sums are formed in a different order: gradients move by ~3e-7 relative).
+template <int QX, int QY, bool SUB = false>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
@@ -309,13 +323,17 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_rec)
 {
-    constexpr int NQ = QX * QY, TPW = 8 * QX, TPH = 8 * QY;
+    static_assert(!SUB || (QX <= 2 && QY == 1), "SUB: a wave serves one quadrant or one 16x8 half of a 16x16 list tile");
+    constexpr int NQ = QX * QY, TPW = SUB ? 16 : 8 * QX, TPH = SUB ? 16 : 8 * QY;
+    constexpr int PARTS = SUB ? 4 / NQ : 1, PCOLS = SUB ? 2 / QX : 1;
     __shared__ float4 srec[64][3];
     __shared__ int sid[64];
     __shared__ float sacc[64][12]; // [staged splat][dword of its gradient record]: totals parked until the batch is flushed
     const int n_tiles = tile_w * tile_h;
-    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int vtile = xcd_remap(blockIdx.x, PARTS * n_tiles);
+    const int tile = vtile / PARTS, part = vtile % PARTS;
     const int tx = tile % tile_w, ty = tile / tile_w;
+    const int px0 = tx * TPW + (part % PCOLS) * 8 * QX, py0 = ty * TPH + (part / PCOLS) * 8 * QY;
     const int lane = threadIdx.x;
 
     const int range_start = offsets[tile];
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     int quad_bin_final[NQ], tile_bin_final = -1;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int ox = tx * TPW + (q % QX) * 8, oy = ty * TPH + (q / QX) * 8;
+        const int ox = px0 + (q % QX) * 8, oy = py0 + (q / QX) * 8;
         const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
         PixBwd& P = px[q];
         P.vr0 = P.vr1 = P.vr2 = P.vr3 = 0.f; P.T = 1.f; P.bdot = 0.f; P.C0 = 0.f; P.bin_final = -1;
@@ -359,8 +377,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         tile_bin_final = max(tile_bin_final, quad_bin_final[q]);
     }
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
-    const float fx0 = (float)(tx * TPW + (lane & 7)) + 0.5f, fy0 = (float)(ty * TPH + (lane >> 3)) + 0.5f;
-    const float tox = (float)(tx * TPW) + 0.5f, toy = (float)(ty * TPH) + 0.5f;
+    const float fx0 = (float)(px0 + (lane & 7)) + 0.5f, fy0 = (float)(py0 + (lane >> 3)) + 0.5f;
+    const float tox = (float)px0 + 0.5f, toy = (float)py0 + 0.5f;
 
     // walk the tile's list back to front in groups of 64; groups entirely behind every pixel's last
     // contributor are skipped without being loaded
@@ -485,6 +503,22 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 
 } // namespace adk
 
+// How many waves serve a 16x16 list tile: 1 (the whole tile), 2 (its 16x8 halves) or 4 (its 8x8 quadrants).  A tile is one wave, the chip
+// has 1 024 SIMDs with 8 wave slots each: with few tiles the one-wave form leaves SIMDs empty or with a single latency-bound wave, and
+// splitting shortens every wave's serial chain to its own hits; with many tiles the duplicated staging / culling (and, backward, one
+// reduction + one parked record per PART a splat contributes to instead of per tile) costs more than it hides.  Same-box A/B on MI355X
+// (tools/lab/ab_split.py -> profiles/r03_ab_split.json; ms, tile / half / quadrant):
+//     tiles      768 (1 M, 512x384)   1 271 (648x486)    1 900             3 072             5 700             8 160 (1080p)      19 764 (4 M)
+//     forward    .127 / .079 / .054   .160 / .103 / .087  .135 / .092 / .085  .155 / .113 / .113  .228 / .197 / .212  .259 / .246 / .288  .516 / .487 / .606
+//     backward   .189 / .120 / .104   .236 / .176 / .171  .223 / .168 / .181  .259 / .229 / .240  .439 / .409 / .455  .543 / .558 / .630  1.06 / 1.09 / 1.33
+// ADK_RASTER_SPLIT_FWD / _BWD = 0 (tile) | 2 (halves) | 1 (quadrants) force a form (read per launch: the labs and tests flip it in-process).
+static int split_parts(int n_tiles, bool bwd) {
+    const char* e = getenv(bwd ? "ADK_RASTER_SPLIT_BWD" : "ADK_RASTER_SPLIT_FWD");
+    if (e && (e[0] == '0' || e[0] == '1' || e[0] == '2')) return e[0] == '0' ? 1 : (e[0] == '1' ? 4 : 2);
+    if (bwd) return n_tiles < 1600 ? 4 : (n_tiles < 7000 ? 2 : 1);
+    return n_tiles < 3072 ? 4 : 2;
+}
+
 // render_colors [H,W,4], render_alphas [H,W], final_T [H,W] (exact final transmittance, consumed by adk_raster_bwd),
 // last_ids [H,W]; backgrounds [4] or NULL; main_ids [H,W] (Gaussian id with the largest alpha*T per pixel, -1 if none) or NULL.
 // tile_px_w x tile_px_h: the tile shape the lists (flatten_ids / offsets) were binned for: 16x16 (gsplat's) or 32x16.
@@ -503,7 +537,15 @@ extern "C" int adk_raster_fwd_t(int width, int height, int tile_px_w, int tile_p
 #define ADK_FWD(QX, QY, MID) hipLaunchKernelGGL((adk::raster_fwd_kernel<QX, QY, MID>), dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, \
         width, height, rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, main_ids)
     if (wide) { if (main_ids) ADK_FWD(4, 2, true); else ADK_FWD(4, 2, false); }
-    else { if (main_ids) ADK_FWD(2, 2, true); else ADK_FWD(2, 2, false); }
+    else {
+#define ADK_FWD_SUB(QX, MID) hipLaunchKernelGGL((adk::raster_fwd_kernel<QX, 1, MID, true>), dim3(4 / QX * tile_w * tile_h), dim3(64), 0, stream, tile_w, \
+        tile_h, width, height, rec, flatten_ids, offsets, (int)n_isects, backgrounds, render_colors, render_alphas, final_T, last_ids, main_ids)
+        const int parts = split_parts(tile_w * tile_h, false);
+        if (parts == 4) { if (main_ids) ADK_FWD_SUB(1, true); else ADK_FWD_SUB(1, false); }
+        else if (parts == 2) { if (main_ids) ADK_FWD_SUB(2, true); else ADK_FWD_SUB(2, false); }
+        else { if (main_ids) ADK_FWD(2, 2, true); else ADK_FWD(2, 2, false); }
+#undef ADK_FWD_SUB
+    }
 #undef ADK_FWD
     ADK_RETURN_LAST_ERROR();
 }
@@ -531,6 +573,12 @@ extern "C" int adk_raster_bwd_t(int width, int height, int tile_px_w, int tile_p
     const int tile_w = (width + tile_px_w - 1) / tile_px_w, tile_h = (height + tile_px_h - 1) / tile_px_h;
     if (wide)
         hipLaunchKernelGGL((adk::raster_bwd_kernel<4, 2>), dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
+    else if (const int parts = split_parts(tile_w * tile_h, true); parts == 4)
+        hipLaunchKernelGGL((adk::raster_bwd_kernel<1, 1, true>), dim3(4 * tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
+    else if (parts == 2)
+        hipLaunchKernelGGL((adk::raster_bwd_kernel<2, 1, true>), dim3(2 * tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
                            rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
     else
         hipLaunchKernelGGL((adk::raster_bwd_kernel<2, 2>), dim3(tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,

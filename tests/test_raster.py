@@ -445,3 +445,53 @@ def test_wide_internal_tiles_composite_the_same_pixels(N, W, H, seed, dev, monke
         g32 = a32["grads"][k]
         rel = float((g32 - g16).norm() / g16.norm().clamp_min(1e-30))
         assert rel <= 2e-5, (k, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,W,H,seed", [(20_000, 250, 187, 0), (300_000, 1000, 530, 1), (1_000_000, 1920, 1080, 2), (1_000_000, 512, 384, 3),
+                                         (5_000, 41, 23, 4)])
+def test_waves_per_tile_forms_composite_the_same_pixels(N, W, H, seed, dev, monkeypatch):
+    """Round 3: a 16x16 list tile is served by one wave, by two (its 16x8 halves) or by four (its 8x8 quadrants), chosen from the frame's
+    tile count (raster_tiles.hip, split_parts).  Every form composites the same splats in the same order on every pixel: forward
+    outputs and the last / main contributor ids are BIT-IDENTICAL (ragged edges where a half or a quadrant lies outside the image
+    included), the gradients differ only by the order of their sums."""
+    sc = dict(_scene(N, W, H, seed), viewmat=_tilted_viewmat(seed))
+    g = torch.Generator().manual_seed(seed)
+    wgt = torch.randn(H, W, 4, generator=g).to(dev)
+    res = {}
+    for form in ("0", "2", "1", None):   # tile, halves, quadrants, the default choice
+        for k in ("ADK_RASTER_SPLIT_FWD", "ADK_RASTER_SPLIT_BWD"):
+            monkeypatch.delenv(k, raising=False) if form is None else monkeypatch.setenv(k, form)
+        r, a, meta, leaves = _run_hip(sc, dev, requires_grad=True)
+        ((r[0] * wgt).sum() + a.sum()).backward()
+        res[form] = dict(r=r.detach().clone(), a=a.detach().clone(), grads={k: v.grad.detach().clone() for k, v in leaves.items()})
+    ref = res["0"]
+    assert float(ref["a"].max()) > 0.5
+    for form in ("2", "1", None):
+        assert torch.equal(ref["r"], res[form]["r"]) and torch.equal(ref["a"], res[form]["a"]), form
+        for k, g0 in ref["grads"].items():
+            rel = float((res[form]["grads"][k] - g0).norm() / g0.norm().clamp_min(1e-30))
+            assert rel <= 2e-5, (form, k, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(96, 64), (250, 187)])
+def test_waves_per_tile_forms_report_the_same_main_gaussian(W, H, dev, monkeypatch):
+    """The GaussianRasterizer adapter's mainGaussID (MAIN_ID kernels) in the three forms."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    N = 8_000
+    sc = dict(_scene(N, W, H, 5), viewmat=_tilted_viewmat(5))
+    fx = float(sc["K"][0, 0])
+    st = GaussianRasterizationSettings(H, W, W / (2 * fx), H / (2 * fx), torch.tensor([0.1, 0.2, 0.3], device=dev), 1.0, torch.eye(4, device=dev), 3,
+                                       torch.zeros(3, device=dev), False, False)
+    t = {k: v.to(dev) for k, v in sc.items() if torch.is_tensor(v)}
+    outs = []
+    for form in ("0", "2", "1"):
+        monkeypatch.setenv("ADK_RASTER_SPLIT_FWD", form)
+        out = GaussianRasterizer(st)(t["means"], torch.zeros_like(t["means"]), t["opacities"][:, None], t["colors"][:, :1], t["colors"][:, 1:],
+                                     t["scales"], t["quats"], t["viewmat"].transpose(0, 1))
+        outs.append([o.detach().clone() for o in out])
+    assert int((outs[0][2] >= 0).sum()) > 0.5 * W * H
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
