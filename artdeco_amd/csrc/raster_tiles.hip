@@ -511,6 +511,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 //     tiles      768 (1 M, 512x384)   1 271 (648x486)    1 900             3 072             5 700             8 160 (1080p)      19 764 (4 M)
 //     forward    .127 / .079 / .054   .160 / .103 / .087  .135 / .092 / .085  .155 / .113 / .113  .228 / .197 / .212  .259 / .246 / .288  .516 / .487 / .606
 //     backward   .189 / .120 / .104   .236 / .176 / .171  .223 / .168 / .181  .259 / .229 / .240  .439 / .409 / .455  .543 / .558 / .630  1.06 / 1.09 / 1.33
+// Measured with the split forms and dropped: requesting the NEXT group's list entries + records before the current group is walked (13
+// more VGPRs): forward +-1 %, backward 0.160 -> 0.168 ms in the quadrant form at 200 k / 648x486 -- the waves do not wait on those loads.
 // ADK_RASTER_SPLIT_FWD / _BWD = 0 (tile) | 2 (halves) | 1 (quadrants) force a form (read per launch: the labs and tests flip it in-process).
 static int split_parts(int n_tiles, bool bwd) {
     const char* e = getenv(bwd ? "ADK_RASTER_SPLIT_BWD" : "ADK_RASTER_SPLIT_FWD");

@@ -34,6 +34,24 @@ def warm_libraries(dev):
     torch.cuda.synchronize()
 
 
+def warm_process(dev, frames=9, use_fused=True):
+    """warm_libraries + every code path of the frame loop once, on a throw-away 2 000-Gaussian / 96x64 scene whose cadence puts a
+    SLAM keyframe and a densified frame inside `frames` frames: the first batched inversion / bmm of the pose re-read, the first
+    launches of the densification kernels, torch's lazily loaded code objects.  One-off costs of the PROCESS (tens of milliseconds, e.g.
+    35 ms on the first SLAM keyframe), not of any frame: a benchmark that times 40 frames must not bill them to those frames, a
+    1 000-frame run does not notice them."""
+    from artdeco_amd import fused
+    warm_libraries(dev)
+    state = np.random.get_state()
+    scene = mapper.build_synthetic_mapper(2_000, 96, 64, dev, seed=1, n_keyframes=0, targets="random")
+    if use_fused:
+        fused.patch_scene_model(scene)
+    run_stream(scene, synthetic_frames(scene, frames, seed=1, slam_hw=(48, 64)), kf_every=3, slam_every=4, test_hold=5)
+    np.random.set_state(state)
+    del scene
+    torch.cuda.synchronize()
+
+
 def frame_flags(i: int, kf_every: int = 5, slam_every: int = 15, test_hold: int = 8):
     is_test = test_hold > 0 and i % test_hold == 0 and i > 0
     is_slam = i % slam_every == 0
