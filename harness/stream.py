@@ -42,12 +42,14 @@ def warm_process(dev, frames=9, use_fused=True):
     1 000-frame run does not notice them."""
     from artdeco_amd import fused
     warm_libraries(dev)
-    state = np.random.get_state()
+    state, cpu_rng, dev_rng = np.random.get_state(), torch.get_rng_state(), torch.cuda.get_rng_state(dev)   # leave every stream as found
     scene = mapper.build_synthetic_mapper(2_000, 96, 64, dev, seed=1, n_keyframes=0, targets="random")
     if use_fused:
         fused.patch_scene_model(scene)
     run_stream(scene, synthetic_frames(scene, frames, seed=1, slam_hw=(48, 64)), kf_every=3, slam_every=4, test_hold=5)
     np.random.set_state(state)
+    torch.set_rng_state(cpu_rng)
+    torch.cuda.set_rng_state(dev_rng, dev)
     del scene
     torch.cuda.synchronize()
 

@@ -1,5 +1,7 @@
 """bench.py's accounting and the frame schedule of harness/stream.py (CPU; the numbers themselves are measured on the GPU box)."""
 import importlib
+
+import pytest
 import os
 import sys
 
@@ -35,3 +37,25 @@ def test_roofline_stages_follow_the_survey_formulas():
             assert abs(v["frac"] - v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3, k
     total_ms = sum(v["mean_ms"] for v in st.values())
     assert abs(r["whole_step"]["ms_sum_of_stages"] - total_ms) < 1e-3                                # every stage's time, also those without a formula
+
+
+@pytest.mark.gpu
+def test_warm_process_runs_every_frame_kind_and_leaves_the_rng_streams_alone():
+    """harness/stream.warm_process (what bench.py / bench_system.py call before anything is timed): a SLAM keyframe, a densified frame
+    and a test frame on a throw-away scene, with numpy's / torch's / the device's random streams left exactly where they were (the
+    timed stream's keyframe choice and its uniform draws must not depend on whether the process was warmed)."""
+    import numpy as np
+    import torch
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    from harness import stream
+    kinds = [stream.frame_flags(i, kf_every=3, slam_every=4, test_hold=5) for i in range(9)]
+    assert any(k["is_slam_keyframe"] for k in kinds[1:]) and any(k["is_test"] for k in kinds)
+    assert any(k["is_important"] and not k["is_test"] for k in kinds[1:])
+    dev = torch.device("cuda:0")
+    np.random.seed(5)
+    torch.manual_seed(5)
+    a = (np.random.get_state()[1].copy(), torch.get_rng_state().clone(), torch.cuda.get_rng_state(dev).clone())
+    stream.warm_process(dev)
+    b = (np.random.get_state()[1], torch.get_rng_state(), torch.cuda.get_rng_state(dev))
+    assert (a[0] == b[0]).all() and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
