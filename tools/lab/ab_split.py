@@ -29,14 +29,10 @@ def setmode(f, b):
 
 
 def render_and_grads(scene):
-    import gsplat
+    from gsplat.rendering import rasterization
     g = torch.Generator(device="cpu").manual_seed(3)
     N = scene.xyz.shape[0]
-    leaves = [scene.xyz.detach().clone().requires_grad_(True)]
-    kf = scene.keyframes[0]
-    pkg = None
-    from gsplat.rendering import rasterization
-    means = leaves[0]
+    means = scene.xyz.detach().clone().requires_grad_(True)
     quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g).to(dev), dim=-1)
     scales = (0.01 + 0.02 * torch.rand(N, 3, generator=g)).to(dev).requires_grad_(True)
     opac = (0.05 + 0.9 * torch.rand(N, generator=g)).to(dev).requires_grad_(True)
