@@ -356,9 +356,11 @@ extern "C" int adk_voxel_assign(const float* xyz, int64_t N, const float* new_xy
     const int hbits = bits_of(max_hash), cbits = N > 0 ? bits_of((unsigned long long)max_cls) : 0;
     const long long sy = (long long)(ny * nz), sz = (long long)nz;
     const float vs_arg = use_reciprocal ? 1.0f / voxel_size : voxel_size;
+    // layout: [old points' tables (N)] [tail: 256 B] [new points' tables (M)] -- the old points' part does not depend on M, so that
+    // adk_voxel_assign_new can come back to it with another batch of new points
     VoxWs wo = vox_carve(workspace, N);
-    VoxWs wn = vox_carve((char*)workspace + vox_ws_bytes(N), M);
-    uint32_t* tail = (uint32_t*)((char*)workspace + vox_ws_bytes(N) + vox_ws_bytes(M)); // [0] voxels, [1] pairs, [2] new voxels
+    uint32_t* tail = (uint32_t*)((char*)workspace + vox_ws_bytes(N)); // [0] voxels, [1] pairs, [2] new voxels
+    VoxWs wn = vox_carve((char*)workspace + vox_ws_bytes(N) + 256, M);
 
     if (N > 0) {
         const unsigned g = (unsigned)ceil_div(N, (int64_t)256);
@@ -384,6 +386,45 @@ extern "C" int adk_voxel_assign(const float* xyz, int64_t N, const float* new_xy
         inclusive_scan_u32(wn.pflag, M, wn.prank, wn.sums, tail + 2, stream);
         hipLaunchKernelGGL(vox_label_new_kernel, dim3(g), dim3(256), 0, stream, wn.idx, M, wn.vflag, wn.prank, wo.mode_key,
                            N > 0 ? max_cls + 1 : (int64_t)0, updated_new);
+        hipLaunchKernelGGL(vox_store_count_kernel, dim3(1), dim3(1), 0, stream, tail + 2, new_voxel_count);
+    } else {
+        hipLaunchKernelGGL(vox_store_count_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)nullptr, new_voxel_count);
+    }
+    ADK_RETURN_LAST_ERROR();
+}
+
+// Stage 2 again, for ANOTHER batch of new points against the SAME old points: the voxel table (distinct voxel hashes + each voxel's
+// majority class) that a previous adk_voxel_assign left in `workspace` is searched, nothing of the N old points is touched.
+// Valid only while everything that table was built from is unchanged -- xyz, cls_id, voxel_size, use_reciprocal, minc, nx / ny / nz,
+// max_cls (the caller compares the bounds of the new call with those of the first) -- and the workspace has not been written since.
+// SceneModel.add_new_gaussians calls update_voxel once per LoD level with the same map and, unless a level changed a label, the same
+// class ids (h3dgsv3.py:884-887): the 7 radix passes over the map's points are then needed once per frame, not four times.
+extern "C" int adk_voxel_assign_new(int64_t N, const float* new_xyz, int64_t M, float voxel_size, int use_reciprocal, const float* minc,
+                                    int64_t nx, int64_t ny, int64_t nz, int64_t max_cls, int64_t* updated_new, int64_t* new_voxel_count,
+                                    void* workspace, int64_t workspace_bytes, hipStream_t stream)
+{
+    using namespace adk;
+    if (N <= 0 || M < 0 || !(voxel_size > 0.f) || !minc || !new_voxel_count || !workspace) return ADK_EINVAL;
+    if (M > 0 && (!new_xyz || !updated_new)) return ADK_EINVAL;
+    if (nx <= 0 || ny <= 0 || nz <= 0 || N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 31)) return ADK_EINVAL;
+    if (workspace_bytes < adk_voxel_workspace_bytes(N, M) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
+    const long double cells = (long double)nx * (long double)ny * (long double)nz;
+    if (cells >= 9.0e18L || max_cls >= ((int64_t)1 << 31) || max_cls < 0) return ADK_EUNSUPPORTED;
+    const unsigned long long max_hash = (unsigned long long)nx * (unsigned long long)ny * (unsigned long long)nz - 1ull;
+    const int hbits = bits_of(max_hash);
+    const long long sy = (long long)(ny * nz), sz = (long long)nz;
+    const float vs_arg = use_reciprocal ? 1.0f / voxel_size : voxel_size;
+    VoxWs wo = vox_carve(workspace, N);
+    uint32_t* tail = (uint32_t*)((char*)workspace + vox_ws_bytes(N));
+    VoxWs wn = vox_carve((char*)workspace + vox_ws_bytes(N) + 256, M);
+    if (M > 0) {
+        const unsigned g = (unsigned)ceil_div(M, (int64_t)256);
+        hipLaunchKernelGGL(vox_hash_kernel, dim3(g), dim3(256), 0, stream, new_xyz, M, vs_arg, use_reciprocal, minc, sy, sz, wn.hash, wn.idx);
+        vox_sort_by_word(wn, M, 1, hbits < 32 ? hbits : 32, nullptr, stream);
+        vox_sort_by_word(wn, M, 2, hbits - 32, nullptr, stream);
+        hipLaunchKernelGGL(vox_match_new_kernel, dim3(g), dim3(256), 0, stream, wn.idx, M, wn.hash, wo.uniq_hash, tail + 0, wn.vflag, wn.pflag);
+        inclusive_scan_u32(wn.pflag, M, wn.prank, wn.sums, tail + 2, stream);
+        hipLaunchKernelGGL(vox_label_new_kernel, dim3(g), dim3(256), 0, stream, wn.idx, M, wn.vflag, wn.prank, wo.mode_key, max_cls + 1, updated_new);
         hipLaunchKernelGGL(vox_store_count_kernel, dim3(1), dim3(1), 0, stream, tail + 2, new_voxel_count);
     } else {
         hipLaunchKernelGGL(vox_store_count_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)nullptr, new_voxel_count);

@@ -16,6 +16,7 @@ scaling_reg_factor = 0 (dataloaders/args.py:90).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import types
 
@@ -771,13 +772,20 @@ def fused_weed_out_gaussians(self):
     self.optimizer.add_and_prune(self.make_dummy_ext_tensor(), weed_mask)
 
 
-def update_voxel_device(new_xyz: torch.Tensor, xyz: torch.Tensor, cls_id: torch.Tensor, voxel_size: float = 0.1, reciprocal: bool = True):
+def update_voxel_device(new_xyz: torch.Tensor, xyz: torch.Tensor, cls_id: torch.Tensor, voxel_size: float = 0.1, reciprocal: bool = True,
+                        table: dict | None = None):
     """SceneModel.update_voxel (h3dgsv3.py:227-316) on the device: the same three results -- (updated_orig_cls_id [N,1] int64,
     updated_new_cls_id [M,1] int64, new_voxel_count: int) -- or, with no old points (the cold start, :244-255),
-    (new_cls_id [M,1] int64, voxel_count: int).  Two small host reads (grid extents, the count) instead of the
+    (new_cls_id [M,1] int64, voxel_count: int).  Two small host reads (grid origin + extents, the count) instead of the
     reference's six-plus synchronising torch.unique / .item() / boolean-mask operations.
     reciprocal: round `(p - min) / voxel_size` the way torch's GPU kernel does (multiply by the fp32 reciprocal; default, it is
-    GPU code that is being replaced) or with a true division like torch's CPU kernel (what the CPU-generated goldens used)."""
+    GPU code that is being replaced) or with a true division like torch's CPU kernel (what the CPU-generated goldens used).
+    table: a dict the CALLER keeps across consecutive calls with the same old points (add_new_gaussians: one call per LoD level,
+    h3dgsv3.py:884-887).  The first call leaves the old points' voxel table (distinct voxels + each voxel's majority class) in a
+    workspace of its own there.  A later call whose `cls_id` IS that call's `updated_orig` and whose grid origin / extents are the
+    same only looks the new points up (adk_voxel_assign_new) and returns the same `updated_orig` tensor: relabelling is idempotent
+    on a fixed grid -- every point of a voxel already carries the voxel's majority class, so the vote, the table and the labels
+    come out as they went in -- and the map's points are hashed and sorted once per frame instead of once per level."""
     lib = _lib.load()
     _lib.require_cuda(new_xyz)
     dev = new_xyz.device
@@ -794,16 +802,47 @@ def update_voxel_device(new_xyz: torch.Tensor, xyz: torch.Tensor, cls_id: torch.
         small = torch.empty(64, dtype=torch.uint8, device=dev)
         _lib.check(lib.adk_voxel_bounds(_lib.ptr(ox_), N, nx_.data_ptr() if M else None, M, _lib.ptr(cls), float(voxel_size), int(bool(reciprocal)), minc.data_ptr(),
                                         info.data_ptr(), small.data_ptr(), small.numel(), st), "adk_voxel_bounds")
-        gx, gy, gz, max_cls = (int(v) for v in info.tolist())      # host read 1: decides the number of radix passes
-        upd_o = torch.empty(N, dtype=torch.int64, device=dev)
+        if table is None or not N:
+            gx, gy, gz, max_cls = (int(v) for v in info.tolist())  # host read 1: decides the number of radix passes
+            grid = None
+        else:                                                       # the same read, with the grid origin (as its bit pattern) next to it
+            vals = torch.cat([info, minc.view(torch.int32).to(torch.int64)]).tolist()
+            gx, gy, gz, max_cls = (int(v) for v in vals[:4])
+            grid = (N, ox_.data_ptr(), float(voxel_size), bool(reciprocal), gx, gy, gz, *vals[4:])   # (the largest class only numbers NEW voxels)
         upd_n = torch.empty(M, dtype=torch.int64, device=dev)
         count = torch.empty(1, dtype=torch.int64, device=dev)
-        ws = _WS.get(dev, int(lib.adk_voxel_workspace_bytes(N, M)) + 256)
-        base = (ws.data_ptr() + 255) & ~255
-        _lib.check(lib.adk_voxel_assign(_lib.ptr(ox_), N, nx_.data_ptr() if M else None, M, _lib.ptr(cls), float(voxel_size), int(bool(reciprocal)), minc.data_ptr(),
-                                        gx, gy, gz, max_cls, upd_o.data_ptr() if N else None, upd_n.data_ptr() if M else None,
-                                        count.data_ptr(), base, ws.numel() - (base - ws.data_ptr()), st), "adk_voxel_assign")
+        reuse = (grid is not None and table.get("grid") == grid and table.get("updated_orig") is not None
+                 and table["updated_orig"].data_ptr() == cls.data_ptr())   # the table keeps that tensor alive: same address = same tensor
+        if reuse:
+            ws, upd_o = table["ws"], table["updated_orig"]
+            base = (ws.data_ptr() + 255) & ~255
+            if ws.numel() - (base - ws.data_ptr()) < int(lib.adk_voxel_workspace_bytes(N, M)):   # the table lives at the front: a longer
+                ws2 = torch.empty(int(lib.adk_voxel_workspace_bytes(N, M)) + 256, dtype=torch.uint8, device=dev)   # tail needs a larger block
+                base2 = (ws2.data_ptr() + 255) & ~255
+                keep = int(lib.adk_voxel_workspace_bytes(N, 0))
+                ws2[base2 - ws2.data_ptr(): base2 - ws2.data_ptr() + keep].copy_(ws[base - ws.data_ptr(): base - ws.data_ptr() + keep])
+                table["ws"], ws, base = ws2, ws2, base2
+            _lib.check(lib.adk_voxel_assign_new(N, nx_.data_ptr() if M else None, M, float(voxel_size), int(bool(reciprocal)), minc.data_ptr(),
+                                                gx, gy, gz, max_cls, upd_n.data_ptr() if M else None, count.data_ptr(), base,
+                                                ws.numel() - (base - ws.data_ptr()), st), "adk_voxel_assign_new")
+        else:
+            upd_o = torch.empty(N, dtype=torch.int64, device=dev)
+            if grid is not None:   # a workspace of this table's own: the shared scratch is rewritten by the renders between the levels
+                need = int(lib.adk_voxel_workspace_bytes(N, max(M, 1 << 16))) + 256
+                ws = table.get("ws")
+                if ws is None or ws.numel() < need or ws.device != dev:
+                    ws = table["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            else:
+                ws = _WS.get(dev, int(lib.adk_voxel_workspace_bytes(N, M)) + 256)
+            base = (ws.data_ptr() + 255) & ~255
+            _lib.check(lib.adk_voxel_assign(_lib.ptr(ox_), N, nx_.data_ptr() if M else None, M, _lib.ptr(cls), float(voxel_size), int(bool(reciprocal)), minc.data_ptr(),
+                                            gx, gy, gz, max_cls, upd_o.data_ptr() if N else None, upd_n.data_ptr() if M else None,
+                                            count.data_ptr(), base, ws.numel() - (base - ws.data_ptr()), st), "adk_voxel_assign")
+            if grid is not None:
+                table.update(grid=grid, updated_orig=upd_o)
         n_new = int(count.item())                                    # host read 2: sizes global_feat (h3dgsv3.py:888)
+    if table is not None:
+        table["reused"] = bool(reuse)
     if N == 0:
         return upd_n.unsqueeze(-1), n_new
     return upd_o.unsqueeze(-1), upd_n.unsqueeze(-1), n_new
@@ -816,7 +855,7 @@ def fused_update_voxel(self, new_xyz, xyz, cls_id, voxel_size=0.1):
     if unfused is not None and not (torch.is_tensor(new_xyz) and new_xyz.is_cuda):
         return unfused(new_xyz, xyz, cls_id, voxel_size)
     try:
-        return update_voxel_device(new_xyz, xyz, cls_id, voxel_size)
+        return update_voxel_device(new_xyz, xyz, cls_id, voxel_size, table=getattr(self, "_voxel_table", None))
     except _lib.AdkError as e:
         if unfused is None or "ADK_EUNSUPPORTED" not in str(e):
             raise
@@ -829,6 +868,17 @@ def _quantile_rank(n: int, q: float):
     rank = np.float32(q) * np.float32(n - 1)
     lo = int(np.floor(rank))
     return lo, float(np.float32(rank - np.float32(lo)))
+
+
+@contextlib.contextmanager
+def _voxel_table_scope(scene):
+    """scene._voxel_table = {} for the duration of one add_new_gaussians call: where update_voxel_device keeps the map's voxel table
+    between the LoD levels (fused_update_voxel hands it over); gone again whatever happens inside."""
+    scene._voxel_table = {}
+    try:
+        yield scene._voxel_table
+    finally:
+        scene._voxel_table = None
 
 
 @torch.no_grad()
@@ -857,7 +907,7 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
     ratio = float(getattr(args, "gs_add_ratio"))
     voxel_size = float(getattr(args, "voxel_size"))
     L_dim, G_dim = int(getattr(args, "local_feat_dim")), int(getattr(args, "global_feat_dim"))
-    with _lib.on_device(dev):
+    with _lib.on_device(dev), _voxel_table_scope(self) as voxel_table:
         st = _lib.raw_stream(dev)
         f32 = dict(dtype=torch.float32, device=dev)
         img0 = img0.contiguous()
@@ -925,7 +975,10 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
             if len(self.xyz) > 0:
                 prev_cls = self.cls_id
                 upd, new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)
-                labels_changed = (upd != prev_cls).any() if upd.shape == prev_cls.shape else None
+                if voxel_table.get("reused"):
+                    labels_changed = False      # the table of the previous level answered: `upd` IS the previous level's tensor
+                else:
+                    labels_changed = (upd != prev_cls).any() if upd.shape == prev_cls.shape else None
                 self.gaussian_params["cls_id"]["val"] = upd
             else:
                 new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 13
+#define ADK_ABI_VERSION 14
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -437,6 +437,13 @@ int adk_voxel_assign(const float* xyz, int64_t N, const float* new_xyz, int64_t 
                      float voxel_size, int use_reciprocal, const float* minc, int64_t nx, int64_t ny, int64_t nz, int64_t max_cls,
                      int64_t* updated_orig, int64_t* updated_new, int64_t* new_voxel_count, void* workspace,
                      int64_t workspace_bytes, adk_stream_t stream);
+/* Stage 2 for ANOTHER batch of new points against the same old points (the next LoD level of add_new_gaussians, :884-887 inside
+ * the loop of :775): searches the voxel table a previous adk_voxel_assign left in `workspace` (same N, same workspace, not written
+ * in between) instead of rebuilding it.  Valid while xyz, cls_id, voxel_size, use_reciprocal, minc, nx / ny / nz and max_cls are
+ * those of that call -- the caller checks the new batch's adk_voxel_bounds against them; updated_orig of that call still holds. */
+int adk_voxel_assign_new(int64_t N, const float* new_xyz, int64_t M, float voxel_size, int use_reciprocal, const float* minc,
+                         int64_t nx, int64_t ny, int64_t nz, int64_t max_cls, int64_t* updated_new, int64_t* new_voxel_count,
+                         void* workspace, int64_t workspace_bytes, adk_stream_t stream);
 
 /* ------------------------------------------- mast3r_slam_backends: Gauss-Newton
  * Replaces gauss_newton_points / gauss_newton_rays / gauss_newton_calib --

@@ -88,3 +88,49 @@ def test_device_update_voxel_equals_the_torch_chain_on_the_gpu(dev):
     a = torch_chain(t(new), t(xyz), t(cls), vs)
     b = fused.update_voxel_device(t(new), t(xyz), t(cls), vs)
     assert a[2] == b[2] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,vs,wide", [(1_000_000, 0.1, False), (300_000, 0.004, True)])
+def test_device_update_voxel_table_reuse_across_lod_levels(N, vs, wide, dev):
+    """add_new_gaussians calls update_voxel once per LoD level with the same map (h3dgsv3.py:884-887).  With a `table` the first call
+    leaves the map's voxel table behind and later calls only look the new points up (adk_voxel_assign_new) -- when the class ids are
+    the table-building call's own output and the grid is the same (relabelling is idempotent on a fixed grid).  Every call must
+    return what a call without the table returns; a batch that moves the grid origin, or another class tensor, must take the full
+    path by itself."""
+    import torch
+    from artdeco_amd import fused
+    import time
+    rng = np.random.default_rng(N)
+    span = 40.0 if wide else 6.0
+    centres = rng.uniform(-span, span, (400, 3))
+    pts = lambda k: (centres[rng.integers(0, 400, k)] + 0.4 * rng.standard_normal((k, 3))).astype(np.float32)
+    xyz = torch.from_numpy(pts(N)).to(dev)
+    cls0 = torch.from_numpy(rng.integers(0, max(N // 10, 1), (N, 1)).astype(np.int64)).to(dev)
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    inside = lambda k: (lo + (hi - lo) * torch.from_numpy(rng.uniform(0.05, 0.95, (k, 3)).astype(np.float32)).to(dev)).contiguous()
+    # level 0 relabels the map (random labels -> majority per voxel) and builds the table; from level 1 on the labels are its output
+    cls, table, reused, t_full, t_reuse = cls0, {}, [], [], []
+    batches = [inside(50_000), inside(20_000), inside(120_000), inside(5_000), torch.cat([inside(1_000), (lo - 1.0)[None]]), inside(3_000), inside(2_000),
+               inside(0)]
+    box = lambda new: (tuple(torch.minimum(lo, new.min(0).values).tolist()), tuple(torch.maximum(hi, new.max(0).values).tolist())) if len(new) else (tuple(lo.tolist()), tuple(hi.tolist()))
+    expected, table_box = [], None
+    for level, new in enumerate(batches):
+        ref_o, ref_n, ref_c = fused.update_voxel_device(new, xyz, cls, vs)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        got_o, got_n, got_c = fused.update_voxel_device(new, xyz, cls, vs, table=table)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+        assert got_c == ref_c and torch.equal(got_o, ref_o) and torch.equal(got_n, ref_n), level
+        expected.append(box(new) == table_box)     # the labels are the table-building call's output by construction: same grid = reuse
+        if not expected[-1]:
+            table_box = box(new)
+        reused.append(table["reused"])
+        (t_reuse if table["reused"] else t_full).append(dt)
+        cls = got_o
+    # level 0 builds (and replaces the random labels by majorities), 1-3 reuse (incl. a batch larger than the first: the workspace
+    # grows), 4 rebuilds (a point outside the map's box moves the grid origin), 5 rebuilds (the origin is back), 6-7 reuse
+    assert reused == expected == [False, True, True, True, False, False, True, True], (reused, expected)
+    print(f"update_voxel at {N}: full {np.mean(t_full):.3f} ms, table reused {np.mean(t_reuse):.3f} ms")
+    # a DIFFERENT class tensor (even with equal values) never hits the table
+    fused.update_voxel_device(batches[1], xyz, cls.clone(), vs, table=table)
+    assert table["reused"] is False
