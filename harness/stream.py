@@ -100,6 +100,20 @@ def make_keyframe(scene, frame, index, is_test=False, pyr_levels=1):
 
 
 @torch.no_grad()
+def slam_pose_update_batched(scene, delta=1e-4, seed=0):
+    """slam_pose_update with the per-keyframe loop replaced by artdeco_amd.keyframe_poses.update_keyframe_poses: what the loop of
+    run_system.py:194-227 costs once a maintainer batches it (NOT what `value` times: the headline keeps ARTDECO's loop)."""
+    from artdeco_amd.keyframe_poses import _world_to_camera, update_keyframe_poses
+    dev = scene.device
+    g = torch.Generator().manual_seed(seed)
+    shifts = (delta * torch.randn(len(scene.keyframes), 3, generator=g)).to(dev)
+    new_Rts = _world_to_camera(torch.stack([kf.rW2C.data for kf in scene.keyframes]), torch.stack([kf.tW2C.data for kf in scene.keyframes]))
+    new_Rts[:, :3, 3] += shifts          # the new poses come from the SLAM graph in one tensor (here: the old ones, moved)
+    old_c2ws, new_c2ws, cam_centres = update_keyframe_poses(scene.keyframes, new_Rts)
+    scene.rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)
+
+
+@torch.no_grad()
 def slam_pose_update(scene, delta=1e-4, seed=0):
     """run_system.py:194-227: on a SLAM keyframe every mapper keyframe's pose is re-read from the (just optimised) SLAM graph and set,
     and the old / new camera-to-world matrices are collected keyframe by keyframe for rigid_transform_gs.  The new poses here are
@@ -158,12 +172,12 @@ class StageClock:
                 for k, v in self.t.items()}
 
 
-def run_frame(scene, frame, index, flags, clock, *, num_key_iterations=20, num_common_iterations=10, pyr_levels=1):
+def run_frame(scene, frame, index, flags, clock, *, num_key_iterations=20, num_common_iterations=10, pyr_levels=1, batched_slam_update=False):
     with clock("keyframe_build"):
         kf = make_keyframe(scene, frame, index, is_test=flags["is_test"], pyr_levels=pyr_levels)
     if flags["is_slam_keyframe"] and index > 0 and scene.keyframes:
         with clock("rigid_transform_gs"):
-            slam_pose_update(scene, seed=index)
+            (slam_pose_update_batched if batched_slam_update else slam_pose_update)(scene, seed=index)
     with clock("add_keyframe"):
         scene.add_keyframe(kf)
     if flags["is_important"]:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Wall time of every frame of the mapper loop on a fresh scene (one device synchronisation per frame): where one-off costs land.
-    python tools/lab/frame_series.py N MAP_W MAP_H [PYR_LEVELS] [FRAMES]"""
+    python tools/lab/frame_series.py N MAP_W MAP_H [PYR_LEVELS] [FRAMES]
+BATCHED=1: the SLAM-keyframe pose re-read through artdeco_amd.keyframe_poses.update_keyframe_poses instead of run_system.py's per-keyframe loop."""
 import os
 import sys
 import time
@@ -30,7 +31,7 @@ for i, fr in enumerate(frames):
     fl = stream.frame_flags(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = stream.run_frame(scene, fr, len(scene.keyframes), fl, clock, pyr_levels=pyr)
+    steps = stream.run_frame(scene, fr, len(scene.keyframes), fl, clock, pyr_levels=pyr, batched_slam_update=os.environ.get('BATCHED', '0') == '1')
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
     tag = ("S" if fl["is_slam_keyframe"] and i > 0 else "-") + ("I" if fl["is_important"] else "-") + ("T" if fl["is_test"] else "-")
