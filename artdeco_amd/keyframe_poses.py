@@ -50,8 +50,13 @@ def update_keyframe_poses(keyframes, new_Rts: torch.Tensor):
     old_c2ws = torch.linalg.inv(old_Rt)
     new_c2ws = torch.linalg.inv(new_Rts)
     # set_Rt for every keyframe: two multi-tensor copies instead of 2 K single ones, one batched -R^T t
-    torch._foreach_copy_(r6, list(new_Rts[:, :3, :2].unbind(0)))
-    torch._foreach_copy_(t, list(new_Rts[:, :3, 3].unbind(0)))
+    if hasattr(torch, "_foreach_copy_"):
+        torch._foreach_copy_(r6, list(new_Rts[:, :3, :2].unbind(0)))
+        torch._foreach_copy_(t, list(new_Rts[:, :3, 3].unbind(0)))
+    else:                                   # older torch: the 2 K single copies set_Rt would issue
+        for dst_r, dst_t, m in zip(r6, t, new_Rts.unbind(0)):
+            dst_r.copy_(m[:3, :2])
+            dst_t.copy_(m[:3, 3])
     approx = -torch.bmm(new_Rts[:, :3, :3].transpose(1, 2), new_Rts[:, :3, 3:4])[:, :, 0]
     for kf, c in zip(keyframes, approx.unbind(0)):
         kf.approx_centre = c

@@ -106,7 +106,7 @@ def slam_pose_update_batched(scene, delta=1e-4, seed=0):
     from artdeco_amd.keyframe_poses import _world_to_camera, update_keyframe_poses
     dev = scene.device
     g = torch.Generator().manual_seed(seed)
-    shifts = (delta * torch.randn(len(scene.keyframes), 3, generator=g)).to(dev)
+    shifts = torch.stack([delta * torch.randn(3, generator=g) for _ in scene.keyframes]).to(dev)   # the loop's draws, in its order
     new_Rts = _world_to_camera(torch.stack([kf.rW2C.data for kf in scene.keyframes]), torch.stack([kf.tW2C.data for kf in scene.keyframes]))
     new_Rts[:, :3, 3] += shifts          # the new poses come from the SLAM graph in one tensor (here: the old ones, moved)
     old_c2ws, new_c2ws, cam_centres = update_keyframe_poses(scene.keyframes, new_Rts)

@@ -72,3 +72,31 @@ def test_batched_pose_reread_with_no_keyframes():
     from artdeco_amd.keyframe_poses import update_keyframe_poses
     o, n, c = update_keyframe_poses([], torch.zeros(0, 4, 4))
     assert o.shape == (0, 4, 4) and n.shape == (0, 4, 4) and c.shape == (0, 3)
+
+
+@pytest.mark.gpu
+def test_batched_pose_reread_on_the_device_feeds_rigid_transform_gs():
+    """The helper on device tensors, through the harness' frame loop: a stream whose SLAM keyframes use the batched re-read ends with
+    the same keyframe poses and (to the inverse's rounding) the same moved Gaussians as one that runs run_system.py's loop."""
+    import numpy as np
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    from artdeco_amd import fused
+    from harness import mapper, stream
+    dev = torch.device("cuda:0")
+    out = []
+    for batched in (False, True):
+        scene = mapper.build_synthetic_mapper(3_000, 96, 64, dev, seed=2, n_keyframes=0, targets="random")
+        fused.patch_scene_model(scene)
+        frames = stream.synthetic_frames(scene, 4, seed=2, slam_hw=(48, 64))
+        clock = stream.StageClock(False)
+        for i, fr in enumerate(frames):            # keyframes only, no optimisation: the two runs see identical maps
+            scene.add_keyframe(stream.make_keyframe(scene, fr, i))
+        xyz0 = scene.xyz.detach().clone()
+        (stream.slam_pose_update_batched if batched else stream.slam_pose_update)(scene, delta=1e-2, seed=9)
+        out.append((torch.stack([kf.get_Rt().detach() for kf in scene.keyframes]), scene.xyz.detach().clone(), scene.rotation.detach().clone(),
+                    scene.cam_centres.clone(), xyz0))
+    (Rt_a, xyz_a, rot_a, cc_a, xyz0), (Rt_b, xyz_b, rot_b, cc_b, _) = out
+    assert float((xyz_a - xyz0).abs().max()) > 1e-3          # the update moved the map
+    assert torch.allclose(Rt_a, Rt_b, atol=1e-6) and torch.allclose(cc_a, cc_b, atol=1e-5)
+    assert torch.allclose(xyz_a, xyz_b, atol=1e-5) and torch.allclose(rot_a, rot_b, atol=1e-5)
