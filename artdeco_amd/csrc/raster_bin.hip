@@ -409,6 +409,119 @@ __global__ __launch_bounds__(256) void bin_tile_sort_wave_kernel(const unsigned 
     else wave_sort_tile<16>(pairs, s, n, lane, (uint32_t)t, flatten_ids, tile_ids);
 }
 
+// ---- lists of 1025 .. 8192 entries, first choice (round 3): split the list into 16 KEY-ORDERED buckets, two per wave, each sorted in
+// registers.  The merge below pads such a list to the next power of two (4 700 keys -> 8 192 slots), sorts every 1 024-slot chunk and
+// then pays three more merge stages with LDS exchanges: ~100 compare-exchange stages per wave, 96 us for the 768 tiles of the 1 M /
+// 512x384 frame -- VALU-bound (61 M wave instructions).  Buckets that partition the KEY RANGE make the buckets' sorted runs concatenate
+// into the sorted list with no merge at all (a sample sort): wave 0 sorts a strided sample of 256 keys in registers, every 16th of them
+// is a splitter, and a key's bucket is the number of splitters not above it -- balanced whatever the depth distribution is
+// (equal-width depth buckets were tried first: a cloud that fills a frustum has twice the tile's average in its farthest eighth, and
+// every tile of the bench frame overflowed).  What goes to LDS is the key's POSITION in the tile's segment (4 B, 16 regions of 1 000:
+// 64 KB hold any list up to 8 192 keys whose buckets stay within twice their mean); slots are handed out per wave -- one ballot per
+// bucket, lanes 0 .. 15 add the counts to the buckets' counters with ONE conflict-free LDS atomic per key slot, a lane's position is
+// the returned base plus its rank among the wave's lanes of that bucket (one returning atomic per key, 64 lanes on 8 addresses,
+// serialises: 0.10 -> 0.16 ms for the frame).  Wave w then sorts buckets 2 w and 2 w + 1 with the smallest network that holds each
+// (128 .. 1 024 slots) and writes them behind the buckets before them.  A tile with a bucket over its region writes
+// BIN_BUCKET_GAVE_UP into its first output slot and is left to the merge kernel, which runs after this one on exactly those tiles.
+// Unique keys => the same list, bit for bit.
+#define BIN_BUCKETS 16               // at most; lists of up to BIN_BUCKET_FEW_N keys take 8 (one per wave: fewer ballots, one network per wave)
+#define BIN_BUCKET_FEW_N 3584
+#define BIN_BUCKET_CAP 1000          // 16 x 1000 positions x 4 B + splitters + counters stay below the 64 KB a workgroup may declare statically
+#define BIN_BUCKET_GAVE_UP (-1)
+template <int E>
+__device__ __forceinline__ void wave_sort_bucket(const unsigned long long* __restrict__ seg, const uint32_t* __restrict__ region, int n, int64_t out,
+                                                 int lane, uint32_t t, int32_t* __restrict__ flatten_ids, uint32_t* __restrict__ tile_ids)
+{
+    unsigned long long v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) { const int i = lane * E + r; v[r] = i < n ? seg[region[i]] : ~0ull; }
+    BitonicStage<E, 2>::run(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = lane * E + r;
+        if (i < n) { flatten_ids[out + i] = (int32_t)(uint32_t)v[r]; if (tile_ids) tile_ids[out + i] = t; }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void sort_tile_by_buckets(const unsigned long long* __restrict__ seg, int n, int64_t s, int t, uint32_t* sk,
+                                                     unsigned long long* split, uint32_t* cnt, int32_t* __restrict__ flatten_ids,
+                                                     uint32_t* __restrict__ tile_ids)
+{
+    const int tid = threadIdx.x, c = tid >> 6, lane = tid & 63;
+    if (tid < NB) cnt[tid] = 0u;
+    constexpr int PER = BIN_SORT_BIG / 512;
+    unsigned long long k[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { const int i = r * 512 + tid; k[r] = i < n ? seg[i] : ~0ull; }
+    if (c == 0) { // splitters: 256 keys taken at equal strides through the list, sorted by this wave; every 16th one splits
+        unsigned long long v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = seg[(int)(((int64_t)(lane * 4 + r) * n) >> 8)];
+        BitonicStage<4, 2>::run(v, lane);
+        constexpr int EVERY = 64 / NB; // lanes per splitter: sorted position 4 lane = (256 / NB) (lane / EVERY)
+        if ((lane % EVERY) == 0 && lane > 0) split[lane / EVERY] = v[0];
+    }
+    __syncthreads();
+    bool lost = false;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const int i = r * 512 + tid;
+        if (r * 512 + (c << 6) >= n) break; // wave-uniform: nothing of this wave's slot r is inside the list
+        const bool have = i < n;
+        int b = 0; // number of splitters <= key, by bisection over the sorted splitters (LDS broadcast-ish reads)
+#pragma unroll
+        for (int step = NB / 2; step >= 1; step >>= 1) b += (k[r] >= split[b + step]) ? step : 0;
+        uint32_t mine = 0u, rank = 0u;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const unsigned long long m = __ballot(have && b == q);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            rank = (b == q) ? below : rank;
+            mine = (lane == q) ? (uint32_t)__popcll(m) : mine;
+        }
+        uint32_t base = 0u;
+        if (lane < NB && mine) base = atomicAdd(&cnt[lane], mine);
+        const uint32_t pos = (uint32_t)__shfl((int)base, b, 64) + rank;
+        if (have) { if (pos < BIN_BUCKET_CAP) sk[b * BIN_BUCKET_CAP + pos] = (uint32_t)i; else lost = true; }
+    }
+    if (__syncthreads_or(lost)) { // a bucket is over its region: the merge kernel takes this tile
+        if (tid == 0) flatten_ids[s] = BIN_BUCKET_GAVE_UP;
+        return;
+    }
+    constexpr int PW = NB / 8; // buckets per wave
+    int before = 0;
+    for (int b = 0; b < PW * c; ++b) before += (int)cnt[b];
+#pragma unroll
+    for (int h = 0; h < PW; ++h) {
+        const int bk = PW * c + h;
+        const int nb = (int)cnt[bk];
+        const uint32_t* region = sk + bk * BIN_BUCKET_CAP;
+        if (nb <= 128) wave_sort_bucket<2>(seg, region, nb, s + before, lane, (uint32_t)t, flatten_ids, tile_ids);
+        else if (nb <= 256) wave_sort_bucket<4>(seg, region, nb, s + before, lane, (uint32_t)t, flatten_ids, tile_ids);
+        else if (nb <= 512) wave_sort_bucket<8>(seg, region, nb, s + before, lane, (uint32_t)t, flatten_ids, tile_ids);
+        else wave_sort_bucket<16>(seg, region, nb, s + before, lane, (uint32_t)t, flatten_ids, tile_ids);
+        before += nb;
+    }
+}
+
+__global__ __launch_bounds__(512) void bin_tile_sort_bucket_kernel(const unsigned long long* __restrict__ pairs, const int32_t* __restrict__ offsets,
+                                                                   int n_tiles, int64_t n_isects, int32_t* __restrict__ flatten_ids,
+                                                                   uint32_t* __restrict__ tile_ids, int max_n)
+{
+    __shared__ uint32_t sk[BIN_BUCKETS * BIN_BUCKET_CAP];
+    __shared__ unsigned long long split[BIN_BUCKETS];   // split[1 .. NB - 1]: bucket b holds the keys in [split[b], split[b + 1])
+    __shared__ uint32_t cnt[BIN_BUCKETS];
+    const int t = blockIdx.x;
+    const int64_t s = offsets[t];
+    const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
+    const int n = (int)(e - s);
+    if (n <= BIN_SORT_WAVE || n > BIN_SORT_BIG) return; // workgroup-uniform
+    if (n > max_n) { if (threadIdx.x == 0) flatten_ids[s] = BIN_BUCKET_GAVE_UP; return; }
+    if (n <= BIN_BUCKET_FEW_N) sort_tile_by_buckets<8>(pairs + s, n, s, t, sk, split, cnt, flatten_ids, tile_ids);
+    else sort_tile_by_buckets<16>(pairs + s, n, s, t, sk, split, cnt, flatten_ids, tile_ids);
+}
+
 // ---- lists of 1025 .. 8192 entries (1 M Gaussians on a 512x384 frame: every tile): the SAME register network, 1024 keys per wave,
 // up to 8 waves per tile.  Wave c sorts chunk c in registers -- ascending for even c, descending for odd c (the ascending network run
 // on the bitwise complements), i.e. exactly the state a 64 x 16 x C bitonic network is in after its K = 1024 stage; the remaining
@@ -418,7 +531,7 @@ __global__ __launch_bounds__(256) void bin_tile_sort_wave_kernel(const unsigned 
 // 768 tiles of that frame -- 20 % of the mapper step.
 __global__ __launch_bounds__(512) void bin_tile_sort_merge_kernel(const unsigned long long* __restrict__ pairs, const int32_t* __restrict__ offsets,
                                                                   int n_tiles, int64_t n_isects, int32_t* __restrict__ flatten_ids,
-                                                                  uint32_t* __restrict__ tile_ids)
+                                                                  uint32_t* __restrict__ tile_ids, int only_flagged)
 {
     constexpr int E = 16, CH = 64 * E; // keys per lane, keys per wave
     __shared__ unsigned long long sk[BIN_SORT_BIG];
@@ -427,6 +540,7 @@ __global__ __launch_bounds__(512) void bin_tile_sort_merge_kernel(const unsigned
     const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
     const int n = (int)(e - s);
     if (n <= BIN_SORT_WAVE || n > BIN_SORT_BIG) return; // workgroup-uniform
+    if (only_flagged && flatten_ids[s] != BIN_BUCKET_GAVE_UP) return; // bin_tile_sort_bucket_kernel sorted this tile (ids are >= 0)
     int m = 2 * CH;
     while (m < n) m <<= 1;
     const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -681,9 +795,16 @@ extern "C" int adk_bin_local_sort_t(int64_t n_isects, int64_t max_tile, int widt
     const int n_tiles = g.wide_w * g.wide_h;
     hipLaunchKernelGGL(bin_tile_sort_wave_kernel, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, stream, (const unsigned long long*)pairs,
                        offsets, n_tiles, n_isects, flatten_ids, tile_ids);
-    if (max_tile > BIN_SORT_WAVE)
+    if (max_tile > BIN_SORT_WAVE) {
+        const char* env = getenv("ADK_BIN_BUCKET_SORT");   // "0": every long list through the merge kernel; "<n>": lists above n keys (A/B, tests)
+        const int max_n = env ? min(atoi(env), BIN_SORT_BIG) : BIN_SORT_BIG;
+        const int buckets = max_n > BIN_SORT_WAVE;
+        if (buckets)
+            hipLaunchKernelGGL(bin_tile_sort_bucket_kernel, dim3(n_tiles), dim3(512), 0, stream, (const unsigned long long*)pairs, offsets,
+                               n_tiles, n_isects, flatten_ids, tile_ids, max_n);
         hipLaunchKernelGGL(bin_tile_sort_merge_kernel, dim3(n_tiles), dim3(512), 0, stream, (const unsigned long long*)pairs, offsets,
-                           n_tiles, n_isects, flatten_ids, tile_ids);
+                           n_tiles, n_isects, flatten_ids, tile_ids, buckets);
+    }
     ADK_RETURN_LAST_ERROR();
 }
 extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets, const void* pairs,

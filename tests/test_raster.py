@@ -495,3 +495,39 @@ def test_waves_per_tile_forms_report_the_same_main_gaussian(W, H, dev, monkeypat
     for other in outs[1:]:
         for x, y in zip(outs[0], other):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["uniform", "shell"])
+def test_long_tile_lists_bucket_sort_equals_merge_sort_and_the_global_route(case, dev, monkeypatch):
+    """Tile lists of 1 025 .. 6 400 entries (1 M Gaussians on a 512x384 frame: every tile) are split into 8 key-ordered buckets by
+    sampled splitters and one wave sorts each bucket in registers (bin_tile_sort_bucket_kernel); longer lists, and tiles whose bucket
+    overflows all the same, are left to the chunk-merge sort.  Every way -- buckets (default), buckets only below 3 000 keys (so that
+    one frame takes BOTH paths), merge only (ADK_BIN_BUCKET_SORT=0), the global radix route (ADK_BIN_LOCAL=0) -- must produce the same
+    bytes.  "shell": 85 % of the cloud inside a 1 %-thick depth shell plus a sparse far tail (what broke equal-width depth buckets)."""
+    N, W, H = 1_000_000, 512, 384
+    sc = dict(_scene(N, W, H, 7), viewmat=_tilted_viewmat(2))
+    if case == "shell":
+        g = torch.Generator().manual_seed(11)
+        means = sc["means"].clone()
+        V = torch.as_tensor(sc["viewmat"], dtype=torch.float32)
+        cam = means @ V[:3, :3].T + V[:3, 3]
+        shell = torch.rand(N, generator=g) < 0.85
+        z_new = 3.0 * (1.0 + 0.01 * torch.rand(N, generator=g))
+        cam[shell] = cam[shell] * (z_new[shell] / cam[shell, 2].clamp_min(1e-3))[:, None]      # same pixel, depth moved into the shell
+        far = (~shell) & (torch.rand(N, generator=g) < 0.3)
+        cam[far] = cam[far] * 6.0                                                               # a sparse far tail that stretches the range
+        sc["means"] = ((cam - V[:3, 3]) @ V[:3, :3]).contiguous()
+    outs = {}
+    for name, env in (("buckets", {}), ("both", {"ADK_BIN_BUCKET_SORT": "3000"}), ("merge", {"ADK_BIN_BUCKET_SORT": "0"}), ("global", {"ADK_BIN_LOCAL": "0"})):
+        for k in ("ADK_BIN_BUCKET_SORT", "ADK_BIN_LOCAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = _binning_outputs(_run_hip(sc, dev)[2])
+    counts = np.diff(np.append(outs["global"]["isect_offsets"].reshape(-1), outs["global"]["flatten_ids"].size))
+    assert counts.max() <= 8192 and (counts > 1024).mean() > 0.5, (counts.max(), (counts > 1024).mean())
+    assert ((counts > 1024) & (counts <= 3000)).any() and (counts > 3000).any()    # "both" really takes both paths
+    for name in ("buckets", "both", "merge"):
+        for k, ref in outs["global"].items():
+            assert np.array_equal(outs[name][k], ref), (case, name, k)
