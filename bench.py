@@ -341,7 +341,7 @@ def roofline_stages(stages, N, V, I, P, W, H):
     counted = [k for k in out]
     tot_b = sum(alg[k] for k in counted)
     tot_ms = sum(v["mean_ms"] for k, v in stages.items() if k not in ("binning",))
-    if tot_ms > 0:
+    if tot_ms > 0 and "raster_fwd" in ms:   # N > 1 runs time raster_bwd only: no whole-step line from one stage
         out["whole_step"] = {"alg_bytes": tot_b, "ms_sum_of_stages": round(tot_ms, 4), "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
                              "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "algorithmic bytes of the stages listed here / the sum of ALL stage times of one optimisation step"}
