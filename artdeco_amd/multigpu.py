@@ -52,6 +52,8 @@ def barrier(device: torch.device | None = None) -> None:
 def aggregate(elapsed_s: float, sums: dict[str, float], device: torch.device) -> tuple[float, dict[str, float]]:
     """MAX over ranks of the elapsed time, SUM over ranks of the additive metrics."""
     keys = sorted(sums)
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        device = torch.device("cpu")            # gloo reduces host tensors; 64 bytes either way
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     v = torch.tensor([float(sums[k]) for k in keys], dtype=torch.float64, device=device)
     if dist.is_initialized():

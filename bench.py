@@ -186,8 +186,11 @@ def main():
         return cpu_dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ARTDECO_BENCH_SHARE_GPU=1 (development only, with --backend gloo): ranks beyond the visible GPUs share them, so that the N > 1
+    # code path can be driven on a one-GPU box; the driver's multi-GPU runs never set it
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("ARTDECO_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     from artdeco_amd import _lib, multigpu, rasterizer
     from harness import mapper
     multigpu.init(args.backend, dev)  # nccl = RCCL over xGMI; used for the barrier + the metric all-reduce only
