@@ -37,9 +37,14 @@ import torch.multiprocessing as mp
 ROUNDS = ("mapper_alone", "frontend_alone", "backend_alone", "together")
 
 
-def _wait_for(counter, k):
+def _wait_for(counter, k, patience_s=300.0):
+    """Block until the upstream stage has delivered frame k (polled like Backend.py:60 / run_system.py:148); a stage that died must not
+    leave its consumers spinning on the GPU box for ever."""
+    t0 = time.perf_counter()
     while counter.value <= k:
         time.sleep(0.001)
+        if time.perf_counter() - t0 > patience_s:
+            raise TimeoutError(f"no frame {k} after {patience_s:.0f} s: the upstream process is gone")
 
 
 def mapper_proc(args, barrier, flow, out_q):
@@ -185,7 +190,7 @@ def main():
     ctx = mp.get_context("spawn")
     barrier, q = ctx.Barrier(4), ctx.Queue()
     flow = {"frontend": ctx.Value("i", 0), "backend": ctx.Value("i", 0)}   # frames delivered so far
-    procs = [ctx.Process(target=f, args=(args, barrier, flow, q)) for f in (mapper_proc, frontend_proc, backend_proc)]
+    procs = [ctx.Process(target=f, args=(args, barrier, flow, q), daemon=True) for f in (mapper_proc, frontend_proc, backend_proc)]   # die with the parent
     for p in procs:
         p.start()
     res = {}
