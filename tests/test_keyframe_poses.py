@@ -78,7 +78,6 @@ def test_batched_pose_reread_with_no_keyframes():
 def test_batched_pose_reread_on_the_device_feeds_rigid_transform_gs():
     """The helper on device tensors, through the harness' frame loop: a stream whose SLAM keyframes use the batched re-read ends with
     the same keyframe poses and (to the inverse's rounding) the same moved Gaussians as one that runs run_system.py's loop."""
-    import numpy as np
     import artdeco_amd
     artdeco_amd.install_dropins()
     from artdeco_amd import fused

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """How much of the optimisation step is the GPU when the map is small (the first few hundred frames of every run)?
 ms per step (wall, 60 steps) next to the sum of the stage times (HIP events) at 512x384.   python tools/lab/small_map_lab.py"""
-import json
 import os
 import sys
 import time
