@@ -36,7 +36,7 @@ def create_window(window_size: int, channel: int, dtype=torch.float32) -> torch.
 def ssim_map(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
     """Per-pixel SSIM map with zero 'same' padding: tests/test.py:35-49."""
     channel = img1.size(-3)
-    window = create_window(window_size, channel, img1.dtype)
+    window = create_window(window_size, channel, img1.dtype).to(img1.device)  # tests/test.py:28-30 (window.cuda(...).type_as(img1))
     pad = window_size // 2
     mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
     mu2 = F.conv2d(img2, window, padding=pad, groups=channel)

@@ -115,8 +115,9 @@ def _sync_state(src, dst):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4, 5, 6, 7])   # five scenes in one process: one green run of one seed was weak evidence (round 3 history)
 @pytest.mark.parametrize("reg", [0.0, 0.05])
-def test_fused_optimization_step_gradients_match_unfused(reg, dev, monkeypatch):
+def test_fused_optimization_step_gradients_match_unfused(reg, seed, dev, monkeypatch):
     """Full optimisation steps (render, loss, backward, pose Adam, sparse Adam) with and without the fused glue FROM THE SAME
     STATE: the loss and every GRADIENT agree at fp32 tolerance.  Gradients are compared before the optimiser touches
     them (Adam with eps = 1e-15 and no bias correction turns rounding noise into steps of ~5 lr, so parameters are the wrong
@@ -125,7 +126,7 @@ def test_fused_optimization_step_gradients_match_unfused(reg, dev, monkeypatch):
     visible rows).  reg != 0 exercises the scaling regulariser, which must average over the LoD-selected rows only
     (h3dgsv3.py:443)."""
     from artdeco_amd import fused
-    a, b = _scene(dev, N=8000, seed=3), _scene(dev, N=8000, seed=3)
+    a, b = _scene(dev, N=8000, seed=seed), _scene(dev, N=8000, seed=seed)
     a.scaling_reg_factor = b.scaling_reg_factor = reg
     assert fused.patch_scene_model(b)
     seen = _capture_rasteriser_inputs(monkeypatch)      # of the unfused scene `a` (the fused one calls the rasteriser directly)

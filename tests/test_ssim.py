@@ -82,6 +82,54 @@ def test_hip_matches_oracle(shape, padding, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("padding", ["same", "valid"])
+def test_hip_matches_oracle_at_1080p(padding, dev):
+    """BASELINE configs[2]'s frame (1 x 3 x 1080 x 1920) against the CPU oracle, value AND gradient: 1 080 rows through the
+    strip-marching kernel's 11-row register ring (the largest oracle-checked shape used to be 216 rows), 30 strips of 64 columns."""
+    from fused_ssim import fused_ssim
+    g = torch.Generator().manual_seed(4321)
+    a, b = torch.rand(1, 3, 1080, 1920, generator=g), torch.rand(1, 3, 1080, 1920, generator=g)
+    xo = a.clone().requires_grad_(True)
+    vo = ssim_oracle.fused_ssim_oracle(xo, b, padding)
+    vo.backward()
+    xh = a.to(dev).requires_grad_(True)
+    vh = fused_ssim(xh, b.to(dev), padding)
+    vh.backward()
+    assert torch.isclose(vh.detach().cpu(), vo.detach())
+    assert grad_close(xh.grad.cpu(), xo.grad)
+    if padding == "valid":   # the 5-pixel frame takes no gradient from its own map entry, only through its neighbours' windows
+        assert float(xh.grad[..., 5:-5, 5:-5].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_the_references_own_test_at_its_own_size(dev):
+    """ONE iteration of the reference's own test (fused-ssim/tests/test.py:57-91) at ITS size and with ITS criteria: seed 0,
+    5 x 5 x 1080 x 1920 on the device, `ssim()` of test.py:14-54 in torch on the same device as the reference side
+    (`ssim_oracle.ssim_map` restates it and is pinned to it by tests/golden/ssim_*.npz), `torch.isclose` (rtol 1e-5, atol 1e-8)
+    on the value (:82) and on EVERY gradient element (:90), padding "same"; "valid" against the [5:-5, 5:-5] crop of the same
+    torch map (fused_ssim/__init__.py:13-14; pytorch_msssim, the reference's own "valid" comparator at :83/:91, is not installed)."""
+    from fused_ssim import fused_ssim
+    torch.manual_seed(0)
+    B, CH, H, W = 5, 5, 1080, 1920
+    with torch.no_grad():
+        img1_og = torch.nn.Parameter(torch.rand([B, CH, H, W], device=dev))
+        img2_og = torch.rand([B, CH, H, W], device=dev)
+        img1_same, img1_valid, img1_crop = (torch.nn.Parameter(img1_og.clone()) for _ in range(3))
+    og = ssim_oracle.ssim_map(img1_og, img2_og).mean()
+    mine_same = fused_ssim(img1_same, img2_og.clone())
+    mine_valid = fused_ssim(img1_valid, img2_og.clone(), "valid")
+    og_valid = ssim_oracle.ssim_map(img1_crop, img2_og)[:, :, 5:-5, 5:-5].mean()
+    assert torch.isclose(og, mine_same)
+    assert torch.isclose(og_valid, mine_valid)
+    og.backward(); mine_same.backward(); mine_valid.backward(); og_valid.backward()
+    assert float(img1_og.grad.abs().max()) > 0
+    assert bool(torch.isclose(img1_og.grad, img1_same.grad).all())
+    assert bool(torch.isclose(img1_crop.grad, img1_valid.grad).all())
+    # the reference's criterion is dominated by atol at this size (gradients ~ 1/(B CH H W) = 2e-8); the north-star 1e-4 on top
+    assert grad_close(img1_same.grad, img1_og.grad) and grad_close(img1_valid.grad, img1_crop.grad)
+
+
+@pytest.mark.gpu
 def test_hip_maps_match_oracle_per_pixel(dev):
     from fused_ssim_cuda import fusedssim
     g = torch.Generator().manual_seed(7)
