@@ -171,4 +171,82 @@ __device__ __forceinline__ Reduce10 wave_reduce10(const float (&a)[10], int lane
     return o;
 }
 
+// Two splats' 10 + 10 per-lane values summed across the 64 lanes in ONE transposing butterfly (round 4).  Every stage halves both the
+// lane extent and the number of values a lane carries, and the stages that cost two instructions per surviving value run while there
+// are many values:
+//   stage 1  row_mirror, bank-masked adds      20 -> 10   banks 0,1 keep splat A's ten, banks 2,3 splat B's                (20 DPP adds)
+//   stage 2  row_half_mirror, bank-masked      10 -> 5    banks 0,2 keep sums 0..4, banks 1,3 sums 5..9                    (10 DPP adds)
+//   stage 3  v_permlane32_swap + add            5 -> 3    rows 0,1 keep the even register of a pair, rows 2,3 the odd one  (3 swaps + 3 adds)
+//   stage 4  v_permlane16_swap + add            3 -> 2                                                                     (2 swaps + 2 adds)
+//   stage 5,6  in-quad all-reduce of the 2 survivors (quad_perm xor 1, xor 2)                                             (4 DPP adds)
+// = 46 cross-lane / add instructions for two splats against 2 x 32 for two wave_reduce10 (whose in-quad stages need selects and whose row
+// stages carry one value each).  Result, lane = 16 r + 4 b + l: every lane of bank b holds, for splat (b >> 1),
+//   z0 = the total of value (b & 1) * 5 + {0, 2, 1, 3}[r],   z1 = the total of value (b & 1) * 5 + 4.
+// Checked on the GPU against a float64 sum by tools/lab/reduce_lab.py (variant 2).  EXEC must be all ones.
+struct Reduce20 { float z0, z1; };
+
+__device__ __forceinline__ Reduce20 wave_reduce20(const float (&A)[10], const float (&B)[10]) {
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, u0, u1, u2, u3, u4;
+    // inline asm: see wave_reduce10 for the wait-state reasoning (s_nop 1 in front: the inputs come straight out of the accumulation fmas;
+    // every DPP read below is >= 3 instructions after the write it depends on).  30-operand limit => three blocks.
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_mirror row_mask:0xf bank_mask:0xc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+        : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9)
+        : "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %8, %8 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %9, %9 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4)
+        : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(r8), "v"(r9));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // swap32(x, y): lanes 0-31 get x.lo + x.hi, lanes 32-63 y.lo + y.hi;  swap16(x, y): rows get x.r0 + x.r1 | y.r0 + y.r1 | x.r2 + x.r3 | y.r2 + y.r3
+    u32x2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u0), __float_as_uint(u1), false, false);
+    const float w0 = __uint_as_float(s.x) + __uint_as_float(s.y);
+    s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u2), __float_as_uint(u3), false, false);
+    const float w1 = __uint_as_float(s.x) + __uint_as_float(s.y);
+    s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u4), __float_as_uint(u4), false, false);
+    const float w2 = __uint_as_float(s.x) + __uint_as_float(s.y);
+    s = __builtin_amdgcn_permlane16_swap(__float_as_uint(w0), __float_as_uint(w1), false, false);
+    float z0 = __uint_as_float(s.x) + __uint_as_float(s.y);
+    s = __builtin_amdgcn_permlane16_swap(__float_as_uint(w2), __float_as_uint(w2), false, false);
+    float z1 = __uint_as_float(s.x) + __uint_as_float(s.y);
+    z0 = dpp_add<0xB1>(z0); z1 = dpp_add<0xB1>(z1);   // quad_perm [1,0,3,2]
+    z0 = dpp_add<0x4E>(z0); z1 = dpp_add<0x4E>(z1);   // quad_perm [2,3,0,1]
+    Reduce20 o;
+    o.z0 = z0; o.z1 = z1;
+    return o;
+}
+
 } // namespace adk

@@ -39,6 +39,13 @@ namespace adk {
 #ifndef ADK_CULL_BALLOT_BWD
 #define ADK_CULL_BALLOT_BWD 1
 #endif
+// Round-4 forms of the backward's accumulate / reduce steps (lab knobs; the defaults are what the same-box A/B kept):
+#ifndef ADK_BWD_FIRST
+#define ADK_BWD_FIRST 0
+#endif
+#ifndef ADK_BWD_PAIR
+#define ADK_BWD_PAIR 0
+#endif
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
@@ -315,8 +322,11 @@ struct PixBwd {
 // SUB: one wave per 8x8 quadrant / 16x8 half of a 16x16 list tile, as in the forward -- for frames with few tiles.  A splat then costs one
 // reduction and one parked record per PART it contributes to instead of per tile: more total work, spread over more waves on a chip that
 // was mostly idle (the sums are formed in a different order: gradients move by ~3e-7 relative).
+#ifndef ADK_BWD_MINWAVES
+#define ADK_BWD_MINWAVES 1
+#endif
 template <int QX, int QY, bool SUB = false>
-__global__ __launch_bounds__(64) void raster_bwd_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 1 : ADK_BWD_MINWAVES, 8))) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     const float* __restrict__ final_T, const int32_t* __restrict__ last_ids,
@@ -355,6 +365,21 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         const int d = lane & 15;
         flush_rowbit = (d < 12 && d != 3 && d != 7) ? (1u << (lane >> 4)) : 0u;
     }
+#if ADK_BWD_PAIR
+    // lane roles after wave_reduce20 (lane = 16 r + 4 b + l): bank b serves splat b >> 1 and holds, in every lane of the bank, z0 = the total of
+    // sum (b & 1) * 5 + {0, 2, 1, 3}[r] and z1 = the total of sum (b & 1) * 5 + 4.  Lane l = 0 of every (row, bank) parks z0, lane l = 1 of row 0 z1.
+    int pk_dword; float pk_scale; bool pk_is_opacity, pk_active, pk_is_b, pk_use_z1;
+    {
+        const int r = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
+        pk_use_z1 = (l == 1);
+        pk_active = (l == 0) || (l == 1 && r == 0);
+        pk_is_b = (b >> 1) != 0;
+        const int slot = (b & 1) * 5 + (pk_use_z1 ? 4 : ((r == 1) ? 2 : (r == 2 ? 1 : r)));
+        pk_dword = acc_to_rec(slot);
+        pk_is_opacity = pk_dword == 2;
+        pk_scale = pk_dword >= 8 ? 1.0f : ((pk_dword == 4 || pk_dword == 6) ? -0.5f : -1.0f);
+    }
+#endif
     PixBwd px[NQ];
     int quad_bin_final[NQ], tile_bin_final = -1;
 #pragma unroll
@@ -422,22 +447,31 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 #else
         unsigned long long any = __ballot(qmask != 0u);
 #endif
-        while (any) {
-            const int t = __builtin_ctzll(any); // staged slot t holds list index batch_end - t (0 = furthest back)
-            const unsigned long long bit = 1ull << t;
-            any &= any - 1;
+        // One staged splat against the quadrants it can reach: the 10 per-lane sums in acc, the splat's 1/opacity in inv_opac; false if
+        // no pixel blended it (acc is then undefined and nothing is reduced or parked).
+        auto eval_splat = [&](const int t, float (&acc)[NACC], float& inv_opac) -> bool {
 #if ADK_CULL_BALLOT_BWD
+            const unsigned long long bit = 1ull << t;
 #define ADK_QHITB(q) (mq[q] & bit)
 #else
             const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)qmask, t); // wave-uniform: quadrants this splat can reach
 #define ADK_QHITB(q) (qm & (1u << (q)))
 #endif
             const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
+            inv_opac = a.w;
             const int idx = batch_end - t;
-            float acc[NACC];
+#if ADK_BWD_FIRST
+            // FIRST-TOUCH form (round 4): the first quadrant that blends the splat WRITES its products (acc0..2 are t1, t2, gq themselves,
+            // the other seven are plain v_mul), later ones accumulate: no 10 v_mov zero-fill per splat and no v_fmac onto a zero.
+            // scalars, not an array (SROA turns a float[10] into one 10-register tuple and copies it whole), and deliberately left
+            // uninitialised: never read before the first quadrant that blends the splat has written them (`touched`), and an undefined
+            // incoming value is what lets the compiler keep ONE register per sum through the first-touch / accumulate branch
+            float c0, c1, c2, c3, c4, c5, c6, c7, c8, c9;
+#else
 #pragma unroll
             for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-            bool touched = false; // wave-uniform
+#endif
+            int touched = 0; // wave-uniform; an int made uniform by readfirstlane so that `if (!touched)` below is a scalar branch (as a bool it was structurised into two ifs + copies)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (ADK_QHITB(q)) { // wave-uniform
@@ -449,7 +483,6 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     float ov = __builtin_amdgcn_exp2f(e); // opacity * exp(-sigma)
                     const bool valid = (idx <= P.bin_final) && !(e > a.z) && !(ov < ALPHA_THR);
                     if (__ballot(valid) == 0ull) continue; // nobody in this quadrant blended it (all finished earlier / below 1/255)
-                    touched = true;
                     float alpha_raw; // min(0.999, ov) on the v_exp result itself (fminf() puts a canonicalising v_max in front)
                     asm("s_nop 0\n\tv_min_f32_e32 %0, 0x3f7fbe77, %1" : "=v"(alpha_raw) : "v"(ov)); // s_nop: v_exp result -> VALU use needs 1 wait state, invisible to hipcc inside asm
                     const float alpha = valid ? alpha_raw : 0.f;
@@ -462,7 +495,30 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     // gq = opacity * vis * v_alpha = -v_sigma (clamped alpha passes no gradient); the opacity gradient is
                     // vis * v_alpha = gq / opacity, divided once per splat at the flush
                     const float gq = (valid && ov <= MAX_ALPHA) ? ov * v_alpha : 0.f;
+#if ADK_BWD_FIRST
+                    // Both forms are written as inline asm on the SAME tied ("+v") operands so that the register allocator keeps one physical
+                    // register per sum through the branch (as plain C++ the products landed in fresh registers and were copied: 10 v_mov_b64).
+#define ADK_MUL(d, x, y) asm("v_mul_f32_e32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
+#define ADK_FMAC(d, x, y) asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(d) : "v"(x), "v"(y))
+                    if (!touched) {
+                        ADK_MUL(c0, gq, dx); ADK_MUL(c1, gq, dy);
+                        asm("v_mov_b32_e32 %0, %1" : "=v"(c2) : "v"(gq));
+                        ADK_MUL(c3, c0, dx); ADK_MUL(c4, c0, dy); ADK_MUL(c5, c1, dy);
+                        ADK_MUL(c6, fac, P.vr0); ADK_MUL(c7, fac, P.vr1); ADK_MUL(c8, fac, P.vr2); ADK_MUL(c9, fac, P.vr3);
+                    } else {
+                        const float t1 = gq * dx, t2 = gq * dy;
+                        asm("v_add_f32_e32 %0, %0, %1" : "+v"(c0) : "v"(t1));
+                        asm("v_add_f32_e32 %0, %0, %1" : "+v"(c1) : "v"(t2));
+                        asm("v_add_f32_e32 %0, %0, %1" : "+v"(c2) : "v"(gq));
+                        ADK_FMAC(c3, t1, dx); ADK_FMAC(c4, t1, dy); ADK_FMAC(c5, t2, dy);
+                        ADK_FMAC(c6, fac, P.vr0); ADK_FMAC(c7, fac, P.vr1); ADK_FMAC(c8, fac, P.vr2); ADK_FMAC(c9, fac, P.vr3);
+                    }
+#undef ADK_MUL
+#undef ADK_FMAC
+                    touched = __builtin_amdgcn_readfirstlane(1);
+#else
                     const float t1 = gq * dx, t2 = gq * dy;
+                    touched = 1;
                     acc[0] += t1;                      // v_mean2d = conic (acc[0], acc[1])^T is formed by project_bwd,
                     acc[1] += t2;                      //   once per Gaussian instead of once per (splat, pixel)
                     acc[2] += gq;                      // opacity * v_opacity
@@ -470,15 +526,47 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                     acc[4] += t1 * dy;                 // -v_conic.b
                     acc[5] += t2 * dy;                 // -2 * v_conic.c
                     acc[6] += fac * P.vr0; acc[7] += fac * P.vr1; acc[8] += fac * P.vr2; acc[9] += fac * P.vr3;
+#endif
                 }
             }
-            if (!touched) continue; // every sum is zero: no reduction, nothing parked
+#if ADK_BWD_FIRST
+            acc[0] = c0; acc[1] = c1; acc[2] = c2; acc[3] = c3; acc[4] = c4; acc[5] = c5; acc[6] = c6; acc[7] = c7; acc[8] = c8; acc[9] = c9;
+#endif
+            return touched != 0;
+        };
+        while (any) {
+            const int t = __builtin_ctzll(any); // staged slot t holds list index batch_end - t (0 = furthest back)
+            any &= any - 1;
+            float acc[NACC], inv_opac;
+            if (!eval_splat(t, acc, inv_opac)) continue; // every sum is zero: no reduction, nothing parked
+#if ADK_BWD_PAIR
+            // PAIRED reduction (round 4): look for the next splat that blends anything and reduce BOTH splats' 20 sums in one butterfly
+            // (wave_reduce20: 46 cross-lane instructions per pair against 2 x 32); an odd splat out takes the single reduction.
+            int t2 = 0;
+            float acc2[NACC], inv_opac2 = 0.f;
+            bool paired = false;
+            while (any) {
+                t2 = __builtin_ctzll(any);
+                any &= any - 1;
+                if (eval_splat(t2, acc2, inv_opac2)) { paired = true; break; }
+            }
+            if (paired) {
+                const Reduce20 red = wave_reduce20(acc, acc2);
+                touched_mask |= (1ull << t) | (1ull << t2);
+                if (pk_active) {
+                    const float v = pk_use_z1 ? red.z1 : red.z0;
+                    const float io = pk_is_b ? inv_opac2 : inv_opac;
+                    sacc[pk_is_b ? t2 : t][pk_dword] = v * (pk_is_opacity ? io : pk_scale);
+                }
+                continue;
+            }
+#endif
             // ONE 64-lane reduction per (splat, tile); the 10 lanes of row 0 that own a total park it in the LDS table
             const Reduce10 red = wave_reduce10(acc, lane);
-            touched_mask |= bit;
+            touched_mask |= 1ull << t;
             // per-splat factors applied by the owner lane as it parks its total: -1 on the v_sigma-weighted dwords, -1/2 on the
             // symmetric conic entries, 1/opacity (staged in a.w) on the opacity gradient
-            if (red.is_owner) sacc[t][own_dword] = red.value * (own_is_opacity ? a.w : own_scale);
+            if (red.is_owner) sacc[t][own_dword] = red.value * (own_is_opacity ? inv_opac : own_scale);
         }
         // Flush the batch: one instruction = 4 staged splats x the 12 dwords of their gradient records (10 live), so its
         // atomics fall into 4 records.  The per-splat factors were applied when the totals were parked, the lane's role

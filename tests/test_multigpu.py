@@ -66,3 +66,34 @@ def test_bench_entry_self_launches_two_ranks_on_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "scene-per-rank x2"
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_entry_runs_two_ranks_on_one_gpu():
+    """The GPU side of the N > 1 path, driver-run: `python bench.py --gpus 2 --backend gloo` started bare on the one-GPU box with
+    ARTDECO_BENCH_SHARE_GPU=1 (both ranks on cuda:0): self-launch under torch.distributed.run, one scene per rank, the frame loop,
+    barrier, MAX(elapsed) / SUM(frames) over ranks, ONE JSON line from rank 0 with n_gpus = 2, `value` = the whole job's frames over
+    the slowest rank's wall time.  (scene per GPU, a barrier + one metric all-reduce; no scaling curve can be measured on
+    one GPU -- this pins the code path the driver's 8-GPU run takes.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ARTDECO_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--gaussians", "200000", "--width", "512", "--height", "384",
+                        "--no-extra-configs", "--no-cpu-baseline", "--no-frontend"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "scene-per-gpu x2"
+    # whole-job value: frames of BOTH ranks / max-over-ranks elapsed = 2 * steps / (ms_per_step * steps)
+    assert abs(out["value"] - 2.0 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+    assert out["config"]["optimisation_steps"] >= 2 * 3 * 10          # SUM over ranks of >= 10 optimisation steps per frame
+    assert out["roofline"]["avg_launch_ms"] > 0

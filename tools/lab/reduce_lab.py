@@ -31,9 +31,24 @@ for l in range(64):
         bad1.append((l, k, float(o1[l]), float(want[k])))
 print("shipped reduce: owners", int(w0.sum()), "mismatches", bad0[:4])
 print("rows-first reduce: mismatches", bad1[:4])
+# round 4: adk::wave_reduce20 -- lane = 16 r + 4 b + l holds, for splat b >> 1, z0 = total of value (b & 1) * 5 + {0, 2, 1, 3}[r], z1 = total of (b & 1) * 5 + 4
+x20 = torch.randn(20, 64, generator=g).to(dev)
+z0, z1 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+assert lib.reduce20_lab_check(P(x20), P(z0), P(z1), st()) == 0
+torch.cuda.synchronize()
+want20 = x20.double().sum(dim=1).cpu()
+bad2 = []
+for l in range(64):
+    r, b = l // 16, (l % 16) // 4
+    k0 = 10 * (b >> 1) + (b & 1) * 5 + [0, 2, 1, 3][r]
+    k1 = 10 * (b >> 1) + (b & 1) * 5 + 4
+    if abs(float(z0[l]) - float(want20[k0])) > 1e-4 or abs(float(z1[l]) - float(want20[k1])) > 1e-4:
+        bad2.append((l, k0, float(z0[l]), float(want20[k0]), k1, float(z1[l]), float(want20[k1])))
+print("paired reduce20: mismatches", bad2[:4])
 blocks, iters = 256 * 4 * 4, 4000          # 4 waves on every SIMD
 out = torch.zeros(blocks * 64, device=dev)
-for variant, name in ((0, "shipped (in-row DPP stages first)"), (1, "rows first (permlane swaps, then DPP)")):
+for variant, name in ((0, "shipped (in-row DPP stages first)"), (1, "rows first (permlane swaps, then DPP)"),
+                      (2, "paired reduce20, per PAIR (2 x (10 fma + reduction))")):
     for _ in range(2):
         lib.reduce_lab_time(variant, blocks, iters, P(out), st())
     torch.cuda.synchronize()
