@@ -702,7 +702,8 @@ extern "C" int adk_bin_tiles(int N, int64_t n_isects, const uint32_t* sorted_ids
 // LDS the per-slice tile histogram may use (bytes): the count / scatter kernels ask for 4 B x tiles of dynamic LDS.
 #define ADK_BIN_LDS_LIMIT (128 * 1024)
 
-static inline bool tile_shape_ok(int tpw, int tph) { return (tpw == 16 || tpw == 32) && (tph == 16 || tph == 32); }
+// the shapes adk_raster_fwd_t / adk_raster_bwd_t consume: gsplat's 16x16 and the wide 32x16 internal tile (a list binned for any other shape has no consumer)
+static inline bool tile_shape_ok(int tpw, int tph) { return (tpw == 16 || tpw == 32) && tph == 16; }
 
 // 1 if adk_bin_local_* can handle this image size (tile histogram fits LDS), else the caller uses adk_bin_depth_order / adk_bin_tiles.
 extern "C" int adk_bin_local_supported_t(int width, int height, int tile_px_w, int tile_px_h)

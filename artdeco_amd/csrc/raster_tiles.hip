@@ -46,6 +46,9 @@ namespace adk {
 #ifndef ADK_BWD_PAIR
 #define ADK_BWD_PAIR 0
 #endif
+#ifndef ADK_BWD_LEAN
+#define ADK_BWD_LEAN 0
+#endif
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
@@ -296,7 +299,11 @@ __device__ __forceinline__ int acc_to_rec(int k) { return k < 3 ? k : (k < 6 ? k
 
 // Per-pixel backward state (one per quadrant the lane serves); the pixel centre is recomputed from the lane's quadrant-0 centre.
 struct PixBwd {
+#if ADK_BWD_LEAN
+    float T, E;          // running transmittance; E = T_final*(v_alpha_out - <bg, v_render>) - <buffer, v_render>: the only combination the two were used in
+#else
     float T, bdot, C0;   // running transmittance, <buffer, v_render>, T_final*(v_alpha_out - <bg, v_render>)
+#endif
     float vr0, vr1, vr2, vr3;
     int bin_final;       // index of the last splat that contributed in the forward (-1: pixel outside the image)
 };
@@ -387,14 +394,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
         const int ox = px0 + (q % QX) * 8, oy = py0 + (q / QX) * 8;
         const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
         PixBwd& P = px[q];
-        P.vr0 = P.vr1 = P.vr2 = P.vr3 = 0.f; P.T = 1.f; P.bdot = 0.f; P.C0 = 0.f; P.bin_final = -1;
+        P.vr0 = P.vr1 = P.vr2 = P.vr3 = 0.f; P.T = 1.f; P.bin_final = -1;
+#if ADK_BWD_LEAN
+        P.E = 0.f;
+#else
+        P.bdot = 0.f; P.C0 = 0.f;
+#endif
         if (pxi < W && pyi < H) {
             const int64_t pix = (int64_t)pyi * W + pxi;
             const float T_final = final_T[pix];
             const float4 v = reinterpret_cast<const float4*>(v_render_colors)[pix];
             P.vr0 = v.x; P.vr1 = v.y; P.vr2 = v.z; P.vr3 = v.w;
             const float bg_dot = bgc[0] * v.x + bgc[1] * v.y + bgc[2] * v.z + bgc[3] * v.w;
+#if ADK_BWD_LEAN
+            P.E = T_final * (v_render_alphas[pix] - bg_dot);
+#else
             P.C0 = T_final * (v_render_alphas[pix] - bg_dot);
+#endif
             P.T = T_final;
             P.bin_final = last_ids[pix];
         }
@@ -483,6 +499,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
                     float ov = __builtin_amdgcn_exp2f(e); // opacity * exp(-sigma)
                     const bool valid = (idx <= P.bin_final) && !(e > a.z) && !(ov < ALPHA_THR);
                     if (__ballot(valid) == 0ull) continue; // nobody in this quadrant blended it (all finished earlier / below 1/255)
+#if ADK_BWD_LEAN
+                    // LEAN form (round 4): validity folded into ov ONCE (an invalid lane then has alpha = 0, ra = 1, fac = 0, gq = 0 on its own),
+                    // the <buffer, v_render> recurrence kept as E = C0 - bdot (one register and one v_sub less per evaluation), and the
+                    // alpha > 0.999 clamp -- which passes no gradient -- handled in a wave-uniform branch that is almost never taken.
+                    const float ov_v = valid ? ov : 0.f;
+                    float alpha;
+                    asm("v_min_f32_e32 %0, 0x3f7fbe77, %1" : "=v"(alpha) : "v"(ov_v));
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha); // 1 ulp v_rcp_f32; alpha <= 0.999
+                    P.T *= ra;
+                    const float fac = alpha * P.T;
+                    const float S1 = col.x * P.vr0 + col.y * P.vr1 + col.z * P.vr2 + col.w * P.vr3;
+                    const float v_alpha = P.T * S1 + ra * P.E;
+                    P.E -= fac * S1;
+                    float gq = ov_v * v_alpha;   // opacity * vis * v_alpha = -v_sigma
+                    if (__ballot(ov_v > MAX_ALPHA) != 0ull) { // clamped alpha passes no gradient (opacity > 0.999 at the splat centre: almost never)
+                        asm volatile("; clamped alpha"); // keeps this a real, not-taken branch (if-converted it costs two compares and a select on every evaluation)
+                        gq = (ov_v > MAX_ALPHA) ? 0.f : gq;
+                    }
+#else
                     float alpha_raw; // min(0.999, ov) on the v_exp result itself (fminf() puts a canonicalising v_max in front)
                     asm("s_nop 0\n\tv_min_f32_e32 %0, 0x3f7fbe77, %1" : "=v"(alpha_raw) : "v"(ov)); // s_nop: v_exp result -> VALU use needs 1 wait state, invisible to hipcc inside asm
                     const float alpha = valid ? alpha_raw : 0.f;
@@ -495,6 +530,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
                     // gq = opacity * vis * v_alpha = -v_sigma (clamped alpha passes no gradient); the opacity gradient is
                     // vis * v_alpha = gq / opacity, divided once per splat at the flush
                     const float gq = (valid && ov <= MAX_ALPHA) ? ov * v_alpha : 0.f;
+#endif
 #if ADK_BWD_FIRST
                     // Both forms are written as inline asm on the SAME tied ("+v") operands so that the register allocator keeps one physical
                     // register per sum through the branch (as plain C++ the products landed in fresh registers and were copied: 10 v_mov_b64).

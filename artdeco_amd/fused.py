@@ -974,6 +974,7 @@ def fused_add_new_gaussians(self, keyframe_id: int = -1):
                 _lib.check(rc, "adk_densify_emit")
             if len(self.xyz) > 0:
                 prev_cls = self.cls_id
+                voxel_table.pop("reused", None)   # set by the device path only: a level that fell back to the torch body must not inherit it
                 upd, new_cls, n_vox = self.update_voxel(xyz, self.xyz, self.cls_id, voxel_size)
                 if voxel_table.get("reused"):
                     labels_changed = False      # the table of the previous level answered: `upd` IS the previous level's tensor
@@ -1021,7 +1022,12 @@ def fused_rigid_transform_gs(self, old_c2ws, new_c2ws, cam_centres):
     lib = _lib.load()
     dev = xyz.device
     with _lib.on_device(dev):
-        delta = torch.bmm(new_c2ws.float(), torch.inverse(old_c2ws.float())).contiguous()
+        # The reference gathers by id FIRST and inverts only rows some Gaussian references (utils.py:33-36): a row the caller left at
+        # its zero initial value (run_system.py:195 initialises to zeros and skips some ids) must not raise here.  inv_ex does not
+        # check (and does not synchronise); a singular row becomes NaN, so a Gaussian that DOES reference it turns visibly invalid.
+        inv_old, info = torch.linalg.inv_ex(old_c2ws.float())
+        inv_old = torch.where((info != 0)[:, None, None], torch.full_like(inv_old, float("nan")), inv_old)
+        delta = torch.bmm(new_c2ws.float(), inv_old).contiguous()
         N, K = xyz.shape[0], delta.shape[0]
         new_xyz, new_rot = torch.empty(N, 3, dtype=torch.float32, device=dev), torch.empty(N, 4, dtype=torch.float32, device=dev)
         rc = lib.adk_rigid_transform(N, ids.reshape(-1).contiguous().data_ptr(), K, delta.data_ptr(), xyz.detach().contiguous().data_ptr(),
@@ -1063,6 +1069,20 @@ def freeze_gc(force: bool = True) -> None:
     gc.collect()
     gc.freeze()
     _GC_FROZEN = True
+
+
+def _centre_is_image_centre(scene) -> bool:
+    """fused_add_new_gaussians back-projects with the principal point ((W - 1) / 2, (H - 1) / 2), which is what SceneModel.__init__
+    puts into `self.centre` (h3dgsv3.py:89) -- a constructor the source pins do not cover.  One host read, once per patched scene:
+    a scene whose `centre` is anything else keeps ARTDECO's own add_new_gaussians."""
+    c = getattr(scene, "centre", None)
+    if c is None:
+        return True          # the harness mirror has no such attribute: it uses the same expression inline
+    try:
+        cx, cy = (float(v) for v in c.detach().reshape(-1)[:2].cpu())
+    except Exception:  # noqa: BLE001
+        return False
+    return cx == (scene.width - 1) / 2 and cy == (scene.height - 1) / 2
 
 
 def patch_scene_model(scene, verify: bool = False) -> bool:
@@ -1110,7 +1130,8 @@ def patch_scene_model(scene, verify: bool = False) -> bool:
         if hasattr(scene, "weed_out_gaussians") and hasattr(scene, "make_dummy_ext_tensor"):
             scene._unfused_weed_out_gaussians = scene.weed_out_gaussians
             scene.weed_out_gaussians = types.MethodType(fused_weed_out_gaussians, scene)
-        if hasattr(scene, "add_new_gaussians") and all(hasattr(scene, a) for a in ("lods", "disc_kernel", "init_proba_scaler", "update_voxel")):
+        if (hasattr(scene, "add_new_gaussians") and all(hasattr(scene, a) for a in ("lods", "disc_kernel", "init_proba_scaler", "update_voxel"))
+                and _centre_is_image_centre(scene)):
             scene._unfused_add_new_gaussians = scene.add_new_gaussians
             scene.add_new_gaussians = types.MethodType(fused_add_new_gaussians, scene)
         if hasattr(scene, "rigid_transform_gs") and "id" in getattr(scene, "gaussian_params", {}):

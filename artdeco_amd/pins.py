@@ -25,14 +25,18 @@ import textwrap
 PIN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_pins.json")
 
 # group -> [(where, attribute)]: where = "scene" (the SceneModel class), "optimizer" (class of scene.optimizer),
-# "keyframe" / "utils" (names bound in the scene-model module: `Keyframe`, and the free functions it imported)
+# "keyframe" / "utils" (names bound in the scene-model module: `Keyframe`, and the free functions it imported),
+# "kfutils" (a free function bound in the module that defines Keyframe).  A method may sit in both groups.
 GROUPS = {
     "step": [("scene", "render"), ("scene", "render_from_id"), ("scene", "optimization_step"), ("optimizer", "step"),
              ("keyframe", "step"), ("keyframe", "get_Rt"), ("utils", "radial_decay_kernel")],
     "densify": [("scene", "update_voxel"), ("scene", "weed_out_gaussians"), ("scene", "add_new_gaussians"),
                 ("scene", "make_dummy_ext_tensor"), ("scene", "rigid_transform_gs"), ("optimizer", "add_and_prune"),
                 ("utils", "update_gaussians"), ("utils", "get_lapla_norm"),
-                ("utils", "sample"), ("utils", "depth2points"), ("utils", "RGB2SH"), ("utils", "inverse_sigmoid")],
+                ("utils", "sample"), ("utils", "make_torch_sampler"), ("utils", "depth2points"), ("utils", "RGB2SH"), ("utils", "inverse_sigmoid"),
+                # fused_add_new_gaussians uses artdeco_amd's PoseRt where the reference calls Keyframe.get_R / get_t / get_Rt -> sixD2mtx
+                # (keyframe.py:144-154, utils.py:223), and replicates make_torch_sampler's uv * 2 / (size - 1) - 1 (utils.py:203-212)
+                ("keyframe", "get_R"), ("keyframe", "get_t"), ("keyframe", "get_Rt"), ("kfutils", "sixD2mtx")],
 }
 
 
@@ -61,14 +65,16 @@ def _resolve(scene_cls, optimizer_cls, where: str, attr: str):
     if where == "optimizer":
         return getattr(optimizer_cls, attr, None) if optimizer_cls is not None else None
     mod = sys.modules.get(scene_cls.__module__)
-    if where == "keyframe":
+    if where in ("keyframe", "kfutils"):
         kf = getattr(mod, "Keyframe", None)
-        return getattr(kf, attr, None) if kf is not None else None
+        if kf is None:
+            return None
+        return getattr(kf, attr, None) if where == "keyframe" else getattr(sys.modules.get(kf.__module__), attr, None)
     return getattr(mod, attr, None)
 
 
 def pin_name(where: str, attr: str) -> str:
-    return {"scene": "SceneModel", "optimizer": "SparseGaussianAdam", "keyframe": "Keyframe", "utils": "utils"}[where] + "." + attr
+    return {"scene": "SceneModel", "optimizer": "SparseGaussianAdam", "keyframe": "Keyframe", "utils": "utils", "kfutils": "utils"}[where] + "." + attr
 
 
 def collect(scene_cls, optimizer_cls) -> dict:

@@ -270,7 +270,7 @@ def main():
                        "important_frame_fraction": sum(f["is_important"] for f in flags) / len(flags),
                        "densified_frames": sum(f["is_important"] and not f["is_test"] for f in flags),
                        "slam_keyframes": sum(f["is_slam_keyframe"] for f in flags),
-                       "optimisation_steps": int(timed["steps"]), "steps_per_frame": timed["steps"] / args.steps,
+                       "optimisation_steps": int(sums["steps"]), "steps_per_frame": sums["steps"] / total_frames,
                        "new_gaussians_per_densified_frame": timed["gaussians_added"] / max(timed["densified_frames"], 1),
                        "gaussians_pruned_in_timed_region": int(timed["gaussians_start"] + timed["gaussians_added"] - timed["gaussians_end"]),
                        "intersections_I": I, "visible_V": V, "pixels_P": P, "gaussians_N": N_end,

@@ -190,6 +190,21 @@ def run_frame(scene, frame, index, flags, clock, *, num_key_iterations=20, num_c
     return n_it
 
 
+@torch.no_grad()
+def fast_forward(scene, frames, n_keyframes, *, start_index=0, test_hold=8, pyr_levels=1, **_):
+    """Put the scene where a sequence is after `n_keyframes` mapped frames WITHOUT running them: with --use_all_frames every frame so
+    far is a mapper keyframe (run_system.py:230), so the late part of a sequence differs from its start by the length of
+    `scene.keyframes` -- which the reference's own SLAM-keyframe loop (run_system.py:194-227) walks entirely, and which the
+    optimisation steps draw their keyframe from (h3dgsv3.py:406-414).  Keyframes are built from `frames` cyclically (Keyframe
+    construction + add_keyframe only: no densification, no optimisation steps; the map keeps its size).  Untimed set-up for the
+    late-window measurements of bench.py."""
+    for j in range(n_keyframes):
+        i = start_index + j
+        is_test = test_hold > 0 and i % test_hold == 0 and i > 0
+        scene.add_keyframe(make_keyframe(scene, frames[j % len(frames)], len(scene.keyframes), is_test=is_test, pyr_levels=pyr_levels))
+    torch.cuda.synchronize()
+
+
 def run_stream(scene, frames, *, start_index=0, breakdown=False, kf_every=5, slam_every=15, test_hold=8, pyr_levels=1, **kw):
     """Feed `frames` through the loop.  Returns dict(seconds, frames, steps, important, added, stage_ms (breakdown only))."""
     clock = StageClock(breakdown)

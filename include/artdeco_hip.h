@@ -202,7 +202,7 @@ int adk_bin_local_scatter(int N, int64_t capacity, const uint32_t* depth_keys, c
                           const void* workspace, int64_t workspace_bytes, void* pairs, adk_stream_t stream);
 int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets,
                        const void* pairs, int32_t* flatten_ids, uint32_t* tile_ids, adk_stream_t stream);
-/* The same three steps for an INTERNAL tile shape tile_px_w x tile_px_h in {16x16, 32x16, 32x32}: a wider tile lists every Gaussian
+/* The same three steps for an INTERNAL tile shape tile_px_w x tile_px_h in {16x16, 32x16} (the shapes adk_raster_fwd_t / adk_raster_bwd_t take; anything else: ADK_EINVAL): a wider tile lists every Gaussian
  * gsplat lists for one of the 16x16 tiles inside it, in the same (depth, id) order; offsets has one entry per internal tile.
  * (`adk_bin_local_*` without the suffix = 16x16 = gsplat's isect_tiles / isect_offset_encode outputs.) */
 int adk_bin_local_supported_t(int width, int height, int tile_px_w, int tile_px_h);

@@ -17,124 +17,19 @@ checkpoints -- so no implementation could be told apart at 0.1 dB; with every le
 stays within 0.013 dB while the reconstruction still climbs 17 -> 31 dB in 100 steps.  The proxy therefore runs at 0.2 x the
 learning rates (both sides), where 0.1 dB is a meaningful bound.
 """
-import importlib.util
-import math
-import os
-
-import numpy as np
 import pytest
-import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N, W, H, STEPS, NKF, NTEST, EVERY, LR_SCALE = 2500, 80, 56, 120, 3, 6, 20, 0.2
-
-
-def _cpu_mapper():
-    """A second copy of the harness module whose natives are the CPU oracles."""
-    import test_mapper_host_logic as HL
-    import types
-    spec = importlib.util.spec_from_file_location("harness_mapper_cpu_oracle", os.path.join(ROOT, "harness", "mapper.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    m.gsplat = types.SimpleNamespace(rendering=types.SimpleNamespace(rasterization=HL._rasterization))
-    m.fused_ssim, m.adamUpdate, m.adamUpdateBasic = HL._fused_ssim, HL._adam_update, HL._adam_update_basic
-    return m
-
-
-def _psnr(a, b):
-    mse = float(((a.double() - b.double()) ** 2).mean())
-    return 10.0 * math.log10(1.0 / max(mse, 1e-20))
-
-
-def _build(mapper, device, truth):
-    """Scene whose keyframes observe `truth` (images + inverse depths rendered beforehand) from a PERTURBED copy of it."""
-    c, targets, poses = truth
-    sc = mapper.MapperScene(W, H, c["fx"], device)
-    with torch.no_grad():
-        last = sc.mlp_cov[2]
-        last.weight.zero_()
-        last.bias.copy_(torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0]))
-        for p in sc.mlp_cov[0].parameters():
-            p.zero_()
-    g = torch.Generator().manual_seed(11)
-    op = c["opacities"].clamp(1e-4, 1 - 1e-4)
-    means = c["means"] + 0.01 * torch.randn(N, 3, generator=g)
-    sh = c["sh"] + 0.25 * torch.randn(c["sh"].shape, generator=g)
-    logit = torch.log(op / (1 - op)) + 0.5 * torch.randn(N, generator=g)
-    sc.set_gaussians(means, c["quats"], torch.log(2.0 * c["scales"]) + 0.15 * torch.randn(N, 3, generator=g), logit, sh, seed=0)
-    for (img, idepth), Rt in zip(targets, poses):
-        sc.add_keyframe(mapper.Keyframe(img.to(device), idepth.to(device), Rt.to(device), torch.device(device)))
-    for k, pd in sc.optimizer.params.items():      # see the module docstring: the proxy's noise floor needs smaller steps
-        if "lr" in pd and k not in ("cls_id", "d_max", "id"):
-            pd["lr"] = pd["lr"] * LR_SCALE
-    sc.lr_dict["xyz"]["lr_init"] *= LR_SCALE
-    return sc
+from harness import psnr_proxy as PP
 
 
 @pytest.mark.gpu
-def test_psnr_of_hip_training_matches_cpu_oracle_training(dev, monkeypatch):
-    from artdeco_amd import fused
-    from harness import mapper as gmap
-    cmap = _cpu_mapper()
-    torch.manual_seed(0)
-    c = gmap.synthetic_cloud(N, W, H, seed=3, sigma_px=2.5)
-    g = torch.Generator().manual_seed(5)
-    poses = []
-    for _ in range(NKF + NTEST):   # the last NTEST poses are held out
-        Rt = torch.eye(4)
-        Rt[:3, 3] = 0.05 * torch.randn(3, generator=g)
-        poses.append(Rt)
-    # ground-truth observations: the true cloud rendered by the CPU oracle path (identical targets for both runs)
-    truth_scene = cmap.MapperScene(W, H, c["fx"], "cpu")
-    with torch.no_grad():
-        truth_scene.mlp_cov[2].weight.zero_()
-        truth_scene.mlp_cov[2].bias.copy_(torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0]))
-        for p in truth_scene.mlp_cov[0].parameters():
-            p.zero_()
-    op = c["opacities"].clamp(1e-4, 1 - 1e-4)
-    truth_scene.set_gaussians(c["means"], c["quats"], torch.log(2.0 * c["scales"]), torch.log(op / (1 - op)), c["sh"], seed=0)
-    targets = []
-    with torch.no_grad():
-        for Rt in poses:
-            pkg = truth_scene.render(W, H, Rt, torch.full((3,), 0.5))
-            targets.append((pkg["render"].clamp(0, 1).contiguous(), pkg["invdepth"].contiguous()))
-    truth = (c, targets[:NKF], poses[:NKF])
-    test_views = list(zip(poses[NKF:], [t[0] for t in targets[NKF:]]))
-
-    cpu = _build(cmap, "cpu", truth)
-    gpu = _build(gmap, dev, truth)
-    assert fused.patch_scene_model(gpu)
-
-    def evaluate(sc):
-        """mean PSNR over the held-out views (SceneModel.evaluate, h3dgsv3.py:523-558, renders test frames the same way)"""
-        with torch.no_grad():
-            bg = torch.full((3,), 0.5, device=sc.device)
-            return float(np.mean([_psnr(sc.render(W, H, Rt.to(sc.device), bg)["render"].clamp(0, 1).cpu(), img) for Rt, img in test_views]))
-
-    p0_cpu, p0_gpu = evaluate(cpu), evaluate(gpu)
-    assert abs(p0_cpu - p0_gpu) < 0.01          # same start, both renderers agree
-    # same random backgrounds on both sides: the step draws torch.rand(3, device=...) (h3dgsv3.py:422), whose stream depends on the device
-    bgs = torch.rand(STEPS, 3, generator=torch.Generator().manual_seed(9))
-    real_rand = torch.rand
-    state = {"i": 0}
-
-    def fake_rand(*size, **kw):
-        if size == (3,) and kw.get("generator") is None:
-            return bgs[state["i"]].to(kw.get("device", "cpu"))
-        return real_rand(*size, **kw)
-    monkeypatch.setattr(torch, "rand", fake_rand)
-    curve = []
-    for i in range(STEPS):
-        state["i"] = i
-        cpu.optimization_step(i % NKF, is_important=(i % 5 != 4))
-        gpu.optimization_step(i % NKF, is_important=(i % 5 != 4))
-        if (i + 1) % EVERY == 0:
-            monkeypatch.setattr(torch, "rand", real_rand)
-            curve.append((i + 1, evaluate(cpu), evaluate(gpu)))
-            monkeypatch.setattr(torch, "rand", fake_rand)
-    monkeypatch.setattr(torch, "rand", real_rand)
-    print(f"held-out PSNR, start {p0_cpu:.2f} dB; (step, CPU-oracle training, HIP training, delta): "
-          + ", ".join(f"({s_}, {a:.3f}, {b:.3f}, {b - a:+.3f})" for s_, a, b in curve))
-    assert curve[-1][1] > p0_cpu + 3.0 and curve[-1][2] > p0_gpu + 3.0       # both runs reconstruct
-    for s_, a, b in curve:
-        assert abs(a - b) <= 0.1, (s_, a, b)                                 # within 0.1 dB at every checkpoint
+def test_psnr_of_hip_training_matches_cpu_oracle_training(dev):
+    """harness/psnr_proxy.run: 120 steps, held-out PSNR at 6 checkpoints (what bench.py's `psnr_proxy` object runs in a shorter form)."""
+    res = PP.run(dev, steps=120, every=20)
+    curve = res["checkpoints"]
+    print(f"held-out PSNR, start {res['start_db']:.2f} dB; (step, CPU-oracle training, HIP training, delta): "
+          + ", ".join(f"({c['step']}, {c['cpu_oracle_db']:.3f}, {c['hip_db']:.3f}, {c['delta_db']:+.3f})" for c in curve))
+    assert abs(res["start_delta_db"]) < 0.01          # same start, both renderers agree
+    assert curve[-1]["cpu_oracle_db"] > res["start_db"] + 3.0 and curve[-1]["hip_db"] > res["start_db"] + 3.0       # both runs reconstruct
+    for c in curve:
+        assert abs(c["delta_db"]) <= 0.1, c                                  # within 0.1 dB at every checkpoint

@@ -259,7 +259,7 @@ def test_binning_is_bit_exact_at_northstar_sizes_on_every_route(N, W, H, route, 
     elif route == "global":
         monkeypatch.setenv("ADK_BIN_LOCAL", "0")
     counts = np.diff(np.append(oi["offsets"].reshape(-1), oi["n_isects"]))
-    assert counts.max() <= 8192 and (counts > 1024).mean() > 0.9, (counts.max(), (counts > 1024).mean())  # the long-list sorts' range
+    assert counts.max() <= 8192 and (counts > 1024).mean() > 0.7, (counts.max(), (counts > 1024).mean())  # the long-list sorts' range (the tilted view leaves a border of short lists)
     r, a, meta, _ = _run_hip(sc, dev)
     assert torch.equal(meta["radii"][0].cpu(), p["radii"])
     assert np.array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), oi["tiles_per_gauss"])
@@ -403,7 +403,7 @@ def _window_oracle(N, W, H, window, tilt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["0", "2", "1"])   # one wave per 16x16 list tile | per 16x8 half | per 8x8 quadrant
 @pytest.mark.parametrize("N,W,H,window,tilt", [(1_000_000, 512, 384, (10, 8, 13, 10), 2),      # interior
-                                               (1_000_000, 512, 384, (30, 22, 32, 24), 2),      # bottom-right corner
+                                               (1_000_000, 512, 384, (30, 22, 32, 24), None),   # bottom-right corner (untilted: the tilted view leaves it empty)
                                                (1_000_000, 648, 486, (18, 12, 21, 14), 2),      # interior (run.sh geometry)
                                                (1_000_000, 648, 486, (39, 29, 41, 31), None)])  # ragged right column AND bottom row
 def test_render_and_backward_at_northstar_sizes_in_every_wave_form(N, W, H, window, tilt, form, dev, monkeypatch):
