@@ -53,3 +53,54 @@ for i in range(3):
             j = int(torch.topk((grads["a"]["xyz"] - grads["b"]["xyz"]).norm(dim=1), 1).indices[0])
             print("   worst row", j, "xyz", a.xyz[j].tolist(), "scaling", a.gaussian_params["scaling"]["val"][j].tolist(), "opacity", a.gaussian_params["opacity"]["val"][j].tolist())
             print("   grad a", grads["a"]["xyz"][j].tolist(), "grad b", grads["b"]["xyz"][j].tolist())
+
+# ---- which path is right?  the same step on the CPU-oracle path (harness/mapper.py with natives = oracle/), from the same state
+if "--oracle" in sys.argv:
+    from harness import psnr_proxy as PP
+    cmap = PP.cpu_mapper()
+    a, b = T._scene(dev, N=8000, seed=seed), T._scene(dev, N=8000, seed=seed)
+    assert fused.patch_scene_model(b)
+    c = cmap.build_synthetic_mapper(8000, 160, 112, "cpu", seed=seed, n_keyframes=2)
+    T._sync_state(a, b)
+    with torch.no_grad():   # c <- a (CPU copy of every parameter / moment / keyframe state / mlp)
+        for k, pd in a.optimizer.params.items():
+            qd = c.optimizer.params[k]
+            for name in ("val", "exp_avg", "exp_avg_sq"):
+                if name in pd and torch.is_tensor(pd[name]):
+                    qd[name].copy_(pd[name].cpu())
+            if torch.is_tensor(pd.get("lr")):
+                qd["lr"].copy_(pd["lr"].cpu())
+        for pa, pc in zip(a.mlp_cov.parameters(), c.mlp_cov.parameters()):
+            pc.copy_(pa.cpu())
+        for ka, kc in zip(a.keyframes, c.keyframes):
+            for name in ("rW2C", "tW2C", "exposure"):
+                getattr(kc, name).copy_(getattr(ka, name).cpu())
+            kc.image_pyr = [t.cpu() for t in ka.image_pyr]
+            kc.idepth_pyr = [t.cpu() for t in ka.idepth_pyr]
+            kc.depth_loss_weight = ka.depth_loss_weight
+    grads = {}
+    for name, sc in (("a", a), ("b", b), ("c", c)):
+        orig = sc.optimizer.step
+
+        def spy(*args, _o=orig, _sc=sc, _n=name, **kw):
+            grads[_n] = {k: _sc.gaussian_params[k]["val"].grad.detach().cpu().clone() for k in keys}
+            return _o(*args, **kw)
+        sc.optimizer.step = spy
+        torch.manual_seed(0)
+        # the step draws its background with torch.rand(3, device=...): make it the same on every side
+        real_rand = torch.rand
+        torch.rand = lambda *size, **kw: (torch.tensor([0.3, 0.6, 0.1], device=kw.get("device", "cpu")) if size == (3,) else real_rand(*size, **kw))
+        try:
+            loss = float(sc.optimization_step(0, is_important=True))
+        finally:
+            torch.rand = real_rand
+        print(f"[oracle check] path {name}: loss {loss:.8f}")
+    for k in keys:
+        ga, gb, gc = (grads[n][k].double() for n in "abc")
+        ra = float((ga - gc).norm() / gc.norm().clamp_min(1e-300)); rb = float((gb - gc).norm() / gc.norm().clamp_min(1e-300)); rab = float((ga - gb).norm() / ga.norm().clamp_min(1e-300))
+        print(f"[oracle check] {k:12s} |unfused - oracle| {ra:.3e}   |fused - oracle| {rb:.3e}   |unfused - fused| {rab:.3e}")
+    j = int(torch.topk((grads["a"]["xyz"] - grads["b"]["xyz"]).norm(dim=1), 1).indices[0])
+    print("[oracle check] worst row", j, "unfused", grads["a"]["xyz"][j].tolist(), "fused", grads["b"]["xyz"][j].tolist(), "oracle", grads["c"]["xyz"][j].tolist())
+    with torch.no_grad():
+        xyz = a.xyz[j].cpu(); dm = float(a.gaussian_params["d_max"]["val"][j])
+        print("[oracle check] worst row d_max", dm, "|xyz|", float(xyz.norm()), "|xyz| / d_max", float(xyz.norm()) / dm)
