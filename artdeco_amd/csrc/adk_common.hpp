@@ -185,54 +185,54 @@ __device__ __forceinline__ Reduce10 wave_reduce10(const float (&a)[10], int lane
 // Checked on the GPU against a float64 sum by tools/lab/reduce_lab.py (variant 2).  EXEC must be all ones.
 struct Reduce20 { float z0, z1; };
 
-__device__ __forceinline__ Reduce20 wave_reduce20(float (&A)[10], float (&B)[10]) {
-    // IN PLACE: stage 1 leaves its ten results in A's registers (banks 0,1 of A[k] become A's pair sums by an add onto themselves; banks 2,3,
-    // whose old contents that add has already consumed, receive B's), stage 2 its five in A[0..4] -- no result registers beyond the 20
-    // inputs (the first version took 15 more and cost the whole-tile kernel a wave of occupancy).
+// MEASURED AND REJECTED (round 4, same box A/B): the same butterfly IN PLACE (stage 1 writes its sums over A's registers, stage 2 over A[0..4]:
+// 15 fewer live registers, 96 instead of 99 VGPRs in the whole-tile kernel) is 3 % SLOWER in every form (raster_bwd 0.525 -> 0.541 ms in the
+// two-halves form, 0.533 -> 0.545 whole-tile at 5 waves): a bank-masked DPP add whose destination is also its source serialises on that register.
+__device__ __forceinline__ Reduce20 wave_reduce20(const float (&A)[10], const float (&B)[10]) {
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, u0, u1, u2, u3, u4;
     // inline asm: see wave_reduce10 for the wait-state reasoning (s_nop 1 in front: the inputs come straight out of the accumulation fmas;
     // every DPP read below is >= 3 instructions after the write it depends on).  30-operand limit => three blocks.
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %9, %9 row_mirror row_mask:0xf bank_mask:0xc"
-        : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4])
-        : "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]));
+        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_mirror row_mask:0xf bank_mask:0xc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+        : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]));
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %9, %9 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
         "s_nop 1"
-        : "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]), "+v"(A[9])
-        : "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9]));
+        : "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9)
+        : "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9]));
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %2, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %4, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %8, %8 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %9, %9 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "s_nop 1"
-        : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4])
-        : "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]));
-    const float u0 = A[0], u1 = A[1], u2 = A[2], u3 = A[3], u4 = A[4];
+        : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4)
+        : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(r8), "v"(r9));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     // swap32(x, y): lanes 0-31 get x.lo + x.hi, lanes 32-63 y.lo + y.hi;  swap16(x, y): rows get x.r0 + x.r1 | y.r0 + y.r1 | x.r2 + x.r3 | y.r2 + y.r3
     u32x2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u0), __float_as_uint(u1), false, false);

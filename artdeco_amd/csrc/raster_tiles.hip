@@ -39,15 +39,24 @@ namespace adk {
 #ifndef ADK_CULL_BALLOT_BWD
 #define ADK_CULL_BALLOT_BWD 1
 #endif
-// Round-4 forms of the backward's accumulate / reduce steps (lab knobs; the defaults are what the same-box A/B kept):
+// Round-4 forms of the backward's accumulate / reduce steps.  Each is a lab knob (set to 0 to get the round-3 form back); the defaults are
+// what the same-box A/Bs kept (tools/lab/ab_bwd_r04.sh, profiles/r04_ab_bwd*.txt; 1 M Gaussians, ms, whole tile / two halves at 1080p, quadrants at 512x384):
+//     round 3                               0.563 / 0.588    0.1055
+//     FIRST                                 0.549 / 0.558    0.1045      first quadrant that blends a splat WRITES its 10 products (no zero fill, no fmac onto 0)
+//     FIRST + PAIR                          0.551 / 0.532    0.1015      two splats' 20 sums reduced in one butterfly (wave_reduce20): 46 instead of 2 x 32 instructions
+//     FIRST + PAIR + LEAN                   0.541 / 0.525    0.0993      validity folded into ov once, E = C0 - bdot, clamp in a not-taken branch
+//     FIRST + PAIR + LEAN, >= 5 waves       0.533 / 0.525    0.0998      (the whole-tile form needs 99 VGPRs otherwise: 4 waves)
+// Counters (profiles/r04_pmc_bwd_variants.txt, whole tile): SQ_INSTS_VALU 333.6 M -> 289.8 M (-13 %), SQ_ACTIVE_INST_VALU 349.3 M -> 306.7 M
+// quad-cycles (-12 %) for -4 % of time at 4 waves per SIMD: with fewer instructions the kernel stops being purely VALU-bound and the lost wave
+// shows; at 5 waves (MINWAVES) and in the two-halves form (6 waves) most of the saving arrives.
 #ifndef ADK_BWD_FIRST
-#define ADK_BWD_FIRST 0
+#define ADK_BWD_FIRST 1
 #endif
 #ifndef ADK_BWD_PAIR
-#define ADK_BWD_PAIR 0
+#define ADK_BWD_PAIR 1
 #endif
 #ifndef ADK_BWD_LEAN
-#define ADK_BWD_LEAN 0
+#define ADK_BWD_LEAN 1
 #endif
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
@@ -330,7 +339,7 @@ struct PixBwd {
 // reduction and one parked record per PART it contributes to instead of per tile: more total work, spread over more waves on a chip that
 // was mostly idle (the sums are formed in a different order: gradients move by ~3e-7 relative).
 #ifndef ADK_BWD_MINWAVES
-#define ADK_BWD_MINWAVES 1
+#define ADK_BWD_MINWAVES 5   // 96 VGPRs, no scratch (99 -> 4 waves without it)
 #endif
 template <int QX, int QY, bool SUB = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 1 : ADK_BWD_MINWAVES, 8))) void raster_bwd_kernel(

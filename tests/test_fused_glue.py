@@ -93,6 +93,39 @@ def test_fused_render_matches_unfused(lod, dev, monkeypatch):
         assert rel <= 1e-4, (k, rel)
 
 
+def _rows_near_image_knife_pixels(sc, kid, seed, is_important, tol=5e-6, margin=16.0):
+    """Pixels on which the LOSS (not the rasteriser) sits on a decision -- |exposed render - target| < tol (sign of an L1 term), exposed
+    render within tol of the clamp bounds 0 / 1, inverse depth within tol of its target, weighted error within tol of the 0.2 outlier
+    threshold -- evaluated on the unfused scene's own render with the background the step is about to draw (torch.manual_seed(seed),
+    first torch.rand(3)).  Returns a bool [N] mask of the Gaussians whose centre projects within `margin` px of such a pixel, or None."""
+    with torch.no_grad():
+        kf = sc.keyframes[kid]
+        lvl = kf.pyr_lvl
+        torch.manual_seed(seed)
+        bg = torch.rand(3, device=sc.device)
+        w, h = sc.width // 2 ** lvl, sc.height // 2 ** lvl
+        Rt = kf.get_Rt().to(sc.device)
+        pkg = sc.render(w, h, Rt, bg)
+        raw = ((kf.exposure[:3, :3] @ pkg["render"].view(3, -1)) + kf.exposure[:3, 3, None]).view(3, h, w)
+        gt = kf.image_pyr[lvl]
+        kn = (((raw - gt).abs() < tol) | (raw.abs() < tol) | ((raw - 1).abs() < tol)).any(0)
+        kn |= ((pkg["invdepth"] - kf.get_mono_idepth(lvl)).abs() < tol)[0]
+        if not is_important:
+            err = sc._rdk_for(h, w) * (raw.clamp(0, 1) - gt).abs()
+            kn |= ((err - 0.2).abs() < tol).any(0)
+        if not bool(kn.any()):
+            return None
+        ys, xs = torch.nonzero(kn, as_tuple=True)
+        cam = sc.xyz @ Rt[:3, :3].T + Rt[:3, 3]
+        z = cam[:, 2].clamp_min(1e-6)
+        f = sc.f / 2 ** lvl
+        u, v = f * cam[:, 0] / z + w / 2.0, f * cam[:, 1] / z + h / 2.0
+        near = torch.zeros(sc.xyz.shape[0], dtype=torch.bool, device=sc.device)
+        for x, y in zip(xs.tolist()[:64], ys.tolist()[:64]):
+            near |= ((u - (x + 0.5)).abs() < margin) & ((v - (y + 0.5)).abs() < margin)
+        return near
+
+
 def _sync_state(src, dst):
     """dst <- src: every Gaussian parameter, both Adam moments, the learning rates, the mlp and the keyframes' state."""
     with torch.no_grad():
@@ -136,6 +169,7 @@ def test_fused_optimization_step_gradients_match_unfused(reg, seed, dev, monkeyp
         for sc in (a, b):   # zero the colour moments so that exp_avg after the step is (1 - b1) * gradient
             for k in ("f_dc", "f_rest"):
                 sc.optimizer.params[k]["exp_avg"].zero_()
+        near_image_knife = _rows_near_image_knife_pixels(a, i % 2, i, is_important=(i != 1))
         grads = {}
         for name, sc in (("a", a), ("b", b)):
             orig = sc.optimizer.step
@@ -174,10 +208,23 @@ def test_fused_optimization_step_gradients_match_unfused(reg, seed, dev, monkeyp
         per_gauss = {k: (grads["a"][k].double(), grads["b"][k].double()) for k in keys}
         per_gauss.update({k: (a.optimizer.params[k]["exp_avg"].double(), b.optimizer.params[k]["exp_avg"].double()) for k in ("f_dc", "f_rest")})
         tol = 2e-3 if knife else 2e-4
+        # The loss has knife edges of its own, in IMAGE space: sign(image - target) of the L1 terms where a rendered value meets its
+        # target, the clamp of the exposed image at 0 and 1, the 0.2 outlier threshold (h3dgsv3.py:432-448).  The two paths' images differ
+        # by ~1e-6; a pixel within 5e-6 of one of these flips dL/dimage there and moves the gradient of the few Gaussians under it by
+        # tens of percent (seed 6, step 0: five rows carried 99.4 % of a 3.8e-3 difference; the CPU-oracle path agrees with BOTH paths to
+        # 1e-6 on another background, tools/lab/fused_grad_diag.py).  Such pixels are identified BEFORE the step from the unfused path's
+        # own render; the Gaussians whose centre projects within 16 px of one leave the per-Gaussian comparison (they must be few), and
+        # the gradients that sum over all Gaussians (mlp, global_feat) are held to 1e-2 on such a step.
+        summed_tol = tol
+        if near_image_knife is not None:
+            assert float(near_image_knife.float().mean()) < 0.3
+            keep_rows = ~near_image_knife
+            per_gauss = {k: ((x[keep_rows], y[keep_rows]) if x.shape[0] == keep_rows.shape[0] else (x, y)) for k, (x, y) in per_gauss.items()}
+            summed_tol = 1e-2
         for k, (x, y) in per_gauss.items():
-            assert rel_of(x, y) <= tol, (i, k, rel_of(x, y), knife)
+            assert rel_of(x, y) <= (summed_tol if k == "global_feat" else tol), (i, k, rel_of(x, y), knife, near_image_knife is not None)
         for k in ["mlp." + n for n, _ in a.mlp_cov.named_parameters()]:
-            assert rel_of(grads["a"][k].double(), grads["b"][k].double()) <= tol, (i, k, knife)
+            assert rel_of(grads["a"][k].double(), grads["b"][k].double()) <= summed_tol, (i, k, knife, near_image_knife is not None)
 
 
 @pytest.mark.gpu
