@@ -53,6 +53,31 @@ __device__ __forceinline__ CamCentre cam_centre_of(const float* __restrict__ V) 
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// ---- sparse Adam of the five per-Gaussian tensors, applied INSIDE the backward (round 4) ---------------------------------------------
+// SparseGaussianAdam.step (Reconstruct/scene/optimizers.py:106-161) runs adamUpdate on xyz / opacity / scaling / rotation / local_feat
+// (27 of a Gaussian's 75 floats; the 48 SH colours already take their step inside the projection backward) on the rows with
+// visibility = radii > 0.  lod_params_bwd is the LAST kernel that touches those five gradients, and each is produced by exactly
+// the thread (or accumulator lane) that can also update the parameter: the gradients are then never written (108 B per Gaussian)
+// nor re-read by a separate Adam kernel together with p, m, v (another 108 B + a launch), and adk_adam_update_multi shrinks to the
+// voxel features, the mlp and the keyframe's pose.  Same arithmetic as adam.hip:adam_elem, IEEE-unfused (this file is compiled with
+// contraction on, hence the pragma): bit-identical to the two-kernel path (tests/test_fused_glue.py).
+struct LodAdam {
+    const uint8_t* visible;                       // [N] rows SparseGaussianAdam.step would touch (radii > 0)
+    float *m_xyz, *v_xyz, *lr_xyz;                // lr_xyz: per-element [N,3], decayed in place on visible rows (optimizers.py:158-161)
+    float *m_opacity, *v_opacity, *m_scaling, *v_scaling, *m_rotation, *v_rotation, *m_local, *v_local;
+    const float *lr_opacity, *lr_scaling, *lr_rotation, *lr_local;   // 0-dim device tensors
+    float lr_decay_xyz, lr_min_xyz, b1, b2, eps;
+};
+
+__device__ __forceinline__ void lod_adam_elem(float& p, float g, float& m, float& v, float lr, float b1, float b2, float omb1, float omb2, float eps)
+{
+#pragma clang fp contract(off)
+    m = b1 * m + omb1 * g;
+    v = b2 * v + omb2 * g * g;
+    const float step = -lr * m / (sqrtf(v) + eps);
+    p += step;
+}
+
 // x[32] = [global_feat[cls], local_feat[g]]
 __device__ __forceinline__ void load_features(const float* __restrict__ global_feat, const float* __restrict__ local_feat,
                                               int64_t cls, int64_t g, float* x)
@@ -156,23 +181,79 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// One visible Gaussian's xyz (per-element lr, decayed in place), opacity, scaling and rotation step (lane = Gaussian).  WITH_LOCAL:
+// also its 16 local features with a zero gradient (chunks without any active Gaussian skip the matrix stages altogether).
+template <bool WITH_LOCAL>
+__device__ __forceinline__ void lod_adam_rows(const LodAdam& A, int64_t g, float lr_o, float lr_s, float lr_r, float lr_l, float omb1, float omb2,
+                                              float* xyz, float* opacity_raw, float* scaling_raw, float* rotation, float* local_feat,
+                                              float go, float gs0, float gs1, float gs2, float4 gq, float gx0, float gx1, float gx2)
+{
+    const float b1 = A.b1, b2 = A.b2, eps = A.eps;
+    {   // opacity [N,1]
+        float p = opacity_raw[g], m = A.m_opacity[g], v = A.v_opacity[g];
+        lod_adam_elem(p, go, m, v, lr_o, b1, b2, omb1, omb2, eps);
+        opacity_raw[g] = p; A.m_opacity[g] = m; A.v_opacity[g] = v;
+    }
+    const float gs[3] = {gs0, gs1, gs2}, gx[3] = {gx0, gx1, gx2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // scaling [N,3], xyz [N,3] with its per-element learning rate
+        float p = scaling_raw[3 * g + k], m = A.m_scaling[3 * g + k], v = A.v_scaling[3 * g + k];
+        lod_adam_elem(p, gs[k], m, v, lr_s, b1, b2, omb1, omb2, eps);
+        scaling_raw[3 * g + k] = p; A.m_scaling[3 * g + k] = m; A.v_scaling[3 * g + k] = v;
+        float px = xyz[3 * g + k], mx = A.m_xyz[3 * g + k], vx = A.v_xyz[3 * g + k];
+        const float lr = A.lr_xyz[3 * g + k];
+        lod_adam_elem(px, gx[k], mx, vx, lr, b1, b2, omb1, omb2, eps);
+        xyz[3 * g + k] = px; A.m_xyz[3 * g + k] = mx; A.v_xyz[3 * g + k] = vx;
+        if (A.lr_decay_xyz != 1.0f) A.lr_xyz[3 * g + k] = fmaxf(lr * A.lr_decay_xyz, A.lr_min_xyz);
+    }
+    {   // rotation [N,4]
+        float4 p = reinterpret_cast<float4*>(rotation)[g], m = reinterpret_cast<float4*>(A.m_rotation)[g], v = reinterpret_cast<float4*>(A.v_rotation)[g];
+        lod_adam_elem(p.x, gq.x, m.x, v.x, lr_r, b1, b2, omb1, omb2, eps);
+        lod_adam_elem(p.y, gq.y, m.y, v.y, lr_r, b1, b2, omb1, omb2, eps);
+        lod_adam_elem(p.z, gq.z, m.z, v.z, lr_r, b1, b2, omb1, omb2, eps);
+        lod_adam_elem(p.w, gq.w, m.w, v.w, lr_r, b1, b2, omb1, omb2, eps);
+        reinterpret_cast<float4*>(rotation)[g] = p; reinterpret_cast<float4*>(A.m_rotation)[g] = m; reinterpret_cast<float4*>(A.v_rotation)[g] = v;
+    }
+    if (WITH_LOCAL) {
+#pragma unroll
+        for (int i = 0; i < LOD_L / 4; ++i) {
+            float4 p = reinterpret_cast<float4*>(local_feat + g * LOD_L)[i], m = reinterpret_cast<float4*>(A.m_local + g * LOD_L)[i],
+                   v = reinterpret_cast<float4*>(A.v_local + g * LOD_L)[i];
+            lod_adam_elem(p.x, 0.f, m.x, v.x, lr_l, b1, b2, omb1, omb2, eps);
+            lod_adam_elem(p.y, 0.f, m.y, v.y, lr_l, b1, b2, omb1, omb2, eps);
+            lod_adam_elem(p.z, 0.f, m.z, v.z, lr_l, b1, b2, omb1, omb2, eps);
+            lod_adam_elem(p.w, 0.f, m.w, v.w, lr_l, b1, b2, omb1, omb2, eps);
+            reinterpret_cast<float4*>(local_feat + g * LOD_L)[i] = p; reinterpret_cast<float4*>(A.m_local + g * LOD_L)[i] = m;
+            reinterpret_cast<float4*>(A.v_local + g * LOD_L)[i] = v;
+        }
+    }
+}
+
+// ADAM: the five per-Gaussian parameter tensors are updated in place (see LodAdam) and their gradients are not written; every read of
+// a parameter precedes the write of the same element in the same thread, so the pointers simply lose their __restrict__.
+template <bool ADAM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lod_params_bwd_kernel(
-    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
-    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
+    int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
+    const float* rotation, const float* local_feat, const float* __restrict__ global_feat,
     const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ viewmat, const float* __restrict__ v_opac_eff, const float* __restrict__ v_scale_eff,
     const float* __restrict__ v_quat_eff,
     float* __restrict__ v_xyz_add /* [N,3] += (fade term) */, float* __restrict__ v_opacity_raw,
     float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation, float* __restrict__ v_local_feat,
-    float* __restrict__ v_global_feat /* [V,G], zeroed, atomics */, float* __restrict__ partials /* [gridDim.x][LOD_NW] */)
+    float* __restrict__ v_global_feat /* [V,G], zeroed, atomics */, float* __restrict__ partials /* [gridDim.x][LOD_NW] */,
+    const LodAdam A)
 {
     // Two 64x33 tiles + a 64x9 one = 19.5 KB per wavefront => 8 single-wave workgroups per CU (2 per SIMD, which is
     // also what the 256-VGPR budget allows).  TH holds H, later VZ: H is dead once dW2 has been accumulated, and
     // the stage order below is chosen so that this alias is legal.
     __shared__ float TX[64 * LOD_LDW], TH[64 * LOD_LDW], TY[64 * LOD_YW];
     __shared__ int TC[64];
+    __shared__ unsigned char TV[64];   // ADAM: the chunk's visibility flags, for the accumulator-layout local_feat update
     float* const TZ = TH;
+    const float omb1 = 1.0f - A.b1, omb2 = 1.0f - A.b2;
+    float lr_o = 0.f, lr_s = 0.f, lr_r = 0.f, lr_l = 0.f;
+    if (ADAM) { lr_o = A.lr_opacity[0]; lr_s = A.lr_scaling[0]; lr_r = A.lr_rotation[0]; lr_l = A.lr_local[0]; }
     const int lane = threadIdx.x, kk = lane >> 5, rc = lane & 31;
 
     // weight fragments (B operands), resident for the whole kernel
@@ -206,6 +287,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         LodGeom L;
         L.alpha_ratio = 1.f; L.inv_dmax = 0.f; L.fading = false; L.selected = false; L.dist = 0.f;
         L.dir[0] = L.dir[1] = L.dir[2] = 0.f;
+        bool visible = false;
+        if (ADAM) { visible = g < N && A.visible[g] != 0; TV[lane] = visible ? 1 : 0; }
         if (g < N) {
             vo = v_opac_eff[g];
             vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
@@ -214,6 +297,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
         }
         if (__ballot(active) == 0ull) { // nothing visible in this chunk: zero gradients, no matrix work
+            if (ADAM) {
+                // visible rows still take their Adam step (zero gradient: the moments decay, the parameter moves by -lr m / (sqrt(v) + eps))
+                if (visible) {
+                    lod_adam_rows<true>(A, g, lr_o, lr_s, lr_r, lr_l, omb1, omb2, const_cast<float*>(xyz), const_cast<float*>(opacity_raw),
+                                        const_cast<float*>(scaling_raw), const_cast<float*>(rotation), const_cast<float*>(local_feat), 0.f,
+                                        0.f, 0.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), v_xyz_add[3 * g], v_xyz_add[3 * g + 1], v_xyz_add[3 * g + 2]);
+                }
+                continue;
+            }
             if (g < N) {
                 v_opacity_raw[g] = 0.f;
                 v_scaling_raw[3 * g] = 0.f; v_scaling_raw[3 * g + 1] = 0.f; v_scaling_raw[3 * g + 2] = 0.f;
@@ -304,7 +396,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 gq = make_float4(vq.x * y[3], vq.y * y[4], vq.z * y[5], vq.w * y[6]);
                 vy[3] = vq.x * q.x; vy[4] = vq.y * q.y; vy[5] = vq.z * q.z; vy[6] = vq.w * q.w;
             }
-            if (g < N) {
+            if (ADAM) {
+                if (visible)
+                    lod_adam_rows<false>(A, g, lr_o, lr_s, lr_r, lr_l, omb1, omb2, const_cast<float*>(xyz), const_cast<float*>(opacity_raw),
+                                         const_cast<float*>(scaling_raw), const_cast<float*>(rotation), const_cast<float*>(local_feat), go,
+                                         gs[0], gs[1], gs[2], gq, v_xyz_add[3 * g] + gx[0], v_xyz_add[3 * g + 1] + gx[1], v_xyz_add[3 * g + 2] + gx[2]);
+            } else if (g < N) {
                 v_opacity_raw[g] = go;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { v_scaling_raw[3 * g + k] = gs[k]; if (gx[k] != 0.f) v_xyz_add[3 * g + k] += gx[k]; }
@@ -362,7 +459,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int s = 0; s < 16; ++s)
                 d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w1n[s], d, 0, 0, 0);
-            if (rc >= LOD_G) {
+            if (ADAM && rc >= LOD_G) {
+                // the gradient d[r] of local_feat[row][rc - 16] meets its parameter and moments here: same 64 B-line-per-quarter-wave
+                // pattern as the gradient store it replaces
+                const int64_t off0 = ((int64_t)chunk * 64 + 4 * kk) * LOD_L + (rc - LOD_G);
+                float* pb = const_cast<float*>(local_feat) + off0;
+                float* mb = A.m_local + off0;
+                float* vb = A.v_local + off0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = rb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (TV[row0 + 4 * kk]) {   // visible implies row < N
+                        float p = pb[row0 * LOD_L], m = mb[row0 * LOD_L], v = vb[row0 * LOD_L];
+                        lod_adam_elem(p, d[r], m, v, lr_l, A.b1, A.b2, omb1, omb2, A.eps);
+                        pb[row0 * LOD_L] = p; mb[row0 * LOD_L] = m; vb[row0 * LOD_L] = v;
+                    }
+                }
+            } else if (rc >= LOD_G) {
                 // one base address per lane, compile-time row offsets (immediate-offset stores)
                 float* lbase = v_local_feat + ((int64_t)chunk * 64 + 4 * kk) * LOD_L + (rc - LOD_G);
                 if ((int64_t)chunk * 64 + 64 <= N) {
@@ -516,10 +629,60 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)v_quat_eff | (uintptr_t)v_rotation | (uintptr_t)v_local_feat) & 15) return ADK_EINVAL;
     int nb = (int)adk::ceil_div(N, 64);
     if (nb > LOD_BWD_MAX_BLOCKS) nb = LOD_BWD_MAX_BLOCKS;
-    hipLaunchKernelGGL(adk::lod_params_bwd_kernel, dim3(nb), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw,
+    adk::LodAdam none{};
+    hipLaunchKernelGGL(adk::lod_params_bwd_kernel<false>, dim3(nb), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw,
                        rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff,
                        v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat,
-                       (float*)workspace);
+                       (float*)workspace, none);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, v_mlp);
+    ADK_RETURN_LAST_ERROR();
+}
+
+// adk_lod_params_bwd with the sparse-Adam step of xyz / opacity / scaling / rotation / local_feat applied INSIDE the kernel
+// (SparseGaussianAdam.step, Reconstruct/scene/optimizers.py:136-161, for those five keys) on the rows with visible[g] != 0:
+// the five parameter tensors (xyz .. local_feat, the same pointers the gradient is evaluated at) and their moments are updated in
+// place, their gradients are NOT written (there are no v_opacity_raw / v_scaling_raw / v_rotation / v_local_feat arguments), xyz's
+// per-element learning rate lr_xyz [N,3] is decayed in place on the visible rows: lr = max(lr * lr_decay_xyz, lr_min_xyz).
+// v_xyz (the rasteriser's gradient of the means) is only read.  lr_opacity .. lr_local: 0-dim device tensors.  v_global_feat
+// (zero-filled by the caller, atomics) and v_mlp are produced as by adk_lod_params_bwd: their Adam stays with the caller.
+extern "C" int adk_lod_params_bwd_adam(int N, float* xyz, float* opacity_raw, float* scaling_raw, float* rotation, float* local_feat,
+                                       const float* global_feat, const int64_t* cls_id, const float* d_max, int local_dim, int global_dim,
+                                       int hidden_dim, const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                                       const float* v_opac_eff, const float* v_scale_eff, const float* v_quat_eff, const float* v_xyz,
+                                       float* v_global_feat, float* v_mlp, void* workspace, int64_t workspace_bytes,
+                                       const uint8_t* visible, float* m_xyz, float* v2_xyz, float* lr_xyz, float lr_decay_xyz, float lr_min_xyz,
+                                       float* m_opacity, float* v2_opacity, const float* lr_opacity, float* m_scaling, float* v2_scaling,
+                                       const float* lr_scaling, float* m_rotation, float* v2_rotation, const float* lr_rotation,
+                                       float* m_local, float* v2_local, const float* lr_local, float beta1, float beta2, float eps,
+                                       hipStream_t stream)
+{
+    if (N < 0) return ADK_EINVAL;
+    if (local_dim != LOD_L || global_dim != LOD_G || hidden_dim != LOD_HID) return ADK_EUNSUPPORTED;
+    if (!v_mlp) return ADK_EINVAL;
+    if (N == 0) return adk::clear_bytes(v_mlp, LOD_NW * sizeof(float), stream);
+    if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 || !viewmat) return ADK_EINVAL;
+    if (!v_opac_eff || !v_scale_eff || !v_quat_eff || !v_xyz || !v_global_feat || !workspace) return ADK_EINVAL;
+    if (!visible || !m_xyz || !v2_xyz || !lr_xyz || !m_opacity || !v2_opacity || !lr_opacity || !m_scaling || !v2_scaling || !lr_scaling ||
+        !m_rotation || !v2_rotation || !lr_rotation || !m_local || !v2_local || !lr_local) return ADK_EINVAL;
+    if (workspace_bytes < adk_lod_params_bwd_workspace_bytes(N)) return ADK_EWORKSPACE;
+    if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)v_quat_eff | (uintptr_t)m_rotation | (uintptr_t)v2_rotation |
+         (uintptr_t)m_local | (uintptr_t)v2_local) & 15) return ADK_EINVAL;
+    int nb = (int)adk::ceil_div(N, 64);
+    if (nb > LOD_BWD_MAX_BLOCKS) nb = LOD_BWD_MAX_BLOCKS;
+    adk::LodAdam A;
+    A.visible = visible;
+    A.m_xyz = m_xyz; A.v_xyz = v2_xyz; A.lr_xyz = lr_xyz; A.lr_decay_xyz = lr_decay_xyz; A.lr_min_xyz = lr_min_xyz;
+    A.m_opacity = m_opacity; A.v_opacity = v2_opacity; A.lr_opacity = lr_opacity;
+    A.m_scaling = m_scaling; A.v_scaling = v2_scaling; A.lr_scaling = lr_scaling;
+    A.m_rotation = m_rotation; A.v_rotation = v2_rotation; A.lr_rotation = lr_rotation;
+    A.m_local = m_local; A.v_local = v2_local; A.lr_local = lr_local;
+    A.b1 = beta1; A.b2 = beta2; A.eps = eps;
+    hipLaunchKernelGGL(adk::lod_params_bwd_kernel<true>, dim3(nb), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw,
+                       rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff,
+                       v_quat_eff, const_cast<float*>(v_xyz), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_global_feat,
+                       (float*)workspace, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, v_mlp);

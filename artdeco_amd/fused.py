@@ -29,6 +29,65 @@ from .rasterizer import _WS, _stage, render_camera
 _NW = 32 * 32 + 32 + 7 * 32 + 7
 
 
+_LOD_ADAM: dict | None = None
+
+
+@contextlib.contextmanager
+def lod_adam(state: dict | None):
+    """While active, FusedLodParams.backward applies the sparse-Adam step of xyz / opacity / scaling / rotation / local_feat inside
+    the kernel (adk_lod_params_bwd_adam: SparseGaussianAdam.step for those five keys, optimizers.py:136-161) instead of returning
+    their gradients: the gradients are then never written (108 B per Gaussian) nor re-read by a separate Adam launch together with
+    p, m and v.  state: see _lod_adam_state.  Only takes effect when the tensors the backward was evaluated at are exactly those
+    parameters; otherwise the gradients are returned as usual.  Process-wide, not thread-local: autograd runs backward nodes on its own
+    device thread."""
+    global _LOD_ADAM
+    prev = _LOD_ADAM
+    _LOD_ADAM = state
+    try:
+        yield
+    finally:
+        _LOD_ADAM = prev
+
+
+_LOD_ADAM_KEYS = ("xyz", "opacity", "scaling", "rotation", "local_feat")
+
+
+def _lod_adam_state(opt, visibility):
+    """State for lod_adam from a SparseGaussianAdam (Reconstruct/scene/optimizers.py:59-75) and the step's visibility mask, or None
+    when the layout is not run.sh's: xyz with a per-element learning rate [N,3] in lr_dict (decay + floor), the other four with 0-dim
+    device learning rates and no schedule, everything contiguous float32 on one device, ARTDECO_AMD_LOD_ADAM != 0."""
+    if os.environ.get("ARTDECO_AMD_LOD_ADAM", "1") == "0":
+        return None
+    try:
+        P = opt.params
+        st = {"visible": visibility, "betas": tuple(float(b) for b in opt.betas), "eps": float(opt.eps)}
+        if visibility.dtype != torch.bool or not visibility.is_contiguous() or not visibility.is_cuda:
+            return None
+        for k in _LOD_ADAM_KEYS:
+            pd = P[k]
+            val, m, v, lr = pd["val"], pd["exp_avg"], pd["exp_avg_sq"], pd["lr"]
+            if not (torch.is_tensor(lr) and lr.is_cuda and lr.dtype == torch.float32 and lr.is_contiguous()):
+                return None
+            if not val.requires_grad:   # e.g. xyz / rotation between rigid_transform_gs and the next add_and_prune (h3dgsv3.py:964-965):
+                return None             # the reference's step skips a parameter without a gradient; so must this
+            for t in (val, m, v):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == visibility.device):
+                    return None
+            if m.numel() != val.numel() or v.numel() != val.numel() or val.shape[0] != visibility.numel():
+                return None
+            if k == "xyz":
+                if k not in opt.lr_dict or lr.numel() != val.numel():
+                    return None
+                st["lr_decay_xyz"] = float(opt.lr_dict[k]["lr_decay"])
+                st["lr_min_xyz"] = float(opt.lr_dict[k]["lr_init"] * 0.1)
+            elif k in opt.lr_dict or lr.numel() != 1:
+                return None
+            st[k] = pd
+        return st
+    except (KeyError, AttributeError, TypeError):
+        return None
+
+
 class FusedLodParams(torch.autograd.Function):
     """(xyz, opacity_raw[N,1], scaling_raw[N,3], rotation[N,4], local_feat[N,16], global_feat[V,16],
     W1, b1, W2, b2 | cls_id, d_max, viewmat) -> opac_eff [N], scale_eff [N,3], quat_eff [N,4], selected [N] bool, xyz
@@ -86,11 +145,35 @@ class FusedLodParams(torch.autograd.Function):
                 v_xyz = v_xyz_through          # the rasteriser's v_means: the fade term is accumulated into it
             else:
                 v_xyz = torch.zeros_like(xyz) if v_xyz_through is None else v_xyz_through.float().contiguous().clone()
-            v_o, v_s, v_r = torch.empty_like(opacity_raw), torch.empty_like(scaling_raw), torch.empty_like(rotation)
-            v_lf = torch.empty_like(local_feat)
             v_gf = torch.zeros_like(global_feat)
             v_mlp = torch.empty(_NW, dtype=torch.float32, device=dev)
             ws = _WS.get(dev, int(lib.adk_lod_params_bwd_workspace_bytes(N)))
+            st = _LOD_ADAM
+            if st is not None and all(t.data_ptr() == st[k]["val"].data_ptr() and t.numel() == st[k]["val"].numel() for k, t in
+                                      zip(_LOD_ADAM_KEYS, (xyz, opacity_raw, scaling_raw, rotation, local_feat))):
+                # the five per-Gaussian tensors take their Adam step inside the kernel; no gradient tensors for them
+                A = {k: st[k] for k in _LOD_ADAM_KEYS}
+                b1_, b2_ = st["betas"]
+                with _stage("lod_params_bwd"):
+                    rc = lib.adk_lod_params_bwd_adam(
+                        N, xyz.data_ptr(), opacity_raw.data_ptr(), scaling_raw.data_ptr(), rotation.data_ptr(), local_feat.data_ptr(),
+                        global_feat.data_ptr(), cls_id.data_ptr(), d_max.data_ptr(), L, G, Hd, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(),
+                        b2.data_ptr(), viewmat.data_ptr(), v_opac.data_ptr(), v_scale.data_ptr(), v_quat.data_ptr(), v_xyz.data_ptr(),
+                        v_gf.data_ptr(), v_mlp.data_ptr(), ws.data_ptr(), ws.numel(), st["visible"].data_ptr(),
+                        A["xyz"]["exp_avg"].data_ptr(), A["xyz"]["exp_avg_sq"].data_ptr(), A["xyz"]["lr"].data_ptr(), st["lr_decay_xyz"], st["lr_min_xyz"],
+                        A["opacity"]["exp_avg"].data_ptr(), A["opacity"]["exp_avg_sq"].data_ptr(), A["opacity"]["lr"].data_ptr(),
+                        A["scaling"]["exp_avg"].data_ptr(), A["scaling"]["exp_avg_sq"].data_ptr(), A["scaling"]["lr"].data_ptr(),
+                        A["rotation"]["exp_avg"].data_ptr(), A["rotation"]["exp_avg_sq"].data_ptr(), A["rotation"]["lr"].data_ptr(),
+                        A["local_feat"]["exp_avg"].data_ptr(), A["local_feat"]["exp_avg_sq"].data_ptr(), A["local_feat"]["lr"].data_ptr(),
+                        b1_, b2_, st["eps"], _lib.stream_of(xyz))
+                _lib.check(rc, "adk_lod_params_bwd_adam")
+                st["applied"] = True
+                vW1 = v_mlp[:Hd * (G + L)].view(Hd, G + L)
+                vb1 = v_mlp[Hd * (G + L):Hd * (G + L) + Hd]
+                o2 = Hd * (G + L) + Hd
+                return None, None, None, None, None, v_gf, vW1, vb1, v_mlp[o2:o2 + 7 * Hd].view(7, Hd), v_mlp[o2 + 7 * Hd:o2 + 7 * Hd + 7], None, None, None
+            v_o, v_s, v_r = torch.empty_like(opacity_raw), torch.empty_like(scaling_raw), torch.empty_like(rotation)
+            v_lf = torch.empty_like(local_feat)
             with _stage("lod_params_bwd"):
                 rc = lib.adk_lod_params_bwd(N, xyz.data_ptr(), opacity_raw.data_ptr(), scaling_raw.data_ptr(),
                                             rotation.data_ptr(), local_feat.data_ptr(), global_feat.data_ptr(),
@@ -490,6 +573,12 @@ def _color_adam_state(opt):
         return None
 
 
+def _gaussian_step_is_ours(self, keyframe) -> bool:
+    """The Gaussians' optimizer step of this training step will be fused_optimizer_step (not a caller's override, not a test keyframe,
+    whose Gaussians are not stepped at all): only then may parts of that step be applied ahead of it, inside the backward kernels."""
+    return getattr(self.optimizer.step, "__func__", None) is fused_optimizer_step and not keyframe.is_test
+
+
 def _apply_steps(self, keyframe, vis, gvis, invdepth):
     """Pose / exposure step of the keyframe, sparse-Adam step of the Gaussians, latest_invdepth (h3dgsv3.py:456-464)."""
     with torch.no_grad():
@@ -579,7 +668,8 @@ def _train_on_keyframe_by_hand(self, keyframe, is_important):
         v_col, v_alpha, v_E = FusedMapperLoss.backward(c_loss, _unit_grad(loss))[:3]
         with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
             v_means, v_quats, v_scales, v_opac, v_dc, v_rest, v_viewmat = rasterizer.RasterizeGaussians.backward(c_ras, v_col, v_alpha)[:7]
-        lod_grads = FusedLodParams.backward(c_lod, v_opac, v_scales, v_quats, None, v_means)[:10]
+        with lod_adam(_lod_adam_state(self.optimizer, vis) if _gaussian_step_is_ours(self, keyframe) else None):
+            lod_grads = FusedLodParams.backward(c_lod, v_opac, v_scales, v_quats, None, v_means)[:10]
         for leaf, g in zip(lod_leaves, lod_grads):
             _accumulate(leaf, g)
         _accumulate(f_dc, v_dc)
@@ -631,7 +721,8 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
         loss = loss + self.scaling_reg_factor * (scaling.prod(dim=1) * selw).sum() / selw.sum().clamp_min(1.0)
     # the SH colours (48 of the 75 floats of a Gaussian) take their Adam step inside the projection backward, on
     # exactly the rows optimizer.step would touch (radii > 0); their .grad stays None and the step below skips them
-    with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)):
+    with rasterizer.color_adam(None if keyframe.is_test else _color_adam_state(self.optimizer)), \
+            lod_adam(_lod_adam_state(self.optimizer, vis) if _gaussian_step_is_ours(self, keyframe) else None):
         loss.backward(gradient=_unit_grad(loss))
     _apply_steps(self, keyframe, vis, gvis, invdepth)
     return loss.detach()

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 14
+#define ADK_ABI_VERSION 15
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -349,6 +349,25 @@ int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_raw, const 
                        float* v_xyz_add, float* v_opacity_raw, float* v_scaling_raw, float* v_rotation,
                        float* v_local_feat, float* v_global_feat, float* v_mlp, void* workspace,
                        int64_t workspace_bytes, adk_stream_t stream);
+
+/* adk_lod_params_bwd with the sparse-Adam step of xyz / opacity / scaling / rotation / local_feat applied INSIDE the kernel: replaces
+ * the adamUpdate calls of SparseGaussianAdam.step for those five keys (Reconstruct/scene/optimizers.py:136-161; 27 of a Gaussian's 75
+ * floats -- the 48 SH colours take theirs inside adk_project_bwd_adam) on the rows with visible[g] != 0 (visibility = radii > 0,
+ * h3dgsv3.py:695).  The five parameter tensors and their moments (m_*, v2_* = exp_avg, exp_avg_sq) are updated IN PLACE, their
+ * gradients are never written; lr_xyz [N,3] is xyz's per-element learning rate, decayed in place on the visible rows after the update,
+ * lr = max(lr * lr_decay_xyz, lr_min_xyz) (optimizers.py:158-161); lr_opacity .. lr_local are 0-dim device tensors.  v_xyz (the
+ * rasteriser's gradient of the means) is only read.  v_global_feat (zero-filled by the caller) and v_mlp as adk_lod_params_bwd.
+ * Arithmetic = adk_adam_update's, IEEE-unfused: bit-identical to adk_lod_params_bwd followed by adk_adam_update_multi. */
+int adk_lod_params_bwd_adam(int N, float* xyz, float* opacity_raw, float* scaling_raw, float* rotation, float* local_feat,
+                            const float* global_feat, const int64_t* cls_id, const float* d_max, int local_dim, int global_dim,
+                            int hidden_dim, const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                            const float* v_opac_eff, const float* v_scale_eff, const float* v_quat_eff, const float* v_xyz,
+                            float* v_global_feat, float* v_mlp, void* workspace, int64_t workspace_bytes,
+                            const uint8_t* visible, float* m_xyz, float* v2_xyz, float* lr_xyz, float lr_decay_xyz, float lr_min_xyz,
+                            float* m_opacity, float* v2_opacity, const float* lr_opacity, float* m_scaling, float* v2_scaling,
+                            const float* lr_scaling, float* m_rotation, float* v2_rotation, const float* lr_rotation,
+                            float* m_local, float* v2_local, const float* lr_local, float beta1, float beta2, float eps,
+                            adk_stream_t stream);
 
 /* Replaces the per-keyframe loop of SceneModel.weed_out_gaussians (h3dgsv3.py:943-950): counts[g] = number of
  * keyframes whose camera centre -R^T t (R = sixD2mtx(r6[k]), r6 [n_kf,3,2], t [n_kf,3]) lies within 2 d_max[g]

@@ -33,8 +33,11 @@ def _capture_rasteriser_inputs(monkeypatch):
     seen = []
 
     def spy(**kw):
-        seen.append({k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
-        return real(**kw)
+        rec = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in kw.items()}
+        out = real(**kw)
+        rec["_radii"], rec["_means2d"] = out[2]["radii"][0].detach(), out[2]["means2d"][0].detach()   # of the LoD-selected subset
+        seen.append(rec)
+        return out
     monkeypatch.setattr(mapper, "gsplat", types.SimpleNamespace(rendering=types.SimpleNamespace(rasterization=spy)))
     return seen
 
@@ -93,11 +96,12 @@ def test_fused_render_matches_unfused(lod, dev, monkeypatch):
         assert rel <= 1e-4, (k, rel)
 
 
-def _rows_near_image_knife_pixels(sc, kid, seed, is_important, tol=5e-6, margin=16.0):
+def _rows_under_image_knife_pixels(sc, kid, seed, is_important, seen, tol=5e-6):
     """Pixels on which the LOSS (not the rasteriser) sits on a decision -- |exposed render - target| < tol (sign of an L1 term), exposed
     render within tol of the clamp bounds 0 / 1, inverse depth within tol of its target, weighted error within tol of the 0.2 outlier
     threshold -- evaluated on the unfused scene's own render with the background the step is about to draw (torch.manual_seed(seed),
-    first torch.rand(3)).  Returns a bool [N] mask of the Gaussians whose centre projects within `margin` px of such a pixel, or None."""
+    first torch.rand(3)).  Returns a bool [N] mask of the Gaussians whose radius box (the rasteriser's own radii: it bounds every pixel
+    the Gaussian can reach) covers such a pixel, or None when there is no such pixel.  `seen`: the spy of _capture_rasteriser_inputs."""
     with torch.no_grad():
         kf = sc.keyframes[kid]
         lvl = kf.pyr_lvl
@@ -116,14 +120,17 @@ def _rows_near_image_knife_pixels(sc, kid, seed, is_important, tol=5e-6, margin=
         if not bool(kn.any()):
             return None
         ys, xs = torch.nonzero(kn, as_tuple=True)
-        cam = sc.xyz @ Rt[:3, :3].T + Rt[:3, 3]
-        z = cam[:, 2].clamp_min(1e-6)
-        f = sc.f / 2 ** lvl
-        u, v = f * cam[:, 0] / z + w / 2.0, f * cam[:, 1] / z + h / 2.0
-        near = torch.zeros(sc.xyz.shape[0], dtype=torch.bool, device=sc.device)
-        for x, y in zip(xs.tolist()[:64], ys.tolist()[:64]):
-            near |= ((u - (x + 0.5)).abs() < margin) & ((v - (y + 0.5)).abs() < margin)
-        return near
+        # the rasteriser saw the LoD-selected subset (harness/mapper.py:render, h3dgsv3.py:626-639): map its rows back
+        cam_centre = Rt.inverse()[:3, 3]
+        selected = torch.nonzero(((sc.xyz - cam_centre).norm(dim=1, keepdim=True) < 2 * sc.d_max).squeeze(-1)).squeeze(-1)
+        radii, m2d = seen[-1]["_radii"].to(sc.device).float(), seen[-1]["_means2d"].to(sc.device)
+        assert radii.shape[0] == selected.shape[0]
+        under = torch.zeros(radii.shape[0], dtype=torch.bool, device=sc.device)
+        for x, y in zip(xs.tolist()[:256], ys.tolist()[:256]):
+            under |= (radii[:, 0] > 0) & ((m2d[:, 0] - (x + 0.5)).abs() <= radii[:, 0] + 1) & ((m2d[:, 1] - (y + 0.5)).abs() <= radii[:, 1] + 1)
+        rows = torch.zeros(sc.xyz.shape[0], dtype=torch.bool, device=sc.device)
+        rows[selected[under]] = True
+        return rows
 
 
 def _sync_state(src, dst):
@@ -169,7 +176,7 @@ def test_fused_optimization_step_gradients_match_unfused(reg, seed, dev, monkeyp
         for sc in (a, b):   # zero the colour moments so that exp_avg after the step is (1 - b1) * gradient
             for k in ("f_dc", "f_rest"):
                 sc.optimizer.params[k]["exp_avg"].zero_()
-        near_image_knife = _rows_near_image_knife_pixels(a, i % 2, i, is_important=(i != 1))
+        near_image_knife = _rows_under_image_knife_pixels(a, i % 2, i, is_important=(i != 1), seen=seen)
         grads = {}
         for name, sc in (("a", a), ("b", b)):
             orig = sc.optimizer.step
@@ -213,7 +220,7 @@ def test_fused_optimization_step_gradients_match_unfused(reg, seed, dev, monkeyp
         # by ~1e-6; a pixel within 5e-6 of one of these flips dL/dimage there and moves the gradient of the few Gaussians under it by
         # tens of percent (seed 6, step 0: five rows carried 99.4 % of a 3.8e-3 difference; the CPU-oracle path agrees with BOTH paths to
         # 1e-6 on another background, tools/lab/fused_grad_diag.py).  Such pixels are identified BEFORE the step from the unfused path's
-        # own render; the Gaussians whose centre projects within 16 px of one leave the per-Gaussian comparison (they must be few), and
+        # own render; the Gaussians whose radius box covers one leave the per-Gaussian comparison (they must be few), and
         # the gradients that sum over all Gaussians (mlp, global_feat) are held to 1e-2 on such a step.
         summed_tol = tol
         if near_image_knife is not None:
@@ -580,6 +587,122 @@ def test_fused_step_applies_colour_adam_in_backward(dev):
     ua = (a.gaussian_params["f_rest"]["val"] - p0).flatten().double()
     ub = (b.gaussian_params["f_rest"]["val"] - p0).flatten().double()
     assert float(ua.norm()) > 0 and float((ua @ ub) / (ua.norm() * ub.norm())) > 0.97
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [5000, 777, 64 * 40])   # ragged last chunk / whole chunks only
+def test_lod_adam_inside_backward_is_bit_identical(N, dev):
+    """adk_lod_params_bwd_adam (sparse-Adam step of xyz / opacity / scaling / rotation / local_feat inside the LoD backward) leaves the
+    same parameters, moments and per-element xyz learning rates, bit for bit, as adk_lod_params_bwd + adamUpdate on the visible rows
+    (+ the reference's lr decay, optimizers.py:158-161), and the same mlp gradient; rows that are not visible stay untouched, visible
+    rows with a ZERO incoming gradient still take their step (incl. whole 64-Gaussian chunks without any gradient, which skip the
+    matrix stages).  One fixed set of incoming gradients: the rasteriser's atomics are not order-deterministic across two full steps."""
+    import artdeco_amd
+    artdeco_amd.install_dropins()
+    from diff_gaussian_rasterization import adamUpdate
+    from artdeco_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N)
+    t = lambda x: x.to(dev).contiguous()
+    V = 300
+    xyz = t(torch.randn(N, 3, generator=g) * 0.5 + torch.tensor([0.0, 0.0, 3.0]))
+    opacity, scaling = t(torch.randn(N, 1, generator=g)), t(torch.randn(N, 3, generator=g) * 0.3 - 3.0)
+    rotation, local = t(torch.randn(N, 4, generator=g)), t(0.5 * torch.randn(N, 16, generator=g))
+    gfeat = t(0.5 * torch.randn(V, 16, generator=g))
+    cls = t(torch.randint(0, V, (N,), generator=g))
+    d_max = t(1.5 + 2.0 * torch.rand(N, 1, generator=g))     # some culled (dist >= 2 d_max), some fading
+    W1, b1 = t(0.3 * torch.randn(32, 32, generator=g)), t(0.1 * torch.randn(32, generator=g))
+    W2, b2 = t(0.3 * torch.randn(7, 32, generator=g)), t(0.1 * torch.randn(7, generator=g))
+    viewmat = torch.eye(4, device=dev)
+    vis = t(torch.rand(N, generator=g) < 0.7)
+    vis[128:192] = False                                      # a whole chunk invisible
+    v_opac, v_scale, v_quat, v_means = t(torch.randn(N, generator=g)), t(torch.randn(N, 3, generator=g)), t(torch.randn(N, 4, generator=g)), t(torch.randn(N, 3, generator=g))
+    zero_rows = torch.zeros(N, dtype=torch.bool, device=dev)
+    zero_rows[::5] = True
+    if N > 400:
+        zero_rows[256:320] = True                             # a whole chunk of visible rows WITHOUT gradient: the skip path
+        vis[256:320] = True
+    for x in (v_opac, v_scale, v_quat):
+        x[zero_rows] = 0
+    v_means[zero_rows] = 0
+    keys = ("xyz", "opacity", "scaling", "rotation", "local_feat")
+    P0 = dict(xyz=xyz, opacity=opacity, scaling=scaling, rotation=rotation, local_feat=local)
+    M0 = {k: t(0.01 * torch.randn(v.shape, generator=g)) for k, v in P0.items()}
+    S0 = {k: t(1e-4 * torch.rand(v.shape, generator=g)) for k, v in P0.items()}
+    lr_xyz0 = t(1e-4 * (0.5 + torch.rand(N, 3, generator=g)))
+    lr = {k: torch.tensor(v, device=dev) for k, v in (("opacity", 5e-2), ("scaling", 5e-3), ("rotation", 1e-3), ("local_feat", 2e-3))}
+    decay, lr_min, be1, be2, eps = 0.99, 8e-5, 0.5, 0.99, 1e-15
+    st = _lib.stream_of(xyz)
+    ws = torch.empty(int(lib.adk_lod_params_bwd_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+
+    # reference path: gradients, then the optimiser
+    A, Am, As = ({k: v.clone() for k, v in D.items()} for D in (P0, M0, S0))
+    lrA = lr_xyz0.clone()
+    v_xyz = v_means.clone()
+    v_o, v_s, v_r, v_lf = torch.empty_like(opacity), torch.empty_like(scaling), torch.empty_like(rotation), torch.empty_like(local)
+    v_gfA, v_mlpA = torch.zeros_like(gfeat), torch.empty(1287, device=dev)
+    _lib.check(lib.adk_lod_params_bwd(N, A["xyz"].data_ptr(), A["opacity"].data_ptr(), A["scaling"].data_ptr(), A["rotation"].data_ptr(),
+                                      A["local_feat"].data_ptr(), gfeat.data_ptr(), cls.data_ptr(), d_max.data_ptr(), 16, 16, 32, W1.data_ptr(),
+                                      b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), viewmat.data_ptr(), v_opac.data_ptr(), v_scale.data_ptr(),
+                                      v_quat.data_ptr(), v_xyz.data_ptr(), v_o.data_ptr(), v_s.data_ptr(), v_r.data_ptr(), v_lf.data_ptr(),
+                                      v_gfA.data_ptr(), v_mlpA.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd")
+    for k, gr, l, M in (("xyz", v_xyz, lrA, 3), ("opacity", v_o, lr["opacity"], 1), ("scaling", v_s, lr["scaling"], 3),
+                        ("rotation", v_r, lr["rotation"], 4), ("local_feat", v_lf, lr["local_feat"], 16)):
+        adamUpdate(A[k], gr, Am[k], As[k], vis, l, be1, be2, eps, N, M)
+    lrA[vis] *= decay                                          # optimizers.py:160-161
+    lrA.clamp_min_(lr_min)
+    # fused path
+    B, Bm, Bs = ({k: v.clone() for k, v in D.items()} for D in (P0, M0, S0))
+    lrB = lr_xyz0.clone()
+    v_gfB, v_mlpB = torch.zeros_like(gfeat), torch.empty(1287, device=dev)
+    _lib.check(lib.adk_lod_params_bwd_adam(
+        N, B["xyz"].data_ptr(), B["opacity"].data_ptr(), B["scaling"].data_ptr(), B["rotation"].data_ptr(), B["local_feat"].data_ptr(),
+        gfeat.data_ptr(), cls.data_ptr(), d_max.data_ptr(), 16, 16, 32, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), viewmat.data_ptr(),
+        v_opac.data_ptr(), v_scale.data_ptr(), v_quat.data_ptr(), v_means.data_ptr(), v_gfB.data_ptr(), v_mlpB.data_ptr(), ws.data_ptr(), ws.numel(),
+        vis.data_ptr(), Bm["xyz"].data_ptr(), Bs["xyz"].data_ptr(), lrB.data_ptr(), decay, lr_min,
+        Bm["opacity"].data_ptr(), Bs["opacity"].data_ptr(), lr["opacity"].data_ptr(), Bm["scaling"].data_ptr(), Bs["scaling"].data_ptr(), lr["scaling"].data_ptr(),
+        Bm["rotation"].data_ptr(), Bs["rotation"].data_ptr(), lr["rotation"].data_ptr(), Bm["local_feat"].data_ptr(), Bs["local_feat"].data_ptr(),
+        lr["local_feat"].data_ptr(), be1, be2, eps, st), "bwd_adam")
+    torch.cuda.synchronize()
+    for k in keys:
+        for name, X, Y in (("param", A, B), ("exp_avg", Am, Bm), ("exp_avg_sq", As, Bs)):
+            assert torch.equal(X[k], Y[k]), (k, name, float((X[k] - Y[k]).abs().max()), int((X[k] != Y[k]).sum()))
+        assert torch.equal(B[k][~vis], P0[k][~vis]) and torch.equal(Bm[k][~vis], M0[k][~vis])      # invisible rows untouched
+        assert not torch.equal(B[k][vis], P0[k][vis])                                               # visible rows stepped
+    zv = zero_rows & vis
+    assert int(zv.sum()) > 0 and not torch.equal(Bm["opacity"][zv], M0["opacity"][zv])           # zero gradient: the moments still decay
+    assert torch.equal(lrA, lrB) and torch.equal(lrB[~vis], lr_xyz0[~vis]) and not torch.equal(lrB[vis], lr_xyz0[vis])
+    assert torch.equal(v_mlpA, v_mlpB)
+    assert torch.allclose(v_gfA, v_gfB, rtol=1e-4, atol=1e-5)                                       # atomics: order varies
+    assert torch.equal(v_means[zero_rows], torch.zeros_like(v_means[zero_rows]))
+
+
+@pytest.mark.gpu
+def test_fused_step_applies_gaussian_adam_in_lod_backward(dev, monkeypatch):
+    """In the fused training step xyz / opacity / scaling / rotation / local_feat never materialise a .grad (their Adam runs inside
+    adk_lod_params_bwd_adam), yet they, their moments and xyz's learning rates move like the two-kernel path (ARTDECO_AMD_LOD_ADAM=0)
+    moves them -- compared through the update direction: the raster backward's atomics make two steps differ in the last bits, and Adam
+    without bias correction (eps 1e-15) turns that into O(lr) differences on rows whose gradient is rounding noise."""
+    from artdeco_amd import fused
+    a, b = _scene(dev, N=7000, seed=12), _scene(dev, N=7000, seed=12)
+    assert fused.patch_scene_model(a) and fused.patch_scene_model(b)
+    keys = ("xyz", "opacity", "scaling", "rotation", "local_feat")
+    p0 = {k: a.gaussian_params[k]["val"].detach().clone() for k in keys}
+    lr0 = a.optimizer.params["xyz"]["lr"].clone()
+    torch.manual_seed(0)
+    a.optimization_step(0)
+    assert all(a.gaussian_params[k]["val"].grad is None for k in keys)
+    monkeypatch.setenv("ARTDECO_AMD_LOD_ADAM", "0")
+    torch.manual_seed(0)
+    b.optimization_step(0)
+    assert all(b.gaussian_params[k]["val"].grad is not None for k in keys)
+    for k in keys:
+        ua = (a.gaussian_params[k]["val"].detach() - p0[k]).flatten().double()
+        ub = (b.gaussian_params[k]["val"].detach() - p0[k]).flatten().double()
+        assert float(ua.norm()) > 0 and float((ua @ ub) / (ua.norm() * ub.norm())) > 0.99, k
+        ma, mb = a.optimizer.params[k]["exp_avg"].flatten().double(), b.optimizer.params[k]["exp_avg"].flatten().double()
+        assert float((ma - mb).norm() / mb.norm()) < 1e-4, k
+    assert torch.equal(a.optimizer.params["xyz"]["lr"], b.optimizer.params["xyz"]["lr"]) and not torch.equal(a.optimizer.params["xyz"]["lr"], lr0)
 
 
 def test_patch_refuses_unsupported_shapes():
