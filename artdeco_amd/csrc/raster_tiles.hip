@@ -644,13 +644,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
 //     tiles      768 (1 M, 512x384)   1 271 (648x486)    1 900             3 072             5 700             8 160 (1080p)      19 764 (4 M)
 //     forward    .127 / .079 / .054   .160 / .103 / .087  .135 / .092 / .085  .155 / .113 / .113  .228 / .197 / .212  .259 / .246 / .288  .516 / .487 / .606
 //     backward   .189 / .120 / .104   .236 / .176 / .171  .223 / .168 / .181  .259 / .229 / .240  .439 / .409 / .455  .543 / .558 / .630  1.06 / 1.09 / 1.33
+// Round 4, with the backward's first-touch / paired-reduction / lean body (profiles/r04_ab_split.json; a reduction per PART is cheaper now, so
+// the halves win further up):
+//     backward   .199 / .126 / .104   .243 / .166 / .156  .221 / .164 / .173  .253 / .206 / .225  .434 / .375 / .421  .515 / .502 / .582  .996 / .996 / 1.23
 // Measured with the split forms and dropped: requesting the NEXT group's list entries + records before the current group is walked (13
 // more VGPRs): forward +-1 %, backward 0.160 -> 0.168 ms in the quadrant form at 200 k / 648x486 -- the waves do not wait on those loads.
 // ADK_RASTER_SPLIT_FWD / _BWD = 0 (tile) | 2 (halves) | 1 (quadrants) force a form (read per launch: the labs and tests flip it in-process).
 static int split_parts(int n_tiles, bool bwd) {
     const char* e = getenv(bwd ? "ADK_RASTER_SPLIT_BWD" : "ADK_RASTER_SPLIT_FWD");
     if (e && (e[0] == '0' || e[0] == '1' || e[0] == '2')) return e[0] == '0' ? 1 : (e[0] == '1' ? 4 : 2);
-    if (bwd) return n_tiles < 1600 ? 4 : (n_tiles < 7000 ? 2 : 1);
+    if (bwd) return n_tiles < 1600 ? 4 : (n_tiles < 20000 ? 2 : 1);   // round 4 (paired reduction): the halves win or tie up to 19 764 tiles, see the table above
     return n_tiles < 3072 ? 4 : 2;
 }
 

@@ -56,7 +56,12 @@ def _lod_adam_state(opt, visibility):
     """State for lod_adam from a SparseGaussianAdam (Reconstruct/scene/optimizers.py:59-75) and the step's visibility mask, or None
     when the layout is not run.sh's: xyz with a per-element learning rate [N,3] in lr_dict (decay + floor), the other four with 0-dim
     device learning rates and no schedule, everything contiguous float32 on one device, ARTDECO_AMD_LOD_ADAM != 0."""
-    if os.environ.get("ARTDECO_AMD_LOD_ADAM", "1") == "0":
+    # OFF by default: measured on MI355X (profiles/r04_ab_lod_adam.txt, 1 M Gaussians): lod_params_bwd 0.160 -> 0.375 ms with the Adam inside
+    # against 0.155 -> 0.018 ms for adk_adam_update_multi, i.e. the step gets 0.08 ms SLOWER.  The LoD backward is a chain of matrix-core
+    # stages at two waves per SIMD; the 570 MB of p / m / v traffic it takes on find no memory-level parallelism there, and all the fusion
+    # can ever save is the gradients' round trip (216 B per Gaussian), not the moments' (DESIGN finding 31).  Kept selectable and tested
+    # bit-identical (ARTDECO_AMD_LOD_ADAM=1).
+    if os.environ.get("ARTDECO_AMD_LOD_ADAM", "0") != "1":
         return None
     try:
         P = opt.params

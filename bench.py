@@ -288,7 +288,7 @@ def main():
             "raster_fwd_ms": stages.get("raster_fwd", {}).get("mean_ms"), "raster_bwd_ms": bwd_ms,
             "frame_stage_ms": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in frame_stages.items()},
             "stage_ms": {k: round(v["mean_ms"], 4) for k, v in stages.items()},
-            "roofline": {"bound": "hbm", "kernel": "raster_bwd_kernel<2, 2, false> (one wave per 16x16 tile: the form a 1080p frame uses)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": bwd_kernel_name(args.width, args.height), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("raster_bwd_hbm_bytes"),
                          "algorithmic_bytes": alg_bytes_bwd, "avg_launch_ms": bwd_ms,
                          "peak_measured_stream_copy": hbm_measured, "frac_of_measured_peak": achieved / hbm_measured,
@@ -305,7 +305,7 @@ def main():
             valu = prof["raster_bwd_valu_wave_insts"]
             peak_valu = 1024 * 2.4e9 / 2.0 / 1e9
             ach = valu / (bwd_ms * 1e-3) / 1e9
-            out["roofline_valu"] = {"bound": "valu", "kernel": "raster_bwd_kernel<2, 2, false> (one wave per 16x16 tile: the form a 1080p frame uses)", "achieved": ach, "peak": peak_valu,
+            out["roofline_valu"] = {"bound": "valu", "kernel": bwd_kernel_name(args.width, args.height), "achieved": ach, "peak": peak_valu,
                                     "unit": "G wave-instr/s", "frac": ach / peak_valu, "wave_insts_per_launch": valu}
             if prof.get("raster_bwd_active_inst_valu_quadcycles"):
                 busy = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / (1024 * bwd_ms * 1e-3 * 2.4e9)
@@ -327,6 +327,16 @@ def main():
             print(json.dumps(stages, indent=1), file=sys.stderr)
         print(json.dumps(out))
     multigpu.shutdown()
+
+
+def bwd_kernel_name(W, H):
+    """The form of raster_bwd_kernel a frame of this size is served by (raster_tiles.hip:split_parts, same thresholds)."""
+    t = ((W + 15) // 16) * ((H + 15) // 16)
+    if t < 1600:
+        return "raster_bwd_kernel<1, 1, true> (one wave per 8x8 quadrant of a 16x16 list tile)"
+    if t < 20000:
+        return "raster_bwd_kernel<2, 1, true> (one wave per 16x8 half of a 16x16 list tile: the form a 1080p frame uses since round 4)"
+    return "raster_bwd_kernel<2, 2, false> (one wave per 16x16 tile)"
 
 
 def roofline_stages(stages, N, V, I, P, W, H):
@@ -526,7 +536,7 @@ def psnr_proxy(dev):
     both at three checkpoints, the largest |delta| and the proxy's own noise floor (CPU vs CPU from positions scaled by 1 + 1e-7)."""
     try:
         from harness import psnr_proxy as PP
-        out = PP.run(dev, steps=45, every=15, noise_floor=True)
+        out = PP.run(dev, steps=30, every=10, noise_floor=True, cpu_threads=8)
         out["reference"] = "PSNR = 10 log10(1 / mse) (Reconstruct/utils.py:86-87) on held-out views rendered like SceneModel.evaluate (h3dgsv3.py:523-558)"
         out["criterion"] = "max_abs_delta_db <= 0.1 (north star: PSNR within 0.1 dB)"
         return out

@@ -97,13 +97,16 @@ def build(mapper, device, truth, position_scale=1.0):
     return sc
 
 
-def run(dev, steps=120, every=20, noise_floor=False):
+def run(dev, steps=120, every=20, noise_floor=False, cpu_threads=None):
     """Train the proxy problem `steps` optimisation steps on the HIP path and on the CPU-oracle path; held-out PSNR of both every
     `every` steps.  Returns dict(start_db, checkpoints=[{step, cpu_oracle_db, hip_db, delta_db}], max_abs_delta_db,
     noise_floor_db (CPU vs CPU from positions scaled by 1 + 1e-7; None unless noise_floor), seconds)."""
     from artdeco_amd import fused
     from harness import mapper as gmap
     t_start = time.perf_counter()
+    threads0 = torch.get_num_threads()
+    if cpu_threads:     # the CPU-oracle side is ~0.3 s per step single-threaded; a handful of threads is where its small tensors stop gaining
+        torch.set_num_threads(int(cpu_threads))
     cmap = cpu_mapper()
     rng_state = torch.get_rng_state()
     torch.manual_seed(0)
@@ -166,6 +169,7 @@ def run(dev, steps=120, every=20, noise_floor=False):
     finally:
         torch.rand = real_rand
         torch.set_rng_state(rng_state)
+        torch.set_num_threads(threads0)
     cps = [{"step": s, "cpu_oracle_db": round(v["cpu"], 4), "hip_db": round(v["hip"], 4), "delta_db": round(v["hip"] - v["cpu"], 4)} for s, v in curve]
     out = {"start_db": round(start["cpu"], 4), "start_delta_db": round(start["hip"] - start["cpu"], 5), "checkpoints": cps,
            "max_abs_delta_db": max(abs(cp["delta_db"]) for cp in cps) if cps else None,

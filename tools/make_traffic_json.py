@@ -18,10 +18,10 @@ import bench  # noqa: E402
 
 f, w, s = (agg(p + "/b_counter_collection.csv") for p in sys.argv[1:4])
 tag, n, wd, ht = sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
-# the whole-tile form is the one the 1080p bench steps launch (the quadrant / half forms only appear in the warm-up scene)
-k = next(k for k in s if "raster_bwd_kernel<2, 2" in k)
+# the form the bench frame launches = the raster_bwd instantiation with the most wave cycles (the warm-up scene's 96x64 frames use the quadrant form)
+k = max((k for k in s if "raster_bwd_kernel<" in k), key=lambda k: s[k].get("SQ_WAVE_CYCLES", 0.0))
 fetch_kb, write_kb = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
-out = {"tag": tag, "gaussians": n, "width": wd, "height": ht, "kernel_source_sha": bench.kernel_source_sha(),
+out = {"tag": tag, "kernel": k, "gaussians": n, "width": wd, "height": ht, "kernel_source_sha": bench.kernel_source_sha(),
        "raster_bwd_hbm_bytes": (2.0 * fetch_kb + write_kb) * 1024.0,
        "raster_bwd_fetch_size_kb": fetch_kb, "raster_bwd_write_size_kb": write_kb,
        "raster_bwd_valu_wave_insts": s[k].get("SQ_INSTS_VALU"),
