@@ -20,6 +20,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o b --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o b -- $BENCH > /tmp/pw.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d /tmp/ps -o b -- $BENCH > /tmp/ps.log 2>&1
 python "$ROOT/tools/pmc_agg.py" /tmp/pf /tmp/pw /tmp/ps > "$OUT/${TAG}_pmc.txt" 2> "$OUT/${TAG}_pmc.err"
+# round 4: per-kernel table of the BENCH scene only (the warm-up scene's launches dropped by grid size), time and counter bytes side by side,
+# and the per-stage roofline "by formula" next to "by counters"
+python "$ROOT/tools/kernel_table.py" /tmp/pk/b_kernel_trace.csv /tmp/pf /tmp/pw --json="$OUT/${TAG}_step_kernel_table.json" > "$OUT/${TAG}_step_kernel_table.txt" 2>> "$OUT/${TAG}_pmc.err"
+python "$ROOT/tools/stage_roofline_table.py" "$OUT/${TAG}_bench_full.json" "$OUT/${TAG}_step_kernel_table.json" > "$OUT/${TAG}_stage_roofline.txt" 2>> "$OUT/${TAG}_pmc.err"
 # per-launch counters of the roofline kernel, stamped with the hash of its sources (bench.py reads profiles/traffic.json)
 python "$ROOT/tools/make_traffic_json.py" /tmp/pf /tmp/pw /tmp/ps "$TAG" 1000000 1920 1080 > "$OUT/${TAG}_traffic.json" 2>> "$OUT/${TAG}_pmc.err"
 tail -2 /tmp/ps.log > "$OUT/${TAG}_pmc_sq.log"
