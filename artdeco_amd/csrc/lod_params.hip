@@ -231,8 +231,14 @@ __device__ __forceinline__ void lod_adam_rows(const LodAdam& A, int64_t g, float
 
 // ADAM: the five per-Gaussian parameter tensors are updated in place (see LodAdam) and their gradients are not written; every read of
 // a parameter precedes the write of the same element in the same thread, so the pointers simply lose their __restrict__.
-template <bool ADAM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lod_params_bwd_kernel(
+#ifndef ADK_LOD_BWD_MINWAVES
+#define ADK_LOD_BWD_MINWAVES 3   // two-wave form: 3 waves per SIMD = 168 VGPRs, no scratch; 4 (128 VGPRs) spills 143 dwords
+#endif
+// WAVES (round 4): 1 = one wave walks both 32-row blocks of a 64-Gaussian chunk (the round-2 form: 2 waves per SIMD); 2 = two waves per
+// workgroup share the chunk's LDS tiles, each takes ONE 32-row block of every matrix stage and half of the K = 64 contraction of the
+// weight gradients: the same 19.5 KB of LDS then carries 4 waves per SIMD and every wave's serial chain of stages is half as long.
+template <bool ADAM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 2 ? ADK_LOD_BWD_MINWAVES : 2, 2 * WAVES))) void lod_params_bwd_kernel(
     int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
     const float* rotation, const float* local_feat, const float* __restrict__ global_feat,
     const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
@@ -244,17 +250,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float* __restrict__ v_global_feat /* [V,G], zeroed, atomics */, float* __restrict__ partials /* [gridDim.x][LOD_NW] */,
     const LodAdam A)
 {
-    // Two 64x33 tiles + a 64x9 one = 19.5 KB per wavefront => 8 single-wave workgroups per CU (2 per SIMD, which is
-    // also what the 256-VGPR budget allows).  TH holds H, later VZ: H is dead once dW2 has been accumulated, and
+    // Two 64x33 tiles + a 64x9 one = 19.5 KB per workgroup => 8 workgroups per CU: 2 waves per SIMD with one wave per workgroup (which is
+    // also what its 256-VGPR budget allows), 4 with two (128 VGPRs each).  TH holds H, later VZ: H is dead once dW2 has been accumulated, and
     // the stage order below is chosen so that this alias is legal.
     __shared__ float TX[64 * LOD_LDW], TH[64 * LOD_LDW], TY[64 * LOD_YW];
     __shared__ int TC[64];
     __shared__ unsigned char TV[64];   // ADAM: the chunk's visibility flags, for the accumulator-layout local_feat update
+    __shared__ int TAny;               // WAVES == 2: does the chunk have an active Gaussian? (decided by wave 0, read by both)
     float* const TZ = TH;
+    const int wave = WAVES == 2 ? (int)(threadIdx.x >> 6) : 0;
+    auto tile_sync = [&]() { if (WAVES == 2) __syncthreads(); else lds_fence(); };   // the tiles are wave-private with one wave
     const float omb1 = 1.0f - A.b1, omb2 = 1.0f - A.b2;
     float lr_o = 0.f, lr_s = 0.f, lr_r = 0.f, lr_l = 0.f;
     if (ADAM) { lr_o = A.lr_opacity[0]; lr_s = A.lr_scaling[0]; lr_r = A.lr_rotation[0]; lr_l = A.lr_local[0]; }
-    const int lane = threadIdx.x, kk = lane >> 5, rc = lane & 31;
+    const int lane = threadIdx.x & 63, kk = lane >> 5, rc = lane & 31;
 
     // weight fragments (B operands), resident for the whole kernel
     float w1t[16], w1n[16], w2t[16], w2n[4];
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int n_chunks = (N + 63) / 64;
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t g = (int64_t)chunk * 64 + lane;
-        // ---- stage 0 (lane = Gaussian): incoming gradients, LoD geometry, feature gather
+        // ---- stage 0 (lane = Gaussian; wave 0): incoming gradients, LoD geometry, feature gather
         bool active = false;
         float vo = 0.f, vs[3] = {0.f, 0.f, 0.f};
         float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -288,94 +297,122 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         L.alpha_ratio = 1.f; L.inv_dmax = 0.f; L.fading = false; L.selected = false; L.dist = 0.f;
         L.dir[0] = L.dir[1] = L.dir[2] = 0.f;
         bool visible = false;
-        if (ADAM) { visible = g < N && A.visible[g] != 0; TV[lane] = visible ? 1 : 0; }
-        if (g < N) {
-            vo = v_opac_eff[g];
-            vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
-            vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
-            L = lod_geometry(xyz, d_max, g, cc);
-            active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
-        }
-        if (__ballot(active) == 0ull) { // nothing visible in this chunk: zero gradients, no matrix work
-            if (ADAM) {
-                // visible rows still take their Adam step (zero gradient: the moments decay, the parameter moves by -lr m / (sqrt(v) + eps))
-                if (visible) {
-                    lod_adam_rows<true>(A, g, lr_o, lr_s, lr_r, lr_l, omb1, omb2, const_cast<float*>(xyz), const_cast<float*>(opacity_raw),
-                                        const_cast<float*>(scaling_raw), const_cast<float*>(rotation), const_cast<float*>(local_feat), 0.f,
-                                        0.f, 0.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), v_xyz_add[3 * g], v_xyz_add[3 * g + 1], v_xyz_add[3 * g + 2]);
-                }
-                continue;
-            }
+        bool any_active = false;
+        if (wave == 0) {
+            if (ADAM) { visible = g < N && A.visible[g] != 0; TV[lane] = visible ? 1 : 0; }
             if (g < N) {
-                v_opacity_raw[g] = 0.f;
-                v_scaling_raw[3 * g] = 0.f; v_scaling_raw[3 * g + 1] = 0.f; v_scaling_raw[3 * g + 2] = 0.f;
-                reinterpret_cast<float4*>(v_rotation)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4* vl = reinterpret_cast<float4*>(v_local_feat + g * LOD_L);
-#pragma unroll
-                for (int i = 0; i < LOD_L / 4; ++i) vl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vo = v_opac_eff[g];
+                vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
+                vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
+                L = lod_geometry(xyz, d_max, g, cc);
+                active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
             }
+            if (WAVES == 2) asm volatile("" : "=v"(vo), "=v"(vs[0]), "=v"(vs[1]), "=v"(vs[2]), "=v"(vq.x), "=v"(vq.y), "=v"(vq.z), "=v"(vq.w));   // dead until re-read below
+            any_active = __ballot(active) != 0ull;
+            if (WAVES == 2 && lane == 0) TAny = any_active ? 1 : 0;
+            if (any_active) {
+                // features straight into the X tile, one float4 at a time (holding all 32 in registers next to the weight fragments spills at 128 VGPRs)
+                int c32 = -1;
+                if (active) {
+                    const int64_t cls = cls_id[g];
+                    c32 = (int)cls;
+                    const float4* gf = reinterpret_cast<const float4*>(global_feat + cls * LOD_G);
+                    const float4* lf = reinterpret_cast<const float4*>(local_feat + g * LOD_L);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float4 v = i < 4 ? gf[i] : lf[i - 4];
+                        float* t = TX + lane * LOD_LDW + 4 * i;
+                        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < LOD_IN; ++i) TX[lane * LOD_LDW + i] = 0.f;
+                }
+                TC[lane] = c32;
+            }
+        }
+        if (WAVES == 2) { __syncthreads(); any_active = TAny != 0; }
+        if (!any_active) { // nothing visible in this chunk: zero gradients, no matrix work
+            if (wave == 0) {
+                if (ADAM) {
+                    // visible rows still take their Adam step (zero gradient: the moments decay, the parameter moves by -lr m / (sqrt(v) + eps))
+                    if (visible) {
+                        lod_adam_rows<true>(A, g, lr_o, lr_s, lr_r, lr_l, omb1, omb2, const_cast<float*>(xyz), const_cast<float*>(opacity_raw),
+                                            const_cast<float*>(scaling_raw), const_cast<float*>(rotation), const_cast<float*>(local_feat), 0.f,
+                                            0.f, 0.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), v_xyz_add[3 * g], v_xyz_add[3 * g + 1], v_xyz_add[3 * g + 2]);
+                    }
+                } else if (g < N) {
+                    v_opacity_raw[g] = 0.f;
+                    v_scaling_raw[3 * g] = 0.f; v_scaling_raw[3 * g + 1] = 0.f; v_scaling_raw[3 * g + 2] = 0.f;
+                    reinterpret_cast<float4*>(v_rotation)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4* vl = reinterpret_cast<float4*>(v_local_feat + g * LOD_L);
+#pragma unroll
+                    for (int i = 0; i < LOD_L / 4; ++i) vl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (WAVES == 2) __syncthreads();   // TAny / TV are rewritten by the next chunk
             continue;
         }
-        {
-            float x[LOD_IN];
-#pragma unroll
-            for (int i = 0; i < LOD_IN; ++i) x[i] = 0.f;
-            int c32 = -1;
-            if (active) {
-                const int64_t cls = cls_id[g];
-                c32 = (int)cls;
-                load_features(global_feat, local_feat, cls, g, x);
-            }
-            TC[lane] = c32;
-#pragma unroll
-            for (int i = 0; i < LOD_IN; ++i) TX[lane * LOD_LDW + i] = x[i];
-        }
-        lds_fence();
+        tile_sync();
 
         // ---- H = relu(X W1^T + b1): two 32-row blocks; keep only the sign mask in registers
         unsigned hmask[2] = {0u, 0u};
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rbi = 0; rbi < 2 / WAVES; ++rbi) {
+            const int rb = WAVES == 2 ? wave : rbi;
+            // the wave's row block enters through BASE pointers and every per-row offset below is a compile-time constant: with rb = wave a
+            // run-time value, offsets written as (rb * 32 + row) * pitch became 16 loop-invariant 64-bit registers per use (spilled)
+            const float* xa = TX + (rb * 32 + rc) * LOD_LDW + kk;
+            float* hw = TH + (rb * 32 + 4 * kk) * LOD_LDW + rc;
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TX[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w1t[s], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * s], w1t[s], d, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const float h = fmaxf(d[r] + bias1, 0.f);
-                TH[row * LOD_LDW + rc] = h;
-                hmask[rb] |= (h > 0.f ? 1u : 0u) << r;
+                hw[((r & 3) + 8 * (r >> 2)) * LOD_LDW] = h;
+                hmask[rbi] |= (h > 0.f ? 1u : 0u) << r;
             }
         }
-        lds_fence();
+        tile_sync();
         // ---- Y = H W2^T + b2 (columns 0..6 of the 32-wide tile)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rbi = 0; rbi < 2 / WAVES; ++rbi) {
+            const int rb = WAVES == 2 ? wave : rbi;
+            const float* ha = TH + (rb * 32 + rc) * LOD_LDW + kk;
+            float* yw = TY + (rb * 32 + 4 * kk) * LOD_YW + rc;
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TH[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w2t[s], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[2 * s], w2t[s], d, 0, 0, 0);
             if (rc < 8) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    TY[row * LOD_YW + rc] = d[r] + bias2;
+                    yw[((r & 3) + 8 * (r >> 2)) * LOD_YW] = d[r] + bias2;
                 }
             }
         }
-        lds_fence();
-        // ---- elementwise stage (lane = Gaussian): activation gradients, vy
-        {
+        tile_sync();
+        // ---- elementwise stage (lane = Gaussian; wave 0): activation gradients, vy
+        if (wave == 0) {
             float y[LOD_OUT], vy[LOD_OUT];
 #pragma unroll
             for (int o = 0; o < LOD_OUT; ++o) { y[o] = TY[lane * LOD_YW + o]; vy[o] = 0.f; }
             float go = 0.f, gs[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f};
             float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WAVES == 2 && active) {
+                // the incoming gradients and the LoD geometry are read AGAIN here instead of being carried through the two matrix stages
+                // (18 registers that pushed the 168-VGPR budget of the two-wave form into scratch); they are L2-resident
+                vo = v_opac_eff[g];
+                vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
+                vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
+                L = lod_geometry(xyz, d_max, g, cc);
+            }
             if (active) {
                 // opacity = sigmoid(o) * alpha_ratio
                 const float so = sigmoidf(opacity_raw[g]);
@@ -411,39 +448,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int o = 0; o < LOD_OUT; ++o) TY[lane * LOD_YW + o] = vy[o];
             TY[lane * LOD_YW + 7] = 0.f;
         }
-        lds_fence();
+        tile_sync();
         // ---- dW2 += VY^T H (K = the 64 Gaussians of the chunk); last use of H
+        const float* ky = TY + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_YW + rc;
+        const float* kh = TH + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_LDW + rc;   // TH = H here, VZ below
 #pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const float a = rc < 8 ? TY[(2 * s + kk) * LOD_YW + rc] : 0.f;
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TH[(2 * s + kk) * LOD_LDW + rc], acc2, 0, 0, 0);
+        for (int si = 0; si < 32 / WAVES; ++si) {
+            const float a = rc < 8 ? ky[2 * si * LOD_YW] : 0.f;   // each wave contracts over its own 32 Gaussians
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kh[2 * si * LOD_LDW], acc2, 0, 0, 0);
             bs2 += a;
         }
         // ---- VZ = (VY W2) * (H > 0), written over H
         f32x16 dz[2];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rbi = 0; rbi < 2 / WAVES; ++rbi) {
+            const int rb = WAVES == 2 ? wave : rbi;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dz[rb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) dz[rbi][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                dz[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(TY[(rb * 32 + rc) * LOD_YW + 2 * s + kk], w2n[s], dz[rb], 0, 0, 0);
+                dz[rbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(TY[(rb * 32 + rc) * LOD_YW + kk + 2 * s], w2n[s], dz[rbi], 0, 0, 0);
         }
-        lds_fence(); // every read of H (dW2) has completed
+        tile_sync(); // every read of H (dW2) has completed
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rbi = 0; rbi < 2 / WAVES; ++rbi) {
+            const int rb = WAVES == 2 ? wave : rbi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                TZ[row * LOD_LDW + rc] = ((hmask[rb] >> r) & 1u) ? dz[rb][r] : 0.f;
+                TZ[(rb * 32 + 4 * kk) * LOD_LDW + rc + ((r & 3) + 8 * (r >> 2)) * LOD_LDW] = ((hmask[rbi] >> r) & 1u) ? dz[rbi][r] : 0.f;
             }
         }
-        lds_fence();
+        tile_sync();
         // ---- dW1 += VZ^T X; last use of X
+        const float* kx = TX + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_LDW + rc;
 #pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const float a = TZ[(2 * s + kk) * LOD_LDW + rc];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, TX[(2 * s + kk) * LOD_LDW + rc], acc1, 0, 0, 0);
+        for (int si = 0; si < 32 / WAVES; ++si) {
+            const float a = kh[2 * si * LOD_LDW];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kx[2 * si * LOD_LDW], acc1, 0, 0, 0);
             bs1 += a;
         }
         // ---- VX = VZ W1, stored straight from the accumulator layout (lane = feature column, register = Gaussian
@@ -452,24 +493,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         //      per instruction) is 3x slower.  Columns 16..31 = local-feature gradients (plain stores, every row),
         //      columns 0..15 scatter into the voxel's global feature (hardware fp32 atomics).
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rbi = 0; rbi < 2 / WAVES; ++rbi) {
+            const int rb = WAVES == 2 ? wave : rbi;
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[(rb * 32 + rc) * LOD_LDW + 2 * s + kk], w1n[s], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[(rb * 32 + rc) * LOD_LDW + kk + 2 * s], w1n[s], d, 0, 0, 0);
             if (ADAM && rc >= LOD_G) {
                 // the gradient d[r] of local_feat[row][rc - 16] meets its parameter and moments here: same 64 B-line-per-quarter-wave
                 // pattern as the gradient store it replaces
-                const int64_t off0 = ((int64_t)chunk * 64 + 4 * kk) * LOD_L + (rc - LOD_G);
+                const int64_t off0 = ((int64_t)chunk * 64 + rb * 32 + 4 * kk) * LOD_L + (rc - LOD_G);
                 float* pb = const_cast<float*>(local_feat) + off0;
                 float* mb = A.m_local + off0;
                 float* vb = A.v_local + off0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row0 = rb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (TV[row0 + 4 * kk]) {   // visible implies row < N
+                    const int row0 = (r & 3) + 8 * (r >> 2);
+                    if (TV[rb * 32 + 4 * kk + row0]) {   // visible implies row < N
                         float p = pb[row0 * LOD_L], m = mb[row0 * LOD_L], v = vb[row0 * LOD_L];
                         lod_adam_elem(p, d[r], m, v, lr_l, A.b1, A.b2, omb1, omb2, A.eps);
                         pb[row0 * LOD_L] = p; mb[row0 * LOD_L] = m; vb[row0 * LOD_L] = v;
@@ -477,30 +519,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             } else if (rc >= LOD_G) {
                 // one base address per lane, compile-time row offsets (immediate-offset stores)
-                float* lbase = v_local_feat + ((int64_t)chunk * 64 + 4 * kk) * LOD_L + (rc - LOD_G);
+                float* lbase = v_local_feat + ((int64_t)chunk * 64 + rb * 32 + 4 * kk) * LOD_L + (rc - LOD_G);
                 if ((int64_t)chunk * 64 + 64 <= N) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) lbase[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LOD_L] = d[r];
+                    for (int r = 0; r < 16; ++r) lbase[((r & 3) + 8 * (r >> 2)) * LOD_L] = d[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row0 = rb * 32 + (r & 3) + 8 * (r >> 2);
-                        if ((int64_t)chunk * 64 + row0 + 4 * kk < N) lbase[row0 * LOD_L] = d[r];
+                        const int row0 = (r & 3) + 8 * (r >> 2);
+                        if ((int64_t)chunk * 64 + rb * 32 + row0 + 4 * kk < N) lbase[row0 * LOD_L] = d[r];
                     }
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int c = TC[rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk];
+                    // four rows at a time: left alone the scheduler forms all 16 addresses (32 registers) and voxel ids up front, which does
+                    // not fit next to the resident weight fragments and accumulators in the two-wave form's 168 VGPRs
+                    if (WAVES == 2 && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                    const int c = TC[rb * 32 + 4 * kk + (r & 3) + 8 * (r >> 2)];
                     if (c >= 0 && d[r] != 0.f) unsafeAtomicAdd(v_global_feat + (int64_t)c * LOD_G + rc, d[r]);
                 }
             }
         }
-        lds_fence(); // tiles are rewritten by the next chunk
+        tile_sync(); // tiles are rewritten by the next chunk
     }
 
     // ---- one partial row per workgroup: dW1 | db1 | dW2 | db2
-    float* out = partials + (size_t)blockIdx.x * LOD_NW;
+    float* out = partials + ((size_t)blockIdx.x * WAVES + wave) * LOD_NW;   // one partial row per WAVE
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
@@ -605,7 +650,7 @@ extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_
 extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)
 {
     if (N < 0) return ADK_EINVAL;
-    return (int64_t)LOD_BWD_MAX_BLOCKS * LOD_NW * (int64_t)sizeof(float);
+    return (int64_t)LOD_BWD_MAX_BLOCKS * 2 * LOD_NW * (int64_t)sizeof(float);   // one partial row per wave, up to two waves per workgroup
 }
 
 // v_mlp: [1287] = dW1 (32x32 row-major) | db1 (32) | dW2 (7x32) | db2 (7).  v_xyz_add is accumulated
@@ -630,13 +675,17 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     int nb = (int)adk::ceil_div(N, 64);
     if (nb > LOD_BWD_MAX_BLOCKS) nb = LOD_BWD_MAX_BLOCKS;
     adk::LodAdam none{};
-    hipLaunchKernelGGL(adk::lod_params_bwd_kernel<false>, dim3(nb), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw,
-                       rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff,
-                       v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat,
-                       (float*)workspace, none);
+    // ADK_LOD_BWD_WAVES = 1 | 2 (read per launch: the lab flips it in-process): waves per 64-Gaussian chunk, see the kernel
+    const char* we = getenv("ADK_LOD_BWD_WAVES");
+    const int waves = (we && we[0] == '1') ? 1 : 2;
+#define ADK_LOD_ARGS N, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff, \
+                     v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat, (float*)workspace, none
+    if (waves == 2) hipLaunchKernelGGL((adk::lod_params_bwd_kernel<false, 2>), dim3(nb), dim3(128), 0, stream, ADK_LOD_ARGS);
+    else hipLaunchKernelGGL((adk::lod_params_bwd_kernel<false, 1>), dim3(nb), dim3(64), 0, stream, ADK_LOD_ARGS);
+#undef ADK_LOD_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, v_mlp);
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb * waves, v_mlp);
     ADK_RETURN_LAST_ERROR();
 }
 
@@ -679,13 +728,16 @@ extern "C" int adk_lod_params_bwd_adam(int N, float* xyz, float* opacity_raw, fl
     A.m_rotation = m_rotation; A.v_rotation = v2_rotation; A.lr_rotation = lr_rotation;
     A.m_local = m_local; A.v_local = v2_local; A.lr_local = lr_local;
     A.b1 = beta1; A.b2 = beta2; A.eps = eps;
-    hipLaunchKernelGGL(adk::lod_params_bwd_kernel<true>, dim3(nb), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw,
-                       rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff,
-                       v_quat_eff, const_cast<float*>(v_xyz), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_global_feat,
-                       (float*)workspace, A);
+    const char* we = getenv("ADK_LOD_BWD_WAVES");
+    const int waves = (we && we[0] == '1') ? 1 : 2;
+#define ADK_LOD_ARGS N, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff, \
+                     v_quat_eff, const_cast<float*>(v_xyz), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_global_feat, (float*)workspace, A
+    if (waves == 2) hipLaunchKernelGGL((adk::lod_params_bwd_kernel<true, 2>), dim3(nb), dim3(128), 0, stream, ADK_LOD_ARGS);
+    else hipLaunchKernelGGL((adk::lod_params_bwd_kernel<true, 1>), dim3(nb), dim3(64), 0, stream, ADK_LOD_ARGS);
+#undef ADK_LOD_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb, v_mlp);
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb * waves, v_mlp);
     ADK_RETURN_LAST_ERROR();
 }
 

@@ -323,6 +323,8 @@ def main():
         if not args.no_frontend and world == 1:
             out["frontend"] = frontend_summary(args, dev, cpu=not args.no_cpu_baseline)
             out["system"] = system_summary()
+            sf = system_summary("fp32", frames=60)
+            out["system_strict_fp32_frontend"] = {k: sf.get(k) for k in ("value", "unit", "pipeline_frames_per_s", "alone_frames_per_s", "error") if k in sf}
         if args.stage_detail:
             print(json.dumps(stages, indent=1), file=sys.stderr)
         print(json.dumps(out))
@@ -426,13 +428,14 @@ def frontend_summary(args, dev, cpu=True):
         return {"error": repr(e)[:300]}
 
 
-def system_summary():
+def system_summary(precision="tf32eq", frames=120):
     """Frontend -> backend -> mapper as a pipeline of three processes on this one GPU (bench_system.py, 120 frames): frames / wall until the
-    mapper has finished the last one."""
+    mapper has finished the last one.  precision "fp32": the same pipeline with strict-fp32 MASt3R networks (a shorter run: it puts the
+    precision dependence of the >= 30 frames/s figure on the record)."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_system.py"), "--frames", "120", "--alone-seconds", "2"],
-                           capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_system.py"), "--frames", str(frames), "--alone-seconds", "2",
+                            "--frontend-precision", precision], capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         return json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
     except Exception as e:

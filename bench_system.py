@@ -78,11 +78,13 @@ def mapper_proc(args, barrier, flow, out_q):
         barrier.wait()
 
 
-def _frontend_graph(dev):
+def _frontend_graph(dev, precision="tf32eq"):
     import bench_frontend as BF
     from artdeco_amd.mast3r_model import vit_large
     torch.manual_seed(0)
-    net = vit_large().to(dev).eval().to_inference_dtype(torch.float16, fp32_stream=True, heads=True)
+    net = vit_large().to(dev).eval()
+    if precision != "fp32":   # fp32: every GEMM / convolution operand stays fp32 (no TF32 MFMA on gfx950: the strict reading of the reference's arithmetic)
+        net = net.to_inference_dtype(torch.float16, fp32_stream=True, heads=True)
     img_f = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
     img_k = torch.rand(1, 3, 384, 512, device=dev) * 2 - 1
     with torch.inference_mode():
@@ -108,7 +110,7 @@ def frontend_proc(args, barrier, flow, out_q):
     import bench_frontend as BF
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    net, graph, _ = _frontend_graph(dev)
+    net, graph, _ = _frontend_graph(dev, args.frontend_precision)
     track = BF.make_tracker_step(dev)
     for _ in range(3):
         graph.replay(); track()
@@ -139,7 +141,7 @@ def backend_proc(args, barrier, flow, out_q):
     from artdeco_amd import synthetic as S
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    net, graph, (img_f, kf_feat, kf_pos) = _frontend_graph(dev)
+    net, graph, (img_f, kf_feat, kf_pos) = _frontend_graph(dev, args.frontend_precision)
     g = S.keyframe_graph(num_poses=16, n=512 * 384, seed=0, extra_edges=12, coherent=True)
     T0 = S.perturb_poses(g["T_gt"], np.random.default_rng(1), 0.01)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -186,6 +188,9 @@ def main():
     ap.add_argument("--slam-every", type=int, default=15)
     ap.add_argument("--cu-mask", nargs=2, default=None, metavar=("FRONTEND", "BACKEND"),
                     help='HSA_CU_MASK for the frontend and backend processes, e.g. "0:0-63" "0:64-127"; "-" leaves one unmasked')
+    ap.add_argument("--frontend-precision", default="tf32eq", choices=["tf32eq", "fp32"],
+                    help="tf32eq: fp16 GEMM / conv operands, fp32 everything else (what the reference's allow_tf32 amounts to, the default); "
+                         "fp32: strict fp32 in the frontend and backend networks")
     args = ap.parse_args()
     ctx = mp.get_context("spawn")
     barrier, q = ctx.Barrier(4), ctx.Queue()
@@ -210,10 +215,10 @@ def main():
                      "(frames / wall until the mapper has finished the last frame)",
            "value": args.frames / max(finish.values()), "unit": "frames/s", "n_gpus": 1, "data": "synthetic, random-init MASt3R weights",
            "config": {"workload": f"{args.frames} tracked frames; mapper: run_system.py's frame loop on {args.gaussians} Gaussians {args.width}x{args.height} "
-                                  f"(20 / 10 iterations, add_new_gaussians on important frames); frontend: MASt3R ViT-L 512x384 tracked frame (TF32-class) + "
+                                  f"(20 / 10 iterations, add_new_gaussians on important frames); frontend: MASt3R ViT-L 512x384 tracked frame ({'TF32-class' if args.frontend_precision == 'tf32eq' else 'strict fp32'}) + "
                                   f"Sim(3) tracker; backend: the frame's second asymmetric match + on every {args.slam_every}th frame a symmetric re-match and "
                                   "gauss_newton_rays over a 16-keyframe graph; three processes, same device",
-                      "cu_mask": args.cu_mask},
+                      "cu_mask": args.cu_mask, "frontend_precision": args.frontend_precision},
            "pipeline_finish_s": finish, "pipeline_frames_per_s": tog, "alone_frames_per_s": alone,
            "gpu_ms_per_frame_alone_sum": sum(1e3 / v for v in alone.values())}
     print(json.dumps(out))

@@ -30,8 +30,9 @@ def main():
         ks = [k for k in table if any(p in k for p in pats)]
         if st not in rs or not ks:
             continue
-        us = sum(table[k]["mean_us"] * table[k]["calls"] for k in ks) / steps
-        mb = sum(table[k].get("hbm_mb", 0.0) * table[k]["calls"] for k in ks) / steps
+        n = max(table[k]["calls"] for k in ks)   # per launch of the stage: its most-launched kernel (test keyframes run no Adam, the first frames no sort)
+        us = sum(table[k]["mean_us"] * table[k]["calls"] for k in ks) / n
+        mb = sum(table[k].get("hbm_mb", 0.0) * table[k]["calls"] for k in ks) / n
         f = rs[st]
         frac_c = (mb / us) * 1000 / 8000.0 if us > 0 else 0.0
         print(f"{st:16s} {f['alg_bytes'] / 1e6:10.1f} {f['ms']:9.4f} {f['frac']:6.3f} | {mb:10.1f} {us / 1e3:10.4f} {frac_c:6.3f} | {mb / (f['alg_bytes'] / 1e6):5.2f}")
