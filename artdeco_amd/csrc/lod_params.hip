@@ -113,11 +113,14 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ W1, const 
 
 struct LodGeom { float dist, alpha_ratio, inv_dmax; bool selected, fading; float dir[3]; };
 
+__device__ __forceinline__ LodGeom lod_geometry_of(float px, float py, float pz, float dm, const CamCentre& cc);
 __device__ __forceinline__ LodGeom lod_geometry(const float* __restrict__ xyz, const float* __restrict__ d_max, int64_t g, const CamCentre& cc) {
+    return lod_geometry_of(xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], d_max[g], cc);
+}
+__device__ __forceinline__ LodGeom lod_geometry_of(float px, float py, float pz, float dm, const CamCentre& cc) {
     LodGeom L;
-    const float dx = xyz[3 * g] - cc.c[0], dy = xyz[3 * g + 1] - cc.c[1], dz = xyz[3 * g + 2] - cc.c[2];
+    const float dx = px - cc.c[0], dy = py - cc.c[1], dz = pz - cc.c[2];
     L.dist = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float dm = d_max[g];
     L.selected = L.dist < 2.f * dm;
     L.fading = (L.dist > dm) && (L.dist < 2.f * dm);
     L.inv_dmax = 1.0f / dm;
@@ -231,6 +234,9 @@ __device__ __forceinline__ void lod_adam_rows(const LodAdam& A, int64_t g, float
 
 // ADAM: the five per-Gaussian parameter tensors are updated in place (see LodAdam) and their gradients are not written; every read of
 // a parameter precedes the write of the same element in the same thread, so the pointers simply lose their __restrict__.
+#ifndef ADK_LOD_PREFETCH
+#define ADK_LOD_PREFETCH 1
+#endif
 #ifndef ADK_LOD_BWD_MINWAVES
 #define ADK_LOD_BWD_MINWAVES 3   // two-wave form: 3 waves per SIMD = 168 VGPRs, no scratch; 4 (128 VGPRs) spills 143 dwords
 #endif
@@ -287,6 +293,27 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     float bs1 = 0.f, bs2 = 0.f;
 
     const int n_chunks = (N + 63) / 64;
+    // Software pipeline (round 4, one-wave form): a chunk's incoming gradients, position, d_max and voxel id are requested while the
+    // PREVIOUS chunk runs its matrix stages.  Stage 0 is a chain of three dependent memory round trips (gradients -> is anything active? ->
+    // cls_id -> the gathered voxel feature) in front of 168 MFMAs, and only two waves share a SIMD: the first two trips now overlap.
+    struct ChunkIn { float vo, vs0, vs1, vs2, px, py, pz, dm; float4 vq; int64_t cls; };
+    auto request = [&](int ch) -> ChunkIn {
+        ChunkIn in;
+        in.vo = in.vs0 = in.vs1 = in.vs2 = in.px = in.py = in.pz = 0.f; in.dm = 1.f; in.vq = make_float4(0.f, 0.f, 0.f, 0.f); in.cls = 0;
+        const int64_t gg = (int64_t)ch * 64 + lane;
+        if (ch < n_chunks && gg < N) {
+            in.vo = v_opac_eff[gg];
+            in.vs0 = v_scale_eff[3 * gg]; in.vs1 = v_scale_eff[3 * gg + 1]; in.vs2 = v_scale_eff[3 * gg + 2];
+            in.vq = reinterpret_cast<const float4*>(v_quat_eff)[gg];
+            in.px = xyz[3 * gg]; in.py = xyz[3 * gg + 1]; in.pz = xyz[3 * gg + 2];
+            in.dm = d_max[gg];
+            in.cls = cls_id[gg];
+        }
+        return in;
+    };
+    ChunkIn nxt;
+    constexpr bool PRE = WAVES == 1 && ADK_LOD_PREFETCH;
+    if (PRE) nxt = request(blockIdx.x);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t g = (int64_t)chunk * 64 + lane;
         // ---- stage 0 (lane = Gaussian; wave 0): incoming gradients, LoD geometry, feature gather
@@ -300,7 +327,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         bool any_active = false;
         if (wave == 0) {
             if (ADAM) { visible = g < N && A.visible[g] != 0; TV[lane] = visible ? 1 : 0; }
-            if (g < N) {
+            int64_t cls_pre = 0;
+            if (PRE) {
+                if (g < N) {
+                    vo = nxt.vo; vs[0] = nxt.vs0; vs[1] = nxt.vs1; vs[2] = nxt.vs2; vq = nxt.vq; cls_pre = nxt.cls;
+                    L = lod_geometry_of(nxt.px, nxt.py, nxt.pz, nxt.dm, cc);
+                    active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
+                }
+            } else if (g < N) {
                 vo = v_opac_eff[g];
                 vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
                 vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
@@ -314,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 // features straight into the X tile, one float4 at a time (holding all 32 in registers next to the weight fragments spills at 128 VGPRs)
                 int c32 = -1;
                 if (active) {
-                    const int64_t cls = cls_id[g];
+                    const int64_t cls = PRE ? cls_pre : cls_id[g];
                     c32 = (int)cls;
                     const float4* gf = reinterpret_cast<const float4*>(global_feat + cls * LOD_G);
                     const float4* lf = reinterpret_cast<const float4*>(local_feat + g * LOD_L);
@@ -330,6 +364,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 }
                 TC[lane] = c32;
             }
+            if (PRE) nxt = request(chunk + (int)gridDim.x);   // lands while this chunk's matrix stages run
         }
         if (WAVES == 2) { __syncthreads(); any_active = TAny != 0; }
         if (!any_active) { // nothing visible in this chunk: zero gradients, no matrix work
@@ -675,9 +710,9 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     int nb = (int)adk::ceil_div(N, 64);
     if (nb > LOD_BWD_MAX_BLOCKS) nb = LOD_BWD_MAX_BLOCKS;
     adk::LodAdam none{};
-    // ADK_LOD_BWD_WAVES = 1 | 2 (read per launch: the lab flips it in-process): waves per 64-Gaussian chunk, see the kernel
+    // ADK_LOD_BWD_WAVES = 1 (default) | 2 (read per launch: the lab flips it in-process): waves per 64-Gaussian chunk, see the kernel
     const char* we = getenv("ADK_LOD_BWD_WAVES");
-    const int waves = (we && we[0] == '1') ? 1 : 2;
+    const int waves = (we && we[0] == '2') ? 2 : 1;   // default: one wave per chunk (the two-wave form measured 60 % slower, profiles/r04_ab_lod_waves.txt)
 #define ADK_LOD_ARGS N, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff, \
                      v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat, (float*)workspace, none
     if (waves == 2) hipLaunchKernelGGL((adk::lod_params_bwd_kernel<false, 2>), dim3(nb), dim3(128), 0, stream, ADK_LOD_ARGS);
@@ -729,7 +764,7 @@ extern "C" int adk_lod_params_bwd_adam(int N, float* xyz, float* opacity_raw, fl
     A.m_local = m_local; A.v_local = v2_local; A.lr_local = lr_local;
     A.b1 = beta1; A.b2 = beta2; A.eps = eps;
     const char* we = getenv("ADK_LOD_BWD_WAVES");
-    const int waves = (we && we[0] == '1') ? 1 : 2;
+    const int waves = (we && we[0] == '2') ? 2 : 1;   // default: one wave per chunk (the two-wave form measured 60 % slower, profiles/r04_ab_lod_waves.txt)
 #define ADK_LOD_ARGS N, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff, \
                      v_quat_eff, const_cast<float*>(v_xyz), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_global_feat, (float*)workspace, A
     if (waves == 2) hipLaunchKernelGGL((adk::lod_params_bwd_kernel<true, 2>), dim3(nb), dim3(128), 0, stream, ADK_LOD_ARGS);
