@@ -234,8 +234,10 @@ __device__ __forceinline__ void lod_adam_rows(const LodAdam& A, int64_t g, float
 
 // ADAM: the five per-Gaussian parameter tensors are updated in place (see LodAdam) and their gradients are not written; every read of
 // a parameter precedes the write of the same element in the same thread, so the pointers simply lose their __restrict__.
+// Requesting the NEXT chunk's stage-0 inputs during the current chunk's matrix stages: built, correct, and NEUTRAL (profiles/r04_ab_lod_prefetch.txt:
+// 0.1530 vs 0.1534 ms at 1 M / 512x384, 0.164 vs 0.163 at 1080p) -- stage 0's dependent memory round trips are not what bounds this kernel.  Off.
 #ifndef ADK_LOD_PREFETCH
-#define ADK_LOD_PREFETCH 1
+#define ADK_LOD_PREFETCH 0
 #endif
 #ifndef ADK_LOD_BWD_MINWAVES
 #define ADK_LOD_BWD_MINWAVES 3   // two-wave form: 3 waves per SIMD = 168 VGPRs, no scratch; 4 (128 VGPRs) spills 143 dwords

@@ -42,6 +42,24 @@ class _Meta(dict):
             self._materialise()
         return super().get(key, default)
 
+    # every way of reading the values without naming a key sees the materialised lists, never the None placeholders
+    def items(self):
+        self._materialise()
+        return super().items()
+
+    def values(self):
+        self._materialise()
+        return super().values()
+
+    def copy(self):
+        self._materialise()
+        return _Meta(super().copy())
+
+    def pop(self, key, *default):
+        if key in ("flatten_ids", "isect_offsets"):
+            self._materialise()
+        return super().pop(key, *default)
+
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 
 
@@ -120,7 +138,10 @@ def rasterization(
     rec = torch.stack([o[3] for o in outs])       # [C,N,12] packed splat records
     dch = 8 if depth_only else 11
     # the lists in the outputs are gsplat's when they were asked for or when the internal tiles are 16x16 anyway
-    gsplat_lists = want_isect_ids or _rasterizer.LAST_STATS.get("tile_px") == (16, 16)
+    # decided per CAMERA from the lists themselves (one offset per 16x16 tile?), not from process-global state: a camera whose wide lists
+    # overflowed falls back to the 16x16 route on its own, and a viewer thread may render concurrently
+    grid16 = ((height + 15) // 16, (width + 15) // 16)
+    gsplat_lists = want_isect_ids or all(tuple(o[6].shape[-2:]) == grid16 for o in outs)
     meta = _Meta({
         "camera_ids": None, "gaussian_ids": None,
         "radii": torch.stack([o[2] for o in outs]),

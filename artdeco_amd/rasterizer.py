@@ -198,7 +198,7 @@ def _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids, t
     _lib.check(rc, "adk_bin_depth_order")
     count_ready.synchronize()  # the one host wait of the pipeline (sizes the list)
     n_isects = int(host_count[0])
-    LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(16, 16), tiles_per_gauss=tiles_per_gauss)
+    LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(16, 16))   # plain numbers only: no tensor is kept alive from here
 
     flatten_ids = _empty_rounded(n_isects, **i32)
     tile_ids = _empty_rounded(n_isects, **i32)
@@ -258,7 +258,7 @@ def _bin_lists(lib, cfg, tile_px, want_tile_ids, N, W, H, rec, depth_keys, gauss
                                                  W, H, tpw, tph, offsets.data_ptr(), tbase, tbytes, pairs.data_ptr(), stream)
                 _lib.check(rc, "adk_bin_local_scatter")
             if stats:
-                LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(tpw, tph), tiles_per_gauss=tiles_per_gauss)
+                LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(tpw, tph))
             flatten_ids = _empty_rounded(n_isects, **i32)
             tile_ids = _empty_rounded(n_isects, **i32) if want_tile_ids else None
             with _stage("bin_sort"):
