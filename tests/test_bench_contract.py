@@ -39,6 +39,38 @@ def test_roofline_stages_follow_the_survey_formulas():
     assert abs(r["whole_step"]["ms_sum_of_stages"] - total_ms) < 1e-3                                # every stage's time, also those without a formula
 
 
+def test_project_bwd_bytes_do_not_count_the_traffic_the_fused_colour_adam_removed():
+    """SURVEY's SH-bwd term 420 V includes WRITING 192 B of colour gradients, which the fused colour Adam never does; the
+    stage is priced at 148 N + (36 + 6 x 192) V (the Adam triple read and written once, the coefficients read once for both purposes)."""
+    bench = importlib.import_module("bench")
+    N, V = 1_000_000, 880_000
+    r = bench.roofline_stages({"project_bwd": {"mean_ms": 0.25}}, N, V, 3_700_000, 1920 * 1080, 1920, 1080)
+    assert r["project_bwd"]["alg_bytes"] == 148.0 * N + 1188.0 * V
+    assert r["project_bwd"]["alg_bytes"] < 148.0 * N + 420.0 * V + 1152.0 * V
+
+
+def test_roofline_names_the_backward_form_the_frame_size_uses():
+    """raster_tiles.hip:split_parts (round 4): quadrants below 1 600 tiles, halves below 20 000, the whole tile above."""
+    bench = importlib.import_module("bench")
+    assert "<1, 1, true>" in bench.bwd_kernel_name(512, 384) and "<1, 1, true>" in bench.bwd_kernel_name(648, 486)
+    assert "<2, 1, true>" in bench.bwd_kernel_name(1920, 1080) and "<2, 1, true>" in bench.bwd_kernel_name(2592, 1944)
+    assert "<2, 2, false>" in bench.bwd_kernel_name(4096, 2160)
+    src = open(os.path.join(ROOT, "artdeco_amd", "csrc", "raster_tiles.hip")).read()
+    assert "n_tiles < 1600 ? 4 : (n_tiles < 20000 ? 2 : 1)" in src          # the kernel's rule and the label's rule are the same
+
+
+def test_late_windows_end_where_the_baseline_sequences_end():
+    """bench.late_windows: the timed 20 frames are frames 280-300 (PINGPONG's 300) and 980-1 000 (configs[2]'s 1 000): 278 / 978 keyframes
+    fast-forwarded + 2 warm frames; each window holds exactly one SLAM keyframe of the stated cadence."""
+    from harness import stream
+    for k0 in (278, 978):
+        flags = [stream.frame_flags(i, kf_every=5, slam_every=15, test_hold=8) for i in range(k0 + 2, k0 + 22)]
+        assert sum(f["is_slam_keyframe"] for f in flags) == 1
+        assert (k0 + 22) in (300, 1000)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '512, 384, 278)' in src and 'args.width, args.height, 978)' in src
+
+
 @pytest.mark.gpu
 def test_warm_process_runs_every_frame_kind_and_leaves_the_rng_streams_alone():
     """harness/stream.warm_process (what bench.py / bench_system.py call before anything is timed): a SLAM keyframe, a densified frame
