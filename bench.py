@@ -315,6 +315,8 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_extra_configs and world == 1:
             out["other_configs"] = extra_configs(args, dev)
+        if world == 1:
+            out["frame_delivery"] = frame_delivery(args, dev, elapsed_max / args.steps * 1e3)
         if not args.no_extra_configs and world == 1:
             out["late_windows"] = late_windows(args, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -530,6 +532,33 @@ def late_windows(args, dev):
             except Exception as e:  # report, never hide
                 res[key] = {"error": repr(e)[:300]}
     return res
+
+
+def frame_delivery(args, dev, ms_per_frame):
+    """What `value` leaves out by contract (inputs resident in HBM): in run_system.py every mapped frame arrives from the backend process
+    through a host queue and is copied to the mapper's device inside the timed loop (run_system.py:162-177: `densePoint.to(device_mapper)`,
+    `dataset.transform.to_map(original_img, device=device_mapper)`).  Measured here: the frame's image (3 x H x W fp32) and dense point map
+    + confidence at the SLAM resolution (384 x 512 x 4 fp32) from PINNED host memory to the device, mean of 10 copies; and the frame rate
+    with that copy serialised in front of every frame (the PCIe-inclusive rate: never `value`)."""
+    try:
+        img = torch.empty(3, args.height, args.width, dtype=torch.float32).pin_memory()
+        pts = torch.empty(384, 512, 4, dtype=torch.float32).pin_memory()
+        for _ in range(2):
+            img.to(dev, non_blocking=True); pts.to(dev, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            a = img.to(dev, non_blocking=True); b = pts.to(dev, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        nbytes = img.numel() * 4 + pts.numel() * 4
+        del a, b
+        return {"bytes_per_frame": nbytes, "h2d_ms_per_frame": ms, "h2d_GBps": nbytes / (ms * 1e-3) / 1e9,
+                "frames_per_s_with_delivery_serialised": 1e3 / (ms_per_frame + ms),
+                "note": "pinned host -> device copy of one frame's image + point map + confidence; inside the reference's wall clock "
+                        "(run_system.py:162-177), outside `value` (inputs resident in HBM by the bench contract)"}
+    except Exception as e:  # report, never hide
+        return {"error": repr(e)[:300]}
 
 
 def psnr_proxy(dev):
