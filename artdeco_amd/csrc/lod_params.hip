@@ -234,20 +234,10 @@ __device__ __forceinline__ void lod_adam_rows(const LodAdam& A, int64_t g, float
 
 // ADAM: the five per-Gaussian parameter tensors are updated in place (see LodAdam) and their gradients are not written; every read of
 // a parameter precedes the write of the same element in the same thread, so the pointers simply lose their __restrict__.
-// Requesting the NEXT chunk's stage-0 inputs during the current chunk's matrix stages: built, correct, and NEUTRAL (profiles/r04_ab_lod_prefetch.txt:
-// 0.1530 vs 0.1534 ms at 1 M / 512x384, 0.164 vs 0.163 at 1080p) -- stage 0's dependent memory round trips are not what bounds this kernel.  Off.
-#ifndef ADK_LOD_PREFETCH
-#define ADK_LOD_PREFETCH 0
-#endif
-// PIPE: every input of chunk i + 1 requested during chunk i's matrix stages and landed before chunk i's first store (see the kernel): built,
-// correct, but its 60 extra live registers push the weight fragments into scratch, whose reloads are vector-memory loads themselves.  Off;
-// the stage reorder (VX before dW1) gets the same effect for free.
-#ifndef ADK_LOD_PIPE
-#define ADK_LOD_PIPE 0
-#endif
-#ifndef ADK_LOD_REORDER
-#define ADK_LOD_REORDER 1
-#endif
+// Tried on the one-wave form in round 4 and REMOVED (evidence under profiles/): requesting the next chunk's stage-0 inputs during this chunk's
+// matrix stages (neutral, r04_ab_lod_prefetch.txt); a full software pipeline that lands every input of chunk i + 1 before chunk i's first store
+// (60 more live registers push the weight fragments into scratch, whose reloads are vector-memory loads themselves: 16 % slower,
+// r04_ab_lod_reorder.txt).  What stayed: the 7-wide products on the 16x16x4 MFMA (SMALL, -9 %) and VX + atomics before dW1 (-1.5 %).
 #ifndef ADK_LOD_SMALL
 #define ADK_LOD_SMALL 1
 #endif
@@ -274,7 +264,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     // also what its 256-VGPR budget allows), 4 with two (128 VGPRs each).  TH holds H, later VZ: H is dead once dW2 has been accumulated, and
     // the stage order below is chosen so that this alias is legal.
     __shared__ float TX[64 * LOD_LDW], TH[64 * LOD_LDW], TY[64 * LOD_YW];
-    __shared__ int TCb[2][64];         // voxel id per row; PIPE double-buffers it (the next chunk's rows are staged while this chunk's atomics still read theirs)
+    __shared__ int TC[64];             // voxel id per row
     __shared__ unsigned char TV[64];   // ADAM: the chunk's visibility flags, for the accumulator-layout local_feat update
     __shared__ int TAny;               // WAVES == 2: does the chunk have an active Gaussian? (decided by wave 0, read by both)
     float* const TZ = TH;
@@ -318,77 +308,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     float bs1 = 0.f, bs2 = 0.f;
 
     const int n_chunks = (N + 63) / 64;
-    // Software pipeline (round 4, one-wave form): a chunk's incoming gradients, position, d_max and voxel id are requested while the
-    // PREVIOUS chunk runs its matrix stages.  Stage 0 is a chain of three dependent memory round trips (gradients -> is anything active? ->
-    // cls_id -> the gathered voxel feature) in front of 168 MFMAs, and only two waves share a SIMD: the first two trips now overlap.
-    constexpr bool PIPE_REQ = WAVES == 1 && !ADAM && ADK_LOD_PIPE;
-    struct ChunkIn { float vo, vs0, vs1, vs2, px, py, pz, dm, op, sc0, sc1, sc2, vx0, vx1, vx2; float4 vq, rot; int64_t cls; };
-    auto request = [&](int ch) -> ChunkIn {
-        ChunkIn in;
-        in.vo = in.vs0 = in.vs1 = in.vs2 = in.px = in.py = in.pz = in.op = in.sc0 = in.sc1 = in.sc2 = in.vx0 = in.vx1 = in.vx2 = 0.f; in.dm = 1.f;
-        in.vq = in.rot = make_float4(0.f, 0.f, 0.f, 0.f); in.cls = 0;
-        const int64_t gg = (int64_t)ch * 64 + lane;
-        if (ch < n_chunks && gg < N) {
-            in.vo = v_opac_eff[gg];
-            in.vs0 = v_scale_eff[3 * gg]; in.vs1 = v_scale_eff[3 * gg + 1]; in.vs2 = v_scale_eff[3 * gg + 2];
-            in.vq = reinterpret_cast<const float4*>(v_quat_eff)[gg];
-            in.px = xyz[3 * gg]; in.py = xyz[3 * gg + 1]; in.pz = xyz[3 * gg + 2];
-            in.dm = d_max[gg];
-            in.cls = cls_id[gg];
-            in.op = opacity_raw[gg];
-            in.sc0 = scaling_raw[3 * gg]; in.sc1 = scaling_raw[3 * gg + 1]; in.sc2 = scaling_raw[3 * gg + 2];
-            in.rot = reinterpret_cast<const float4*>(rotation)[gg];
-            if (PIPE_REQ) { in.vx0 = v_xyz_add[3 * gg]; in.vx1 = v_xyz_add[3 * gg + 1]; in.vx2 = v_xyz_add[3 * gg + 2]; }   // only this lane ever writes them
-        }
-        return in;
-    };
-    // PIPE (round 4, one-wave form without the fused Adam): NO load is outstanding when a chunk's stores and atomics are issued, and none is
-    // issued behind them that the chunk still needs.  Loads and stores share one in-order counter (vmcnt) on gfx9-family parts, and with both
-    // kinds pending the compiler must wait for vmcnt(0): a load issued after the previous chunk's 70 stores / global atomics -- stage 0's, and
-    // the element-wise stage's parameter reads -- waited for every one of those atomics to complete (SQ_WAIT_INST_ANY: 43 % of a wave's life,
-    // 0.17 vector-memory instructions in flight on average, profiles/r04_pmc_lod_bwd.txt).  Now every input of chunk i + 1 (gradients,
-    // position, d_max, voxel id, raw parameters; then, once those say which Gaussians are active, the feature rows) is requested while chunk
-    // i runs its matrix stages and has LANDED in registers before chunk i's first store.
-    constexpr bool PIPE = WAVES == 1 && !ADAM && ADK_LOD_PIPE;
-    constexpr bool PRE = WAVES == 1 && ADK_LOD_PREFETCH && !PIPE;
-    ChunkIn nxt, cur_in;
-    int tcp = 0;               // which TCb half belongs to the current chunk
-    int* TC = TCb[0];
-    bool active_pre = false;   // PIPE: this lane's Gaussian of the current chunk is active
-    LodGeom L_pre;
-    L_pre.alpha_ratio = 1.f; L_pre.inv_dmax = 0.f; L_pre.fading = false; L_pre.selected = false; L_pre.dist = 0.f; L_pre.dir[0] = L_pre.dir[1] = L_pre.dir[2] = 0.f;
-    // geometry + activity of a requested chunk, and the request of its feature rows (valid only where active)
-    auto prepare = [&](const ChunkIn& in, int ch, LodGeom& Lo, bool& act, float4 (&f)[8]) {
-        const int64_t gg = (int64_t)ch * 64 + lane;
-        act = false;
-        if (ch < n_chunks && gg < N) {
-            Lo = lod_geometry_of(in.px, in.py, in.pz, in.dm, cc);
-            act = Lo.selected && (in.vo != 0.f || in.vs0 != 0.f || in.vs1 != 0.f || in.vs2 != 0.f || in.vq.x != 0.f || in.vq.y != 0.f || in.vq.z != 0.f || in.vq.w != 0.f);
-        }
-        if (act) {
-            const float4* gf = reinterpret_cast<const float4*>(global_feat + in.cls * LOD_G);
-            const float4* lf = reinterpret_cast<const float4*>(local_feat + gg * LOD_L);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] = i < 4 ? gf[i] : lf[i - 4];
-        }
-    };
-    // the requested rows go straight into the X tile (free since the previous chunk's dW1) and the row's voxel id into the OTHER half of TCb
-    auto stage_rows = [&](const float4 (&f)[8], bool act, int64_t cls, int* tc) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 v = act ? f[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float* t = TX + lane * LOD_LDW + 4 * i;
-            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-        }
-        tc[lane] = act ? (int)cls : -1;
-    };
-    if (PIPE) {
-        float4 feat[8];
-        cur_in = request(blockIdx.x);
-        prepare(cur_in, blockIdx.x, L_pre, active_pre, feat);
-        stage_rows(feat, active_pre, cur_in.cls, TCb[0]);
-    }
-    if (PRE) nxt = request(blockIdx.x);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t g = (int64_t)chunk * 64 + lane;
         // ---- stage 0 (lane = Gaussian; wave 0): incoming gradients, LoD geometry, feature gather
@@ -402,17 +321,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         bool any_active = false;
         if (wave == 0) {
             if (ADAM) { visible = g < N && A.visible[g] != 0; TV[lane] = visible ? 1 : 0; }
-            int64_t cls_pre = 0;
-            if (PIPE) {
-                vo = cur_in.vo; vs[0] = cur_in.vs0; vs[1] = cur_in.vs1; vs[2] = cur_in.vs2; vq = cur_in.vq; cls_pre = cur_in.cls;
-                L = L_pre; active = active_pre;
-            } else if (PRE) {
-                if (g < N) {
-                    vo = nxt.vo; vs[0] = nxt.vs0; vs[1] = nxt.vs1; vs[2] = nxt.vs2; vq = nxt.vq; cls_pre = nxt.cls;
-                    L = lod_geometry_of(nxt.px, nxt.py, nxt.pz, nxt.dm, cc);
-                    active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
-                }
-            } else if (g < N) {
+            if (g < N) {
                 vo = v_opac_eff[g];
                 vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
                 vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
@@ -425,10 +334,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             if (any_active) {
                 // features straight into the X tile, one float4 at a time (holding all 32 in registers next to the weight fragments spills at 128 VGPRs)
                 int c32 = -1;
-                if (PIPE) {
-                    // X tile and voxel ids were staged during the previous chunk (stage_rows)
-                } else if (active) {
-                    const int64_t cls = PRE ? cls_pre : cls_id[g];
+                if (active) {
+                    const int64_t cls = cls_id[g];
                     c32 = (int)cls;
                     const float4* gf = reinterpret_cast<const float4*>(global_feat + cls * LOD_G);
                     const float4* lf = reinterpret_cast<const float4*>(local_feat + g * LOD_L);
@@ -442,22 +349,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 #pragma unroll
                     for (int i = 0; i < LOD_IN; ++i) TX[lane * LOD_LDW + i] = 0.f;
                 }
-                if (!PIPE) TC[lane] = c32;
+                TC[lane] = c32;
             }
-            if (PRE) nxt = request(chunk + (int)gridDim.x);   // lands while this chunk's matrix stages run
         }
         if (WAVES == 2) { __syncthreads(); any_active = TAny != 0; }
         if (!any_active) { // nothing visible in this chunk: zero gradients, no matrix work
-            if (PIPE) {      // the next chunk's inputs land (and are staged) before this chunk's stores go out
-                float4 feat[8];
-                cur_in = request(chunk + (int)gridDim.x);
-                prepare(cur_in, chunk + (int)gridDim.x, L_pre, active_pre, feat);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                tcp ^= 1;
-                stage_rows(feat, active_pre, cur_in.cls, TCb[tcp]);
-                TC = TCb[tcp];
-                lds_fence();
-            }
             if (wave == 0) {
                 if (ADAM) {
                     // visible rows still take their Adam step (zero gradient: the moments decay, the parameter moves by -lr m / (sqrt(v) + eps))
@@ -554,7 +450,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             }
             if (active) {
                 // opacity = sigmoid(o) * alpha_ratio
-                const float so = sigmoidf(PIPE ? cur_in.op : opacity_raw[g]);
+                const float so = sigmoidf(opacity_raw[g]);
                 go = vo * L.alpha_ratio * so * (1.f - so);
                 if (L.fading) { // d(alpha_ratio)/d(xyz) = -dir / d_max
                     const float c = -vo * so * L.inv_dmax;
@@ -563,13 +459,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 // scaling = exp(s) * sigmoid(y)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float sraw = PIPE ? (k == 0 ? cur_in.sc0 : (k == 1 ? cur_in.sc1 : cur_in.sc2)) : scaling_raw[3 * g + k];
+                    const float sraw = scaling_raw[3 * g + k];
                     const float e = __expf(sraw), sy = sigmoidf(y[k]);
                     gs[k] = vs[k] * e * sy;
                     vy[k] = vs[k] * e * sy * (1.f - sy);
                 }
                 // quat = rotation * y[3:7]
-                const float4 q = PIPE ? cur_in.rot : reinterpret_cast<const float4*>(rotation)[g];
+                const float4 q = reinterpret_cast<const float4*>(rotation)[g];
                 gq = make_float4(vq.x * y[3], vq.y * y[4], vq.z * y[5], vq.w * y[6]);
                 vy[3] = vq.x * q.x; vy[4] = vq.y * q.y; vy[5] = vq.z * q.z; vy[6] = vq.w * q.w;
             }
@@ -583,10 +479,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     v_scaling_raw[3 * g + k] = gs[k];
-                    if (gx[k] != 0.f) {
-                        if (PIPE) v_xyz_add[3 * g + k] = (k == 0 ? cur_in.vx0 : (k == 1 ? cur_in.vx1 : cur_in.vx2)) + gx[k];   // no load behind the previous chunk's atomics
-                        else v_xyz_add[3 * g + k] += gx[k];
-                    }
+                    if (gx[k] != 0.f) v_xyz_add[3 * g + k] += gx[k];
                 }
                 reinterpret_cast<float4*>(v_rotation)[g] = gq;
             }
@@ -594,8 +487,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int o = 0; o < LOD_OUT; ++o) TY[lane * LOD_YW + o] = vy[o];
             TY[lane * LOD_YW + 7] = 0.f;
         }
-        // PIPE: this chunk's inputs are dead from here on; the next chunk's are requested now and land during the dW2 / VZ / dW1 stages
-        if (PIPE) cur_in = request(chunk + (int)gridDim.x);
         tile_sync();
         // ---- dW2 += VY^T H (K = the 64 Gaussians of the chunk); last use of H
         const float* ky = TY + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_YW + rc;
@@ -638,16 +529,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             }
         }
         tile_sync();
-#if !ADK_LOD_REORDER
-        // ---- dW1 += VZ^T X; last use of X
-        const float* kx = TX + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_LDW + rc;
-#pragma unroll 8
-        for (int si = 0; si < 32 / WAVES; ++si) {
-            const float a = kh[2 * si * LOD_LDW];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kx[2 * si * LOD_LDW], acc1, 0, 0, 0);
-            bs1 += a;
-        }
-#endif
         // Round 4: VX and its stores / atomics come BEFORE dW1 (they only share read-only tiles).  Loads and stores share one in-order counter
         // (vmcnt) on this family, and with both kinds pending the compiler has to wait for vmcnt(0): the next chunk's stage-0 loads waited for
         // every global atomic of this chunk's output stage (SQ_WAIT_INST_ANY: 43 % of a wave's life, profiles/r04_pmc_lod_bwd.txt).  With dW1's
@@ -657,8 +538,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         //      Gaussian per half-wave).  Measured: re-laying VX out one Gaussian per lane (16 B per lane, 64 lines
         //      per instruction) is 3x slower.  Columns 16..31 = local-feature gradients (plain stores, every row),
         //      columns 0..15 scatter into the voxel's global feature (hardware fp32 atomics).
-        float4 featn[8];
-        if (PIPE) prepare(cur_in, chunk + (int)gridDim.x, L_pre, active_pre, featn);   // which of the next chunk's Gaussians are active; their feature rows requested
 #pragma unroll
         for (int rbi = 0; rbi < 2 / WAVES; ++rbi) {
             const int rb = WAVES == 2 ? wave : rbi;
@@ -668,10 +547,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 #pragma unroll
             for (int s = 0; s < 16; ++s)
                 d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[(rb * 32 + rc) * LOD_LDW + kk + 2 * s], w1n[s], d, 0, 0, 0);
-            if (PIPE && rbi == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and landed: nothing is in flight when the stores below go out
-                stage_rows(featn, active_pre, cur_in.cls, TCb[tcp ^ 1]);   // X is free since dW1; this chunk's atomics keep reading TCb[tcp]
-            }
             if (ADAM && rc >= LOD_G) {
                 // the gradient d[r] of local_feat[row][rc - 16] meets its parameter and moments here: same 64 B-line-per-quarter-wave
                 // pattern as the gradient store it replaces
@@ -712,7 +587,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 }
             }
         }
-#if ADK_LOD_REORDER
         // ---- dW1 += VZ^T X; last use of X
         const float* kx = TX + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_LDW + rc;
 #pragma unroll 8
@@ -721,9 +595,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kx[2 * si * LOD_LDW], acc1, 0, 0, 0);
             bs1 += a;
         }
-#endif
         tile_sync(); // tiles are rewritten by the next chunk
-        if (PIPE) { tcp ^= 1; TC = TCb[tcp]; }
     }
 
     // ---- one partial row per workgroup: dW1 | db1 | dW2 | db2
