@@ -23,6 +23,7 @@ import types
 import torch
 
 from . import _lib
+from . import native_step
 from . import rasterizer
 from .rasterizer import _WS, _stage, render_camera
 
@@ -625,7 +626,7 @@ def _hand_chain_ok(self, keyframe) -> bool:
             and keyframe.tW2C.is_cuda and os.environ.get("ARTDECO_AMD_HAND_CHAIN", "1") != "0" and torch.is_grad_enabled())
 
 
-def _train_on_keyframe_by_hand(self, keyframe, is_important):
+def _train_on_keyframe_by_hand(self, keyframe, is_important, bg=None):
     """fused_train_on_keyframe without the autograd engine.  The chain is fixed -- PoseRt -> FusedLodParams ->
     RasterizeGaussians -> FusedMapperLoss and back -- so the four Functions' forward / backward static methods are called
     directly, in that order, on rasterizer.HandCtx objects, and the gradients are handed to the leaves the way
@@ -635,7 +636,8 @@ def _train_on_keyframe_by_hand(self, keyframe, is_important):
     HandCtx = rasterizer.HandCtx
     dev = self.device
     lvl = keyframe.pyr_lvl
-    bg = torch.rand(3, device=dev)
+    if bg is None:   # else: already drawn by the native step that handed this frame back (one draw per step, h3dgsv3.py:421)
+        bg = torch.rand(3, device=dev)
     scale = 2 ** lvl
     width, height = self.width // scale, self.height // scale
     P = self.gaussian_params
@@ -697,6 +699,12 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     keyframe.zero_grad()
     self.optimizer.zero_grad()
     if _hand_chain_ok(self, keyframe):
+        if native_step.enabled():
+            # the whole forward / loss / backward as one native call; None = this step needs the per-stage chain (nothing modified)
+            loss, bg = native_step.train_on_keyframe(self, keyframe, is_important)
+            if loss is not None:
+                return loss
+            return _train_on_keyframe_by_hand(self, keyframe, is_important, bg=bg)
         return _train_on_keyframe_by_hand(self, keyframe, is_important)
     dev = self.device
     bg = torch.rand(3, device=dev)

@@ -46,11 +46,18 @@ class StageTimer:
 
     def summary_ms(self) -> dict[str, dict]:
         torch.cuda.synchronize()
-        out = {}
+        acc: dict[str, list] = {}   # stage -> [sum, min, count]
         for k, evs in self.events.items():
             ts = [a.elapsed_time(b) for a, b in evs]
-            out[k] = {"mean_ms": sum(ts) / len(ts), "min_ms": min(ts), "count": len(ts)}
-        return out
+            acc[k] = [sum(ts), min(ts), len(ts)]
+        # stages that ran inside adk_mapper_step recorded their event pairs on the C side (artdeco_amd/native_step.py)
+        from . import native_step
+        for k, (s, m, c) in native_step.drain_timings().items():
+            if self.only is not None and k not in self.only:
+                continue
+            a = acc.setdefault(k, [0.0, m, 0])
+            a[0] += s; a[1] = min(a[1], m); a[2] += c
+        return {k: {"mean_ms": a[0] / a[2], "min_ms": a[1], "count": a[2]} for k, a in acc.items()}
 
 
 _TIMER: StageTimer | None = None
@@ -59,6 +66,9 @@ _NULL = contextlib.nullcontext()
 
 def set_stage_timer(t: StageTimer | None) -> None:
     global _TIMER
+    if t is not None:
+        from . import native_step
+        native_step.drain_timings()   # pairs recorded under a previous timer are not this one's
     _TIMER = t
 
 

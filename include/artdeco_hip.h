@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 15
+#define ADK_ABI_VERSION 16
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -585,6 +585,70 @@ int adk_prune_mask(int64_t N, const float* opacity_raw, const float* scaling_raw
  * quaternion(R * R(quat)) (wxyz) with (R | t) = delta[ids[i]]; delta [n_keyframes,4,4] = new_c2w @ inverse(old_c2w) per keyframe. */
 int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, const float* delta, const float* xyz, const float* quat,
                         float* xyz_out, float* quat_out, adk_stream_t stream);
+
+/* ------------------------------------------------------ the mapper's optimisation step as ONE call
+ * Forward, loss and backward of SceneModel.optimization_step (Reconstruct/scene/scene_models/h3dgsv3.py:418-455: render at the
+ * keyframe's level -> exposure / clamp / L1 + fused-SSIM + inverse-depth loss -> loss.backward()) with every stage above enqueued by
+ * one host call: pose6d_fwd, lod_params_fwd, project_fwd, tile-local binning (count | scatter | sort), raster_fwd, visibility masks,
+ * photometric_fwd, fused_ssim_fwd_sums, photometric_loss_sums, fused_ssim_bwd, photometric_bwd, raster_bwd, project_bwd (with the SH
+ * colours' sparse-Adam step when color_adam != 0), lod_params_bwd, pose6d_bwd.  The optimiser steps that follow (Keyframe.step,
+ * SparseGaussianAdam.step: h3dgsv3.py:456-462) stay with the caller: they belong to ARTDECO's optimiser objects and consume the
+ * gradient buffers this call filled (adk_adam_update_multi_betas, one launch).
+ *
+ * Why a call of its own: the step has ONE host wait (the intersection count sizes the tile lists).  Everything a host does between
+ * that wait and the forward rasteriser's launch is time the GPU idles, and a Python host spends 0.55 ms per step on ~1 200 calls
+ * around the 20 C entries; here the wait, the sort's launch and the rasteriser's launch are consecutive statements.
+ *
+ * Every buffer is the caller's (a "plan": allocated once per (N, V, width, height), reused by every step); the call allocates
+ * nothing on the device.  Field kinds: P = device pointer, L = int64_t, I = int32_t, F = float; pointers come first so that the
+ * layout has no padding (bindings build their struct from this list: artdeco_amd/native_step.py parses it).
+ *   inputs       r6 [3,2], t [3], exposure [3,4], bg [3], gt [3,H,W], mono [1,H,W] (mono inverse depth), rdk [H,W], Kmat [3,3],
+ *                unit_grad [1] (the 1.0 loss.backward() starts from);
+ *   Gaussians    xyz .. d_max as adk_lod_params_fwd; f_dc [N,1,3], f_rest [N,sh_K-1,3] and, for color_adam, their moments exp_avg_* / exp_avg_sq_* and
+ *                0-dim learning rates lr_dc / lr_rest as adk_project_bwd_adam (adam_b1 / adam_b2 / adam_eps);
+ *   per step     loss [1], invdepth [H,W] (Keyframe.latest_invdepth) -- the two results a caller keeps beyond the step;
+ *   plan         everything else: intermediates (viewmat [16] .. last_ids), masks vis [N] / gvis [V] (bytes), loss scratch, and the
+ *                gradients v_* the optimisers read: v_means (= gradient of xyz, LoD fade term included), v_opacity_raw, v_scaling_raw,
+ *                v_rotation, v_local_feat, v_global_feat, v_mlp [1287] = dW1 | db1 | dW2 | db2, v_exposure [12], v_r6 [6], v_t [3];
+ *                v_dc / v_rest only without color_adam.  cam_grad: 16 floats zeroed once by the caller (left zeroed by the call);
+ *                pairs [isect_capacity] 8 B keys, flatten_ids [isect_capacity]; bin_table: adk_bin_local_workspace_bytes_t + 256 bytes.
+ * Return: ADK_OK; ADK_STEP_ECAPACITY when the frame has more intersections than isect_capacity (out->n_isects says how many: grow
+ * pairs / flatten_ids and call again); ADK_STEP_EROUTE when a tile list is too long for the tile-local sort (out->max_tile > 8192:
+ * use the per-stage calls with the global route).  Both are decided BEFORE anything the caller owns has been modified.  Any other
+ * negative value: the failing stage's own code, out->stage = its index in ADK_MAPPER_STAGES.
+ * ssim_grad_scale = -lambda_dssim / (3 W H), formed by the caller in double precision as the per-stage binding does (adk_fused_ssim_bwd's
+ * dL_scalar).  time_mask: bit s set = bracket stage s with a pair of events (adk_mapper_step_timings folds and frees them). */
+#define ADK_STEP_ECAPACITY (-16)
+#define ADK_STEP_EROUTE (-17)
+#define ADK_MAPPER_STEP_FIELDS(P, L, I, F) \
+    P(r6) P(t) P(exposure) P(bg) P(gt) P(mono) P(rdk) P(Kmat) P(unit_grad) \
+    P(xyz) P(opacity_raw) P(scaling_raw) P(rotation) P(local_feat) P(global_feat) P(W1) P(b1) P(W2) P(b2) P(cls_id) P(d_max) \
+    P(f_dc) P(f_rest) P(exp_avg_dc) P(exp_avg_sq_dc) P(exp_avg_rest) P(exp_avg_sq_rest) P(lr_dc) P(lr_rest) \
+    P(loss) P(invdepth) \
+    P(viewmat) P(opac) P(scale) P(quat) P(sel) P(rec) P(radii) P(depth_keys) P(gauss_ids) P(tiles_per_gauss) \
+    P(offsets) P(bin_stats) P(bin_table) P(pairs) P(flatten_ids) \
+    P(render_colors) P(render_alphas) P(final_T) P(last_ids) P(vis) P(gvis) \
+    P(image) P(gt_used) P(dm) P(parts) P(ssim_sums) P(photo_ws) P(v_img) P(v_col) P(v_alpha) P(v_exposure) \
+    P(v_rec) P(v_means) P(v_quats) P(v_scales) P(v_opac) P(v_dc) P(v_rest) P(cam_grad) P(v_viewmat) \
+    P(v_opacity_raw) P(v_scaling_raw) P(v_rotation) P(v_local_feat) P(v_global_feat) P(v_mlp) P(lod_ws) P(v_r6) P(v_t) \
+    L(isect_capacity) L(bin_table_bytes) L(lod_ws_bytes) L(photo_ws_bytes) L(n_ssim_sums) \
+    I(N) I(V) I(width) I(height) I(tile_px_w) I(tile_px_h) I(sh_K) I(sh_degree) I(mask_outliers) I(color_adam) I(pose_grad) I(time_mask) \
+    F(eps2d) F(near_plane) F(far_plane) F(radius_clip) F(lambda_dssim) F(depth_weight) F(adam_b1) F(adam_b2) F(adam_eps) F(ssim_grad_scale)
+#define ADK_MAPPER_STAGES(S) \
+    S(lod_params_fwd) S(project_fwd) S(bin_count) S(bin_scatter) S(bin_sort) S(raster_fwd) S(photometric_fwd) S(ssim_fwd) \
+    S(photometric_loss) S(ssim_bwd) S(photometric_bwd) S(raster_bwd) S(project_bwd) S(lod_params_bwd)
+#define ADK_MAPPER_N_STAGES 14
+#define ADK_FIELD_P(n) void* n;
+#define ADK_FIELD_L(n) int64_t n;
+#define ADK_FIELD_I(n) int32_t n;
+#define ADK_FIELD_F(n) float n;
+typedef struct AdkMapperStepArgs { ADK_MAPPER_STEP_FIELDS(ADK_FIELD_P, ADK_FIELD_L, ADK_FIELD_I, ADK_FIELD_F) } AdkMapperStepArgs;
+typedef struct AdkMapperStepOut { int64_t n_isects; int64_t max_tile; int32_t stage; int32_t reserved; } AdkMapperStepOut;
+int64_t adk_mapper_step_args_bytes(void);   /* sizeof(AdkMapperStepArgs): a binding checks its own layout against it */
+int adk_mapper_step(const AdkMapperStepArgs* args, AdkMapperStepOut* out, adk_stream_t stream);
+/* Folds the event pairs recorded under time_mask since the last call (waits for them): per stage the sum and the minimum of the
+ * elapsed times in ms and the number of pairs; arrays of ADK_MAPPER_N_STAGES.  Returns the total number of pairs folded. */
+int64_t adk_mapper_step_timings(double* sum_ms, double* min_ms, int64_t* count);
 
 #ifdef __cplusplus
 }

@@ -248,6 +248,7 @@ def test_hand_driven_chain_matches_the_autograd_chain(important, dev, monkeypatc
     got = {}
     for name, sc, env in (("hand", a, "1"), ("engine", b, "0")):
         monkeypatch.setenv("ARTDECO_AMD_HAND_CHAIN", env)
+        monkeypatch.setenv("ARTDECO_AMD_NATIVE_STEP", "0")   # the per-stage chain itself (tests/test_native_step.py holds the one-call form to it)
         for k in ("f_dc", "f_rest"):
             sc.optimizer.params[k]["exp_avg"].zero_()
         kf = sc.keyframes[1]
