@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "adk_common.hpp"
+#include "adk_internal.hpp"
 #include "artdeco_hip.h"
 
 namespace adk {
@@ -137,7 +138,10 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
     const int64_t table_bytes = A->bin_table_bytes - (int64_t)(tb - tb0);
 
     // ---- forward: pose -> LoD / mlp_cov -> projection -> binning -> rasteriser (h3dgsv3.py:626-680)
-    ADK_STEP_TRY(STAGE_lod_params_fwd, adk_pose6d_fwd(cf(A->r6), cf(A->t), f(A->viewmat), stream));
+    // the pose's launch also zeroes the two buffers later stages set bits in / scatter into (the voxel visibility mask: the projection;
+    // the voxel-feature gradient: the LoD backward), instead of a ~4 us launch each
+    ADK_STEP_TRY(STAGE_lod_params_fwd, adk::pose6d_fwd_clear(cf(A->r6), cf(A->t), f(A->viewmat), A->gvis, (int64_t)A->V, A->v_global_feat,
+                                                             (int64_t)A->V * 16 * sizeof(float), stream));
     {
         adk::StageScope ts(A, STAGE_lod_params_fwd, stream);
         ADK_STEP_TRY(STAGE_lod_params_fwd,
@@ -148,11 +152,14 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
     }
     {
         adk::StageScope ts(A, STAGE_project_fwd, stream);
+        // the visibility masks of h3dgsv3.py:695-698 come out of the projection itself (adk_visibility_masks' rule on the radii it forms)
+        const adk::ProjectMasks masks = {static_cast<const int64_t*>(A->cls_id), (int64_t)A->V, static_cast<uint8_t*>(A->vis),
+                                         static_cast<uint8_t*>(A->gvis)};
         ADK_STEP_TRY(STAGE_project_fwd,
-                     adk_project_fwd(N, cf(A->xyz), cf(A->quat), cf(A->scale), cf(A->opac), cf(A->f_dc), cf(A->f_rest), A->sh_K, A->sh_degree,
-                                     0 /* SH */, cf(A->viewmat), cf(A->Kmat), W, H, A->eps2d, A->near_plane, A->far_plane, A->radius_clip, 0,
-                                     f(A->rec), static_cast<int32_t*>(A->radii), static_cast<uint32_t*>(A->depth_keys),
-                                     static_cast<uint32_t*>(A->gauss_ids), static_cast<int32_t*>(A->tiles_per_gauss), stream));
+                     adk::project_fwd_launch(N, cf(A->xyz), cf(A->quat), cf(A->scale), cf(A->opac), cf(A->f_dc), cf(A->f_rest), A->sh_K,
+                                             A->sh_degree, 0 /* SH */, cf(A->viewmat), cf(A->Kmat), W, H, A->eps2d, A->near_plane, A->far_plane,
+                                             A->radius_clip, 0, f(A->rec), static_cast<int32_t*>(A->radii), static_cast<uint32_t*>(A->depth_keys),
+                                             static_cast<uint32_t*>(A->gauss_ids), static_cast<int32_t*>(A->tiles_per_gauss), &masks, stream));
     }
     {
         adk::StageScope ts(A, STAGE_bin_count, stream);
@@ -187,8 +194,6 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
                                       n_isects, nullptr, f(A->render_colors), f(A->render_alphas), f(A->final_T), static_cast<int32_t*>(A->last_ids),
                                       nullptr, stream));
     }
-    ADK_STEP_TRY(STAGE_raster_fwd, adk_visibility_masks(N, static_cast<const int*>(A->radii), static_cast<const int64_t*>(A->cls_id), A->V,
-                                                        static_cast<uint8_t*>(A->vis), static_cast<uint8_t*>(A->gvis), stream));
 
     // ---- loss (h3dgsv3.py:690-694, 611-614, 430-448)
     const float* gt_used = A->mask_outliers ? cf(A->gt_used) : cf(A->gt);
@@ -238,22 +243,25 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
         adk::StageScope ts(A, STAGE_project_bwd, stream);
         float* const cam_grad = A->pose_grad ? f(A->cam_grad) : nullptr;
         float* const v_viewmat = A->pose_grad ? f(A->v_viewmat) : nullptr;
+        // Keyframe.get_Rt's backward rides in the launch that finalises the camera gradient
+        const float* const pose_r6 = A->pose_grad ? cf(A->r6) : nullptr;
         if (A->color_adam) {
             ADK_STEP_TRY(STAGE_project_bwd,
-                         adk_project_bwd_adam(N, cf(A->xyz), cf(A->quat), cf(A->scale), f(A->f_dc), f(A->f_rest), A->sh_K, A->sh_degree, cf(A->viewmat),
-                                              cf(A->Kmat), W, H, A->eps2d, A->near_plane, A->far_plane, 0, static_cast<const int32_t*>(A->radii),
-                                              cf(A->v_rec), f(A->v_means), f(A->v_quats), f(A->v_scales), f(A->v_opac), cam_grad, v_viewmat,
-                                              f(A->exp_avg_dc), f(A->exp_avg_sq_dc), f(A->exp_avg_rest), f(A->exp_avg_sq_rest), cf(A->lr_dc),
-                                              cf(A->lr_rest), A->adam_b1, A->adam_b2, A->adam_eps, stream));
+                         adk::project_bwd_adam_launch(N, cf(A->xyz), cf(A->quat), cf(A->scale), f(A->f_dc), f(A->f_rest), A->sh_K, A->sh_degree,
+                                                      cf(A->viewmat), cf(A->Kmat), W, H, A->eps2d, A->near_plane, A->far_plane, 0,
+                                                      static_cast<const int32_t*>(A->radii), cf(A->v_rec), f(A->v_means), f(A->v_quats),
+                                                      f(A->v_scales), f(A->v_opac), cam_grad, v_viewmat, f(A->exp_avg_dc), f(A->exp_avg_sq_dc),
+                                                      f(A->exp_avg_rest), f(A->exp_avg_sq_rest), cf(A->lr_dc), cf(A->lr_rest), A->adam_b1,
+                                                      A->adam_b2, A->adam_eps, pose_r6, f(A->v_r6), f(A->v_t), stream));
         } else {
             ADK_STEP_TRY(STAGE_project_bwd,
-                         adk_project_bwd(N, cf(A->xyz), cf(A->quat), cf(A->scale), cf(A->f_dc), cf(A->f_rest), A->sh_K, A->sh_degree, 0, cf(A->viewmat),
-                                         cf(A->Kmat), W, H, A->eps2d, A->near_plane, A->far_plane, 0, static_cast<const int32_t*>(A->radii),
-                                         cf(A->v_rec), f(A->v_means), f(A->v_quats), f(A->v_scales), f(A->v_opac), f(A->v_dc), f(A->v_rest), cam_grad,
-                                         v_viewmat, stream));
+                         adk::project_bwd_launch(N, cf(A->xyz), cf(A->quat), cf(A->scale), cf(A->f_dc), cf(A->f_rest), A->sh_K, A->sh_degree, 0,
+                                                 cf(A->viewmat), cf(A->Kmat), W, H, A->eps2d, A->near_plane, A->far_plane, 0,
+                                                 static_cast<const int32_t*>(A->radii), cf(A->v_rec), f(A->v_means), f(A->v_quats), f(A->v_scales),
+                                                 f(A->v_opac), f(A->v_dc), f(A->v_rest), cam_grad, v_viewmat, nullptr, pose_r6, f(A->v_r6), f(A->v_t),
+                                                 stream));
         }
     }
-    ADK_STEP_TRY(STAGE_lod_params_bwd, adk::step_zero(A->v_global_feat, (int64_t)A->V * 16 * sizeof(float), stream));
     {
         adk::StageScope ts(A, STAGE_lod_params_bwd, stream);
         // v_means doubles as the LoD backward's v_xyz_add: the fade term is accumulated into the rasteriser's gradient of the means
@@ -264,7 +272,5 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
                                         f(A->v_scaling_raw), f(A->v_rotation), f(A->v_local_feat), f(A->v_global_feat), f(A->v_mlp), A->lod_ws,
                                         A->lod_ws_bytes, stream));
     }
-    if (A->pose_grad)
-        ADK_STEP_TRY(STAGE_lod_params_bwd, adk_pose6d_bwd(cf(A->r6), cf(A->v_viewmat), f(A->v_r6), f(A->v_t), stream));
     return ADK_OK;
 }

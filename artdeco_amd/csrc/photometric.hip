@@ -16,6 +16,8 @@
 // Also here: the 6D-pose -> view matrix map of Keyframe.get_Rt (scene/keyframe.py:150-154, utils.py:223-229) with
 // its analytic backward, and the visibility masks of render (h3dgsv3.py:695-698).
 #include "adk_common.hpp"
+#include "adk_internal.hpp"
+#include "pose6d.hpp"
 
 namespace adk {
 
@@ -179,33 +181,7 @@ __global__ __launch_bounds__(PHOTO_THREADS) void photometric_bwd_kernel(
     }
 }
 
-// ---- 6D pose <-> view matrix (single thread; 9 numbers) ----------------------------------------------
-struct Pose6 { float b1[3], b2[3], b3[3], a2[3], n1, nu, d; };
-
-__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
-    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-
-__device__ __forceinline__ Pose6 pose6_of(const float* __restrict__ r6 /* [3,2] row-major */) {
-    Pose6 q;
-    float a1[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { a1[i] = r6[2 * i]; q.a2[i] = r6[2 * i + 1]; }
-    q.n1 = sqrtf(dot3(a1, a1));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) q.b1[i] = a1[i] / q.n1;
-    q.d = dot3(q.b1, q.a2);
-    float u[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) u[i] = q.a2[i] - q.d * q.b1[i];
-    q.nu = sqrtf(dot3(u, u));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) q.b2[i] = u[i] / q.nu;
-    cross3(q.b1, q.b2, q.b3);
-    return q;
-}
-
+// ---- 6D pose <-> view matrix (single thread; 9 numbers): device functions in pose6d.hpp --------------------
 __global__ void pose6d_fwd_kernel(const float* __restrict__ r6, const float* __restrict__ t, float* __restrict__ Rt) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const Pose6 q = pose6_of(r6);
@@ -217,32 +193,31 @@ __global__ void pose6d_fwd_kernel(const float* __restrict__ r6, const float* __r
 __global__ void pose6d_bwd_kernel(const float* __restrict__ r6, const float* __restrict__ v_Rt, float* __restrict__ v_r6,
                                   float* __restrict__ v_t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    pose6d_bwd_body(r6, v_Rt, v_r6, v_t);
+}
+
+// pose6d_fwd + zero fill of up to two spans in the same launch (the one-call step: the voxel visibility mask the projection sets bits in,
+// the voxel-feature gradient the LoD backward scatters into -- two ~4 us launches less per step).  Thread 0 of block 0 builds the matrix;
+// every thread zeroes its share: 16 B per lane where the span is aligned, bytes at the ragged ends.
+__device__ __forceinline__ void zero_span(unsigned char* p, int64_t nbytes, int64_t tid, int64_t nthreads) {
+    if (p == nullptr || nbytes <= 0) return;
+    const int64_t head = min(nbytes, (int64_t)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15));
+    const int64_t n16 = (nbytes - head) >> 4;
+    float4* q = reinterpret_cast<float4*>(p + head);
+    for (int64_t i = tid; i < n16; i += nthreads) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = tid; i < head; i += nthreads) p[i] = 0;
+    for (int64_t i = head + (n16 << 4) + tid; i < nbytes; i += nthreads) p[i] = 0;
+}
+__global__ __launch_bounds__(256) void pose6d_fwd_clear_kernel(const float* __restrict__ r6, const float* __restrict__ t, float* __restrict__ Rt,
+                                                               unsigned char* a, int64_t na, unsigned char* b, int64_t nb) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    zero_span(a, na, tid, nthreads);
+    zero_span(b, nb, tid, nthreads);
+    if (tid != 0) return;
     const Pose6 q = pose6_of(r6);
-    float g1[3], g2[3], g3[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { g1[i] = v_Rt[4 * i]; g2[i] = v_Rt[4 * i + 1]; g3[i] = v_Rt[4 * i + 2]; v_t[i] = v_Rt[4 * i + 3]; }
-    // b3 = b1 x b2
-    float vb1[3], vb2[3], tmp[3];
-    cross3(q.b2, g3, tmp);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) vb1[i] = g1[i] + tmp[i];
-    cross3(g3, q.b1, tmp);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) vb2[i] = g2[i] + tmp[i];
-    // b2 = u / |u|
-    float vu[3];
-    const float s2 = dot3(q.b2, vb2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) vu[i] = (vb2[i] - q.b2[i] * s2) / q.nu;
-    // u = a2 - (b1 . a2) b1
-    const float s1 = dot3(q.b1, vu);
-    float va2[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { va2[i] = vu[i] - q.b1[i] * s1; vb1[i] -= q.d * vu[i] + s1 * q.a2[i]; }
-    // b1 = a1 / |a1|
-    const float s0 = dot3(q.b1, vb1);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { v_r6[2 * i] = (vb1[i] - q.b1[i] * s0) / q.n1; v_r6[2 * i + 1] = va2[i]; }
+    for (int i = 0; i < 3; ++i) { Rt[4 * i] = q.b1[i]; Rt[4 * i + 1] = q.b2[i]; Rt[4 * i + 2] = q.b3[i]; Rt[4 * i + 3] = t[i]; }
+    Rt[12] = 0.f; Rt[13] = 0.f; Rt[14] = 0.f; Rt[15] = 1.f;
 }
 
 // ---- visibility masks (h3dgsv3.py:695-698) -------------------------------------------------------------------
@@ -353,6 +328,16 @@ extern "C" int adk_pose6d_fwd(const float* r6, const float* t, float* Rt, hipStr
 {
     if (!r6 || !t || !Rt) return ADK_EINVAL;
     hipLaunchKernelGGL(adk::pose6d_fwd_kernel, dim3(1), dim3(64), 0, stream, r6, t, Rt);
+    ADK_RETURN_LAST_ERROR();
+}
+
+int adk::pose6d_fwd_clear(const float* r6, const float* t, float* Rt, void* a, int64_t na, void* b, int64_t nb, hipStream_t stream)
+{
+    if (!r6 || !t || !Rt || na < 0 || nb < 0) return ADK_EINVAL;
+    const int64_t work = adk::ceil_div((na > nb ? na : nb), 16);
+    const int blocks = (int)(work <= 256 ? 1 : (adk::ceil_div(work, 256) > 2048 ? 2048 : adk::ceil_div(work, 256)));
+    hipLaunchKernelGGL(adk::pose6d_fwd_clear_kernel, dim3(blocks), dim3(256), 0, stream, r6, t, Rt, static_cast<unsigned char*>(a), na,
+                       static_cast<unsigned char*>(b), nb);
     ADK_RETURN_LAST_ERROR();
 }
 

@@ -18,6 +18,8 @@
 // so depth sort keys, radii and tile ranges are bit-identical to the oracle.  log() on the
 // radius path is evaluated in fp64 and rounded (one per Gaussian; free on an HBM-bound kernel).
 #include "adk_common.hpp"
+#include "adk_internal.hpp"
+#include "pose6d.hpp"
 
 namespace adk {
 
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height, int tile_w, int tile_h,
     float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth,
     float* __restrict__ rec, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
-    uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss)
+    uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss, const ProjectMasks masks)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     gauss_ids[g] = (uint32_t)g;
     if (!valid) {
         radii[2 * g] = 0; radii[2 * g + 1] = 0;
+        if (masks.vis) masks.vis[g] = 0;
         depth_keys[g] = 0xFFFFFFFFu; // sorts behind every visible Gaussian
         tiles_per_gauss[g] = 0;
         r4[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -304,6 +307,14 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     }
 
     radii[2 * g] = (int32_t)rad_x; radii[2 * g + 1] = (int32_t)rad_y;
+    if (masks.vis) { // adk_visibility_masks' rule on the radii just written (h3dgsv3.py:695-698)
+        const bool seen = (int32_t)rad_x > 0 && (int32_t)rad_y > 0;
+        masks.vis[g] = seen ? 1 : 0;
+        if (seen && masks.gvis) {
+            const int64_t c = masks.cls_id[g];
+            if (c >= 0 && c < masks.V) masks.gvis[c] = 1; // every writer stores the same byte
+        }
+    }
     depth_keys[g] = __float_as_uint(P.mc[2]);
     int x0, x1, y0, y1;
     tile_range(P.m2x, P.m2y, rad_x, rad_y, tile_w, tile_h, x0, x1, y0, y1);
@@ -663,7 +674,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 //   campos = -Ri t  =>  v_Ri = -v_cp t^T ; v_R' = -Ri^T v_Ri Ri^T = Ri^T v_cp t^T Ri^T = (Ri^T v_cp)(Ri t)^T
 // Leaves cam_grad zeroed again: a caller can keep ONE accumulator per stream instead of clearing a fresh one every step.
 __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, float* __restrict__ cam_grad,
-                                             float* __restrict__ v_viewmat)
+                                             float* __restrict__ v_viewmat, const float* __restrict__ pose_r6, float* __restrict__ v_r6,
+                                             float* __restrict__ v_t)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float R[3][3], t[3];
@@ -690,6 +702,8 @@ __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, 
     }
     for (int j = 0; j < 4; ++j) v_viewmat[12 + j] = 0.f;
     for (int j = 0; j < 16; ++j) cam_grad[j] = 0.f;
+    // the one-call step: Keyframe.get_Rt's backward on the matrix this thread has just written (else a launch of its own, adk_pose6d_bwd)
+    if (pose_r6) pose6d_bwd_body(pose_r6, v_viewmat, v_r6, v_t);
 }
 
 } // namespace adk
@@ -708,8 +722,23 @@ extern "C" int adk_project_fwd(int N, const float* means, const float* quats, co
                                float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
                                uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, hipStream_t stream)
 {
+    return adk::project_fwd_launch(N, means, quats, scales, opacities, colors_in, sh_rest, sh_K, sh_degree, color_mode, viewmat, Kmat, width, height,
+                                   eps2d, near_plane, far_plane, radius_clip, inv_depth, rec, radii, depth_keys, gauss_ids, tiles_per_gauss, nullptr,
+                                   stream);
+}
+
+int adk::project_fwd_launch(int N, const float* means, const float* quats, const float* scales, const float* opacities, const float* colors_in,
+                            const float* sh_rest, int sh_K, int sh_degree, int color_mode, const float* viewmat, const float* Kmat, int width,
+                            int height, float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
+                            uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, const ProjectMasks* masks_in, hipStream_t stream)
+{
     if (N < 0 || width <= 0 || height <= 0) return ADK_EINVAL;
     if (N == 0) return 0;
+    ProjectMasks masks = {nullptr, 0, nullptr, nullptr};
+    if (masks_in) {
+        masks = *masks_in;
+        if (!masks.vis || (masks.gvis && (!masks.cls_id || masks.V <= 0))) return ADK_EINVAL;
+    }
     if (!means || !quats || !scales || !opacities || !viewmat || !Kmat || !rec || !radii || !depth_keys || !gauss_ids || !tiles_per_gauss) return ADK_EINVAL;
     if (color_mode < 0 || color_mode > 2 || (color_mode != 2 && !colors_in)) return ADK_EINVAL;
     if (color_mode == 0 && (sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1))) return ADK_EINVAL;
@@ -721,21 +750,22 @@ extern "C" int adk_project_fwd(int N, const float* means, const float* quats, co
     ADK_DISPATCH_SH(deg, hipLaunchKernelGGL((adk::project_fwd_kernel<SH_DEG>), grid, block, 0, stream, N, means, quats,
                                             scales, opacities, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
                                             tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, inv_depth, rec, radii,
-                                            depth_keys, gauss_ids, tiles_per_gauss));
+                                            depth_keys, gauss_ids, tiles_per_gauss, masks));
     ADK_RETURN_LAST_ERROR();
 }
 
-static int project_bwd_launch(int N, const float* means, const float* quats, const float* scales,
-                              const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
-                              const float* viewmat, const float* Kmat, int width, int height, float eps2d,
-                              float near_plane, float far_plane, int inv_depth, const int32_t* radii,
-                              const float* v_rec, float* v_means, float* v_quats, float* v_scales,
-                              float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad,
-                              float* v_viewmat, const adk::ColorAdam* opt, hipStream_t stream)
+int adk::project_bwd_launch(int N, const float* means, const float* quats, const float* scales,
+                            const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
+                            const float* viewmat, const float* Kmat, int width, int height, float eps2d,
+                            float near_plane, float far_plane, int inv_depth, const int32_t* radii,
+                            const float* v_rec, float* v_means, float* v_quats, float* v_scales,
+                            float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad,
+                            float* v_viewmat, const adk::ColorAdam* opt, const float* pose_r6, float* v_r6, float* v_t, hipStream_t stream)
 {
     if (N < 0 || width <= 0 || height <= 0) return ADK_EINVAL;
     if (!viewmat || !Kmat) return ADK_EINVAL;
     if ((v_viewmat != nullptr) != (cam_grad != nullptr)) return ADK_EINVAL;
+    if (pose_r6 && (!v_viewmat || !v_r6 || !v_t)) return ADK_EINVAL;
     if (N > 0) {
         if (!means || !quats || !scales || !radii || !v_rec) return ADK_EINVAL;
         if (color_mode < 0 || color_mode > 2 || (color_mode == 0 && !colors_in)) return ADK_EINVAL;
@@ -758,7 +788,7 @@ static int project_bwd_launch(int N, const float* means, const float* quats, con
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    if (v_viewmat) hipLaunchKernelGGL(adk::viewmat_grad_finalize_kernel, dim3(1), dim3(64), 0, stream, viewmat, cam_grad, v_viewmat);
+    if (v_viewmat) hipLaunchKernelGGL(adk::viewmat_grad_finalize_kernel, dim3(1), dim3(64), 0, stream, viewmat, cam_grad, v_viewmat, pose_r6, v_r6, v_t);
     ADK_RETURN_LAST_ERROR();
 }
 
@@ -770,9 +800,9 @@ extern "C" int adk_project_bwd(int N, const float* means, const float* quats, co
                                float* v_opacities, float* v_colors, float* v_sh_rest, float* cam_grad /*[16], zeroed*/,
                                float* v_viewmat /*[16] or NULL*/, hipStream_t stream)
 {
-    return project_bwd_launch(N, means, quats, scales, colors_in, sh_rest, sh_K, sh_degree, color_mode, viewmat, Kmat, width, height,
-                              eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities,
-                              v_colors, v_sh_rest, cam_grad, v_viewmat, nullptr, stream);
+    return adk::project_bwd_launch(N, means, quats, scales, colors_in, sh_rest, sh_K, sh_degree, color_mode, viewmat, Kmat, width, height,
+                                   eps2d, near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities,
+                                   v_colors, v_sh_rest, cam_grad, v_viewmat, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // adk_project_bwd with the sparse-Adam step of the SH coefficients applied in the same pass: no v_colors / v_sh_rest
@@ -788,6 +818,18 @@ extern "C" int adk_project_bwd_adam(int N, const float* means, const float* quat
                                     float* m_dc, float* v_dc, float* m_rest, float* v_rest, const float* lr_dc,
                                     const float* lr_rest, float b1, float b2, float eps, hipStream_t stream)
 {
+    return adk::project_bwd_adam_launch(N, means, quats, scales, f_dc, f_rest, sh_K, sh_degree, viewmat, Kmat, width, height, eps2d, near_plane,
+                                        far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities, cam_grad, v_viewmat, m_dc, v_dc,
+                                        m_rest, v_rest, lr_dc, lr_rest, b1, b2, eps, nullptr, nullptr, nullptr, stream);
+}
+
+int adk::project_bwd_adam_launch(int N, const float* means, const float* quats, const float* scales, float* f_dc, float* f_rest, int sh_K,
+                                 int sh_degree, const float* viewmat, const float* Kmat, int width, int height, float eps2d, float near_plane,
+                                 float far_plane, int inv_depth, const int32_t* radii, const float* v_rec, float* v_means, float* v_quats,
+                                 float* v_scales, float* v_opacities, float* cam_grad, float* v_viewmat, float* m_dc, float* v_dc, float* m_rest,
+                                 float* v_rest, const float* lr_dc, const float* lr_rest, float b1, float b2, float eps, const float* pose_r6,
+                                 float* v_r6, float* v_t, hipStream_t stream)
+{
     if (!f_dc || !f_rest || sh_K < 2 || !m_dc || !v_dc || !m_rest || !v_rest || !lr_dc || !lr_rest) return ADK_EINVAL;
     if (sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1)) return ADK_EINVAL;
     if (sh_K > 16) return ADK_EUNSUPPORTED;
@@ -795,7 +837,7 @@ extern "C" int adk_project_bwd_adam(int N, const float* means, const float* quat
     adk::ColorAdam opt;
     opt.m_dc = m_dc; opt.v_dc = v_dc; opt.m_rest = m_rest; opt.v_rest = v_rest; opt.lr_dc = lr_dc; opt.lr_rest = lr_rest;
     opt.b1 = b1; opt.b2 = b2; opt.eps = eps;
-    return project_bwd_launch(N, means, quats, scales, f_dc, f_rest, sh_K, sh_degree, 0, viewmat, Kmat, width, height, eps2d,
-                              near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities,
-                              nullptr, nullptr, cam_grad, v_viewmat, &opt, stream);
+    return adk::project_bwd_launch(N, means, quats, scales, f_dc, f_rest, sh_K, sh_degree, 0, viewmat, Kmat, width, height, eps2d,
+                                   near_plane, far_plane, inv_depth, radii, v_rec, v_means, v_quats, v_scales, v_opacities,
+                                   nullptr, nullptr, cam_grad, v_viewmat, &opt, pose_r6, v_r6, v_t, stream);
 }
