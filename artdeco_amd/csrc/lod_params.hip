@@ -241,6 +241,12 @@ __device__ __forceinline__ void lod_adam_rows(const LodAdam& A, int64_t g, float
 #ifndef ADK_LOD_SMALL
 #define ADK_LOD_SMALL 1
 #endif
+// LATE: the next chunk's stage-0 inputs (incoming gradients, position, d_max, voxel id) are requested right after this chunk's atomics, in
+// front of dW1's 32 MFMAs -- behind the atomics in the memory counter's order, so the wait at the top of the next chunk covers both, but
+// 2 048 matrix cycles later; two of stage 0's three dependent round trips leave the critical path.
+#ifndef ADK_LOD_LATE
+#define ADK_LOD_LATE 1
+#endif
 #ifndef ADK_LOD_BWD_MINWAVES
 #define ADK_LOD_BWD_MINWAVES 3   // two-wave form: 3 waves per SIMD = 168 VGPRs, no scratch; 4 (128 VGPRs) spills 143 dwords
 #endif
@@ -308,6 +314,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     float bs1 = 0.f, bs2 = 0.f;
 
     const int n_chunks = (N + 63) / 64;
+    constexpr bool LATE = WAVES == 1 && !ADAM && ADK_LOD_LATE;
+    struct NextIn { float vo, vs0, vs1, vs2, px, py, pz, dm; float4 vq; int64_t cls; };
+    auto request = [&](int ch) -> NextIn {
+        NextIn in;
+        in.vo = in.vs0 = in.vs1 = in.vs2 = in.px = in.py = in.pz = 0.f; in.dm = 1.f; in.vq = make_float4(0.f, 0.f, 0.f, 0.f); in.cls = 0;
+        const int64_t gg = (int64_t)ch * 64 + lane;
+        if (ch < n_chunks && gg < N) {
+            in.vo = v_opac_eff[gg];
+            in.vs0 = v_scale_eff[3 * gg]; in.vs1 = v_scale_eff[3 * gg + 1]; in.vs2 = v_scale_eff[3 * gg + 2];
+            in.vq = reinterpret_cast<const float4*>(v_quat_eff)[gg];
+            in.px = xyz[3 * gg]; in.py = xyz[3 * gg + 1]; in.pz = xyz[3 * gg + 2];
+            in.dm = d_max[gg];
+            in.cls = cls_id[gg];
+        }
+        return in;
+    };
+    NextIn nxt;
+    if (LATE) nxt = request(blockIdx.x);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t g = (int64_t)chunk * 64 + lane;
         // ---- stage 0 (lane = Gaussian; wave 0): incoming gradients, LoD geometry, feature gather
@@ -321,7 +345,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         bool any_active = false;
         if (wave == 0) {
             if (ADAM) { visible = g < N && A.visible[g] != 0; TV[lane] = visible ? 1 : 0; }
-            if (g < N) {
+            int64_t cls_next = 0;
+            if (LATE) {
+                if (g < N) {
+                    vo = nxt.vo; vs[0] = nxt.vs0; vs[1] = nxt.vs1; vs[2] = nxt.vs2; vq = nxt.vq; cls_next = nxt.cls;
+                    L = lod_geometry_of(nxt.px, nxt.py, nxt.pz, nxt.dm, cc);
+                    active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
+                }
+            } else if (g < N) {
                 vo = v_opac_eff[g];
                 vs[0] = v_scale_eff[3 * g]; vs[1] = v_scale_eff[3 * g + 1]; vs[2] = v_scale_eff[3 * g + 2];
                 vq = reinterpret_cast<const float4*>(v_quat_eff)[g];
@@ -335,7 +366,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 // features straight into the X tile, one float4 at a time (holding all 32 in registers next to the weight fragments spills at 128 VGPRs)
                 int c32 = -1;
                 if (active) {
-                    const int64_t cls = cls_id[g];
+                    const int64_t cls = LATE ? cls_next : cls_id[g];
                     c32 = (int)cls;
                     const float4* gf = reinterpret_cast<const float4*>(global_feat + cls * LOD_G);
                     const float4* lf = reinterpret_cast<const float4*>(local_feat + g * LOD_L);
@@ -372,6 +403,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 }
             }
             if (WAVES == 2) __syncthreads();   // TAny / TV are rewritten by the next chunk
+            if (LATE) nxt = request(chunk + (int)gridDim.x);
             continue;
         }
         tile_sync();
@@ -587,6 +619,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 }
             }
         }
+        if (LATE) nxt = request(chunk + (int)gridDim.x);   // lands while dW1 runs
         // ---- dW1 += VZ^T X; last use of X
         const float* kx = TX + ((WAVES == 2 ? 32 * wave : 0) + kk) * LOD_LDW + rc;
 #pragma unroll 8
