@@ -50,7 +50,6 @@ class StepOut(ctypes.Structure):
     _fields_ = [("n_isects", ctypes.c_int64), ("max_tile", ctypes.c_int64), ("stage", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-_POINTER_FIELDS = frozenset(name for kind, name in _FIELDS if kind == "P")
 _checked = False
 
 
@@ -74,7 +73,6 @@ def _round_cap(n: int) -> int:
     return max(((int(n) + _GRAIN - 1) // _GRAIN) * _GRAIN, _GRAIN)
 
 
-_LEAF_KEYS = ("xyz", "opacity", "scaling", "rotation", "local_feat", "global_feat")
 _NW = 32 * 32 + 32 + 7 * 32 + 7
 STATS = {"native": 0, "fallback_layout": 0, "fallback_route": 0, "capacity_retries": 0, "plans_built": 0}
 

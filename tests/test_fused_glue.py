@@ -679,6 +679,50 @@ def test_lod_adam_inside_backward_is_bit_identical(N, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [5000, 64 * 33])
+def test_lod_backward_two_wave_form_matches_the_default(N, dev, monkeypatch):
+    """ADK_LOD_BWD_WAVES=2 (two waves share a 64-Gaussian chunk; measured 60 % slower, DESIGN finding 32, kept selectable) computes what the
+    one-wave form computes: per-Gaussian gradients from the same products (the K = 32 contractions are the same), the weight gradients
+    up to the order of their partial sums, the voxel-feature gradient up to the atomics' order."""
+    from artdeco_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + 1)
+    t = lambda x: x.to(dev).contiguous()
+    V = 200
+    xyz = t(torch.randn(N, 3, generator=g) * 0.5 + torch.tensor([0.0, 0.0, 3.0]))
+    opacity, scaling = t(torch.randn(N, 1, generator=g)), t(torch.randn(N, 3, generator=g) * 0.3 - 3.0)
+    rotation, local = t(torch.randn(N, 4, generator=g)), t(0.5 * torch.randn(N, 16, generator=g))
+    gfeat = t(0.5 * torch.randn(V, 16, generator=g))
+    cls = t(torch.randint(0, V, (N,), generator=g))
+    d_max = t(1.5 + 2.0 * torch.rand(N, 1, generator=g))
+    W1, b1 = t(0.3 * torch.randn(32, 32, generator=g)), t(0.1 * torch.randn(32, generator=g))
+    W2, b2 = t(0.3 * torch.randn(7, 32, generator=g)), t(0.1 * torch.randn(7, generator=g))
+    viewmat = torch.eye(4, device=dev)
+    v_opac, v_scale, v_quat, v_means = t(torch.randn(N, generator=g)), t(torch.randn(N, 3, generator=g)), t(torch.randn(N, 4, generator=g)), t(torch.randn(N, 3, generator=g))
+    v_opac[128:192] = 0; v_scale[128:192] = 0; v_quat[128:192] = 0          # a whole chunk without gradient: the skip path
+    st = _lib.stream_of(xyz)
+    ws = torch.empty(int(lib.adk_lod_params_bwd_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+    got = {}
+    for waves in ("1", "2"):
+        monkeypatch.setenv("ADK_LOD_BWD_WAVES", waves)
+        v_xyz = v_means.clone()
+        v_o, v_s, v_r, v_lf = torch.empty_like(opacity), torch.empty_like(scaling), torch.empty_like(rotation), torch.empty_like(local)
+        v_gf, v_mlp = torch.zeros_like(gfeat), torch.empty(1287, device=dev)
+        _lib.check(lib.adk_lod_params_bwd(N, xyz.data_ptr(), opacity.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), local.data_ptr(),
+                                          gfeat.data_ptr(), cls.data_ptr(), d_max.data_ptr(), 16, 16, 32, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(),
+                                          b2.data_ptr(), viewmat.data_ptr(), v_opac.data_ptr(), v_scale.data_ptr(), v_quat.data_ptr(), v_xyz.data_ptr(),
+                                          v_o.data_ptr(), v_s.data_ptr(), v_r.data_ptr(), v_lf.data_ptr(), v_gf.data_ptr(), v_mlp.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), st), "bwd")
+        torch.cuda.synchronize()
+        got[waves] = dict(v_xyz=v_xyz, v_o=v_o, v_s=v_s, v_r=v_r, v_lf=v_lf, v_gf=v_gf, v_mlp=v_mlp)
+    for k, x in got["1"].items():
+        y = got["2"][k]
+        assert float(x.abs().max()) > 0, k
+        rel = float((x.double() - y.double()).norm() / x.double().norm())
+        assert rel <= 2e-6, (k, rel)
+
+
+@pytest.mark.gpu
 def test_fused_step_applies_gaussian_adam_in_lod_backward(dev, monkeypatch):
     """With ARTDECO_AMD_LOD_ADAM=1 (off by default: measured slower, DESIGN finding 31) xyz / opacity / scaling / rotation / local_feat never
     materialise a .grad in the fused training step (their Adam runs inside adk_lod_params_bwd_adam), yet they, their moments and xyz's
