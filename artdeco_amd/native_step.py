@@ -77,10 +77,23 @@ _NW = 32 * 32 + 32 + 7 * 32 + 7
 STATS = {"native": 0, "fallback_layout": 0, "fallback_route": 0, "capacity_retries": 0, "plans_built": 0}
 
 
+_N_GRAIN = int(os.environ.get("ARTDECO_AMD_PLAN_GRAIN", 1 << 16))   # 1 = exact sizes (a plan per N: the lab's A/B)
+_V_GRAIN = max(_N_GRAIN >> 4, 1)
+
+
+def _round_up(n: int, grain: int) -> int:
+    return max(((int(n) + grain - 1) // grain) * grain, grain)
+
+
 class StepPlan:
-    """Buffers of one (N, V, width, height) and the argument block that points at them."""
+    """Buffers of one (width, height) for UP TO N Gaussians and V voxels, and the argument block that points at them.  The per-Gaussian /
+    per-voxel buffers are sized for the capacities (N, V rounded up to 65 536 / 4 096): a densification that adds 7 000 Gaussians to a
+    million keeps the plan -- no allocation of new sizes (each a hipMalloc, a stall of the whole stream), only new views of the same buffers
+    for the leaves' `.grad` (`set_sizes`)."""
 
     def __init__(self, lib, dev, N, V, W, H, tile_px, capacity):
+        self.n, self.v = -1, -1
+        N, V = _round_up(N, _N_GRAIN), _round_up(V, _V_GRAIN)
         self.dev, self.N, self.V, self.W, self.H, self.tile_px = dev, N, V, W, H, tile_px
         self.args = StepArgs()
         self.out = StepOut()
@@ -116,21 +129,33 @@ class StepPlan:
         A = self.args
         for name, ten in self.t.items():
             setattr(A, name, ten.data_ptr())
-        A.N, A.V, A.width, A.height, A.tile_px_w, A.tile_px_h = N, V, W, H, tpw, tph
+        A.N, A.V, A.width, A.height, A.tile_px_w, A.tile_px_h = 0, 0, W, H, tpw, tph
         A.bin_table_bytes = self.t["bin_table"].numel()
         A.lod_ws_bytes = self.t["lod_ws"].numel()
         A.photo_ws_bytes = self.t["photo_ws"].numel()
         A.n_ssim_sums = n_sums
         A.ssim_grad_scale = 0.0
         self.set_capacity(capacity)
-        # the gradients as the leaves' `.grad` (views of the plan, shaped like the leaves)
-        m = self.t["v_mlp"]
-        o2 = 32 * 32 + 32
-        self.grads = {"xyz": self.t["v_means"], "opacity": self.t["v_opacity_raw"], "scaling": self.t["v_scaling_raw"],
-                      "rotation": self.t["v_rotation"], "local_feat": self.t["v_local_feat"], "global_feat": self.t["v_global_feat"],
-                      "W1": m[:32 * 32].view(32, 32), "b1": m[32 * 32:o2], "W2": m[o2:o2 + 7 * 32].view(7, 32), "b2": m[o2 + 7 * 32:o2 + 7 * 32 + 7],
-                      "exposure": self.t["v_exposure"].view(3, 4), "r6": self.t["v_r6"], "t": self.t["v_t"]}
+        self.grads: dict[str, torch.Tensor] = {}
+        self.vis = self.gvis = None
         STATS["plans_built"] += 1
+
+    def set_sizes(self, n: int, v: int) -> None:
+        """The step's actual sizes: the kernels' N / V and the leaves' `.grad` (views of the plan's buffers, shaped like the leaves)."""
+        if n == self.n and v == self.v:
+            return
+        self.n, self.v = n, v
+        self.args.N, self.args.V = n, v
+        t = self.t
+        m = t["v_mlp"]
+        o2 = 32 * 32 + 32
+        self.grads = {"xyz": t["v_means"][:n], "opacity": t["v_opacity_raw"][:n], "scaling": t["v_scaling_raw"][:n],
+                      "rotation": t["v_rotation"][:n], "local_feat": t["v_local_feat"][:n], "global_feat": t["v_global_feat"][:v],
+                      "W1": m[:32 * 32].view(32, 32), "b1": m[32 * 32:o2], "W2": m[o2:o2 + 7 * 32].view(7, 32), "b2": m[o2 + 7 * 32:o2 + 7 * 32 + 7],
+                      "exposure": t["v_exposure"].view(3, 4), "r6": t["v_r6"], "t": t["v_t"]}
+        self.vis, self.gvis = t["vis"][:n], t["gvis"][:v]
+        if "v_dc" in t:
+            self.grads["f_dc"], self.grads["f_rest"] = t["v_dc"][:n], t["v_rest"][:n]
 
     def set_capacity(self, capacity: int) -> None:
         cap = _round_cap(capacity)
@@ -142,11 +167,12 @@ class StepPlan:
 
     def color_grads(self, f_dc, f_rest):
         """Gradient buffers of the SH colours: only a test keyframe's step needs them (no colour Adam inside the projection backward)."""
-        if "v_dc" not in self.t:
-            self.t["v_dc"] = torch.empty_like(f_dc)
-            self.t["v_rest"] = torch.empty_like(f_rest)
+        if "v_dc" not in self.t or self.t["v_rest"].shape[1:] != f_rest.shape[1:]:
+            self.t["v_dc"] = torch.empty((self.N,) + tuple(f_dc.shape[1:]), dtype=torch.float32, device=self.dev)
+            self.t["v_rest"] = torch.empty((self.N,) + tuple(f_rest.shape[1:]), dtype=torch.float32, device=self.dev)
+            self.grads["f_dc"], self.grads["f_rest"] = self.t["v_dc"][:self.n], self.t["v_rest"][:self.n]
         self.args.v_dc, self.args.v_rest = self.t["v_dc"].data_ptr(), self.t["v_rest"].data_ptr()
-        return self.t["v_dc"], self.t["v_rest"]
+        return self.grads["f_dc"], self.grads["f_rest"]
 
 
 def _ok32(t, shape=None) -> bool:
@@ -157,12 +183,13 @@ def _plan_for(scene, lib, dev, N, V, W, H, tile_px):
     plans = scene.__dict__.setdefault("_adk_step_plans", {})
     key = (W, H, tile_px)
     plan = plans.get(key)
-    if plan is None or plan.N != N or plan.V != V or plan.dev != dev:
+    if plan is None or plan.N < N or plan.V < V or plan.dev != dev:
         hint = rasterizer._CAPACITY_HINT.get((dev.index, W, H, tile_px[0]))
         cap = int(hint * 1.25) if hint else (plan.args.isect_capacity if plan is not None else 4 * N)
         skip = plan.skip_until - plan.calls if plan is not None else 0
         plan = plans[key] = StepPlan(lib, dev, N, V, W, H, tile_px, cap)
         plan.skip_until = max(skip, 0)
+    plan.set_sizes(N, V)
     return plan
 
 
@@ -301,7 +328,7 @@ def train_on_keyframe(scene, keyframe, is_important):
             r6.grad = g["r6"]
         if t.requires_grad:
             t.grad = g["t"]
-    fused._apply_steps(scene, keyframe, plan.t["vis"], plan.t["gvis"], invdepth)
+    fused._apply_steps(scene, keyframe, plan.vis, plan.gvis, invdepth)
     return loss, None
 
 
