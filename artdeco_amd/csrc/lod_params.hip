@@ -661,275 +661,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     }
 }
 
-// ---- the same backward on 32-GAUSSIAN chunks (round 4, late) ---------------------------------------------------------------------------
-// The ablation of the 64-Gaussian kernel (DESIGN finding 32) says it is bound by the number of dependent memory phases a wave walks
-// through per chunk at TWO waves per SIMD (19.5 KB of LDS and 239 VGPRs per wave allow no more).  A 32-Gaussian chunk needs half the
-// LDS (9.6 KB) and one row block of every matrix stage instead of two (dz[2] -> dz: 16 registers less, plus the second block's
-// addresses): ADK_LOD32_WAVES waves per SIMD instead of two walk their phases side by side.  Same arithmetic per Gaussian (the K = 32
-// contractions of the weight gradients see half the rows per partial row, so dW sums differ in the order of their partial sums only).
-// One wave per workgroup, no Adam inside (that form stays with the kernel above); both half-waves hold the chunk's 32 Gaussians
-// (lane & 31), the lower half gathers the voxel rows, the upper half the local rows.
-#ifndef ADK_LOD32_WAVES
-#define ADK_LOD32_WAVES 3
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ADK_LOD32_WAVES, ADK_LOD32_WAVES))) void lod_params_bwd32_kernel(
-    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
-    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
-    const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
-    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
-    const float* __restrict__ viewmat, const float* __restrict__ v_opac_eff, const float* __restrict__ v_scale_eff,
-    const float* __restrict__ v_quat_eff, float* __restrict__ v_xyz_add, float* __restrict__ v_opacity_raw,
-    float* __restrict__ v_scaling_raw, float* __restrict__ v_rotation, float* __restrict__ v_local_feat,
-    float* __restrict__ v_global_feat, float* __restrict__ partials)
-{
-    constexpr int CH = 32;
-    __shared__ float TX[CH * LOD_LDW], TH[CH * LOD_LDW], TY[CH * LOD_YW];
-    __shared__ int TC[CH];
-    float* const TZ = TH;
-    const int lane = threadIdx.x & 63, kk = lane >> 5, rc = lane & 31, c16 = lane & 15, q16 = lane >> 4;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-    float w1t[16], w1n[16], w2n[4], w2y[8];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        w1t[s] = W1[rc * LOD_IN + 2 * s + kk];
-        w1n[s] = W1[(2 * s + kk) * LOD_IN + rc];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int o = 2 * s + kk;
-        w2n[s] = o < LOD_OUT ? W2[o * LOD_HID + rc] : 0.f;
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) w2y[s] = c16 < LOD_OUT ? W2[c16 * LOD_HID + 4 * s + q16] : 0.f;
-    const float bias1 = b1[rc], bias2y = c16 < LOD_OUT ? b2[c16] : 0.f;
-    f32x4 acc2a = {0.f, 0.f, 0.f, 0.f}, acc2b = {0.f, 0.f, 0.f, 0.f};
-    f32x16 acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-    float bs1 = 0.f, bs2 = 0.f;
-    const CamCentre cc = cam_centre_of(viewmat);
-
-    const int n_chunks = (N + CH - 1) / CH;
-    struct NextIn { float vo, vs0, vs1, vs2, px, py, pz, dm; float4 vq; int64_t cls; };
-    auto request = [&](int ch) -> NextIn {   // both half-waves read the same 32 Gaussians (one request per address pair)
-        NextIn in;
-        in.vo = in.vs0 = in.vs1 = in.vs2 = in.px = in.py = in.pz = 0.f; in.dm = 1.f; in.vq = make_float4(0.f, 0.f, 0.f, 0.f); in.cls = 0;
-        const int64_t gg = (int64_t)ch * CH + rc;
-        if (ch < n_chunks && gg < N) {
-            in.vo = v_opac_eff[gg];
-            in.vs0 = v_scale_eff[3 * gg]; in.vs1 = v_scale_eff[3 * gg + 1]; in.vs2 = v_scale_eff[3 * gg + 2];
-            in.vq = reinterpret_cast<const float4*>(v_quat_eff)[gg];
-            in.px = xyz[3 * gg]; in.py = xyz[3 * gg + 1]; in.pz = xyz[3 * gg + 2];
-            in.dm = d_max[gg];
-            in.cls = cls_id[gg];
-        }
-        return in;
-    };
-    NextIn nxt = request(blockIdx.x);
-    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t g = (int64_t)chunk * CH + rc;
-        // ---- stage 0 (lane & 31 = Gaussian, in both half-waves)
-        bool active = false;
-        float vo = 0.f, vs[3] = {0.f, 0.f, 0.f};
-        float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
-        LodGeom L;
-        L.alpha_ratio = 1.f; L.inv_dmax = 0.f; L.fading = false; L.selected = false; L.dist = 0.f;
-        L.dir[0] = L.dir[1] = L.dir[2] = 0.f;
-        int64_t cls = 0;
-        if (g < N) {
-            vo = nxt.vo; vs[0] = nxt.vs0; vs[1] = nxt.vs1; vs[2] = nxt.vs2; vq = nxt.vq; cls = nxt.cls;
-            L = lod_geometry_of(nxt.px, nxt.py, nxt.pz, nxt.dm, cc);
-            active = L.selected && (vo != 0.f || vs[0] != 0.f || vs[1] != 0.f || vs[2] != 0.f || vq.x != 0.f || vq.y != 0.f || vq.z != 0.f || vq.w != 0.f);
-        }
-        const bool any_active = __ballot(active) != 0ull;
-        if (!any_active) {
-            if (kk == 0 && g < N) {
-                v_opacity_raw[g] = 0.f;
-                v_scaling_raw[3 * g] = 0.f; v_scaling_raw[3 * g + 1] = 0.f; v_scaling_raw[3 * g + 2] = 0.f;
-                reinterpret_cast<float4*>(v_rotation)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (g < N) {   // 8 of the 16 local-feature gradients per half-wave
-                float4* vl = reinterpret_cast<float4*>(v_local_feat + g * LOD_L) + 2 * kk;
-                vl[0] = make_float4(0.f, 0.f, 0.f, 0.f); vl[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            nxt = request(chunk + (int)gridDim.x);
-            continue;
-        }
-        {   // features straight into the X tile: the lower half-wave gathers the voxel row (columns 0..15), the upper one the local row
-            float* t = TX + rc * LOD_LDW + 16 * kk;
-            if (active) {
-                const float4* src = kk == 0 ? reinterpret_cast<const float4*>(global_feat + cls * LOD_G)
-                                            : reinterpret_cast<const float4*>(local_feat + g * LOD_L);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 v = src[i];
-                    t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t[i] = 0.f;
-            }
-            if (kk == 0) TC[rc] = active ? (int)cls : -1;
-        }
-        lds_fence();
-
-        // ---- H = relu(X W1^T + b1); only the sign mask stays in registers
-        unsigned hmask = 0u;
-        {
-            const float* xa = TX + rc * LOD_LDW + kk;
-            float* hw = TH + (4 * kk) * LOD_LDW + rc;
-            f32x16 d;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * s], w1t[s], d, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float h = fmaxf(d[r] + bias1, 0.f);
-                hw[((r & 3) + 8 * (r >> 2)) * LOD_LDW] = h;
-                hmask |= (h > 0.f ? 1u : 0u) << r;
-            }
-        }
-        lds_fence();
-        // ---- Y = H W2^T + b2 on the 16x16x4 MFMA (two blocks of 16 Gaussians)
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-            const float* ha = TH + (16 * ib + c16) * LOD_LDW + q16;
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[4 * s], w2y[s], d, 0, 0, 0);
-            if (c16 < 8) {
-                float* yw = TY + (16 * ib + 4 * q16) * LOD_YW + c16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yw[r * LOD_YW] = d[r] + bias2y;
-            }
-        }
-        lds_fence();
-        // ---- element-wise stage (lower half-wave: lane = Gaussian)
-        if (kk == 0) {
-            float y[LOD_OUT], vy[LOD_OUT];
-#pragma unroll
-            for (int o = 0; o < LOD_OUT; ++o) { y[o] = TY[rc * LOD_YW + o]; vy[o] = 0.f; }
-            float go = 0.f, gs[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f};
-            float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active) {
-                const float so = sigmoidf(opacity_raw[g]);
-                go = vo * L.alpha_ratio * so * (1.f - so);
-                if (L.fading) {
-                    const float c = -vo * so * L.inv_dmax;
-                    gx[0] = c * L.dir[0]; gx[1] = c * L.dir[1]; gx[2] = c * L.dir[2];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float sraw = scaling_raw[3 * g + k];
-                    const float e = __expf(sraw), sy = sigmoidf(y[k]);
-                    gs[k] = vs[k] * e * sy;
-                    vy[k] = vs[k] * e * sy * (1.f - sy);
-                }
-                const float4 q = reinterpret_cast<const float4*>(rotation)[g];
-                gq = make_float4(vq.x * y[3], vq.y * y[4], vq.z * y[5], vq.w * y[6]);
-                vy[3] = vq.x * q.x; vy[4] = vq.y * q.y; vy[5] = vq.z * q.z; vy[6] = vq.w * q.w;
-            }
-            if (g < N) {
-                v_opacity_raw[g] = go;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    v_scaling_raw[3 * g + k] = gs[k];
-                    if (gx[k] != 0.f) v_xyz_add[3 * g + k] += gx[k];
-                }
-                reinterpret_cast<float4*>(v_rotation)[g] = gq;
-            }
-#pragma unroll
-            for (int o = 0; o < LOD_OUT; ++o) TY[rc * LOD_YW + o] = vy[o];
-            TY[rc * LOD_YW + 7] = 0.f;
-        }
-        lds_fence();
-        // ---- dW2 += VY^T H (K = the chunk's 32 Gaussians); last use of H
-        {
-            const float* ky16 = TY + q16 * LOD_YW + c16;
-            const float* kh16 = TH + q16 * LOD_LDW + c16;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float a = c16 < 8 ? ky16[4 * s * LOD_YW] : 0.f;
-                acc2a = __builtin_amdgcn_mfma_f32_16x16x4f32(a, kh16[4 * s * LOD_LDW], acc2a, 0, 0, 0);
-                acc2b = __builtin_amdgcn_mfma_f32_16x16x4f32(a, kh16[4 * s * LOD_LDW + 16], acc2b, 0, 0, 0);
-                bs2 += a;
-            }
-        }
-        // ---- VZ = (VY W2) * (H > 0), written over H
-        {
-            f32x16 dz;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dz[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) dz = __builtin_amdgcn_mfma_f32_32x32x2f32(TY[rc * LOD_YW + kk + 2 * s], w2n[s], dz, 0, 0, 0);
-            lds_fence();   // every read of H (dW2) has completed
-#pragma unroll
-            for (int r = 0; r < 16; ++r) TZ[(4 * kk + (r & 3) + 8 * (r >> 2)) * LOD_LDW + rc] = ((hmask >> r) & 1u) ? dz[r] : 0.f;
-        }
-        lds_fence();
-        // ---- VX = VZ W1, stored from the accumulator layout; its stores / atomics in front of dW1 (see the kernel above)
-        {
-            f32x16 d;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(TZ[rc * LOD_LDW + kk + 2 * s], w1n[s], d, 0, 0, 0);
-            if (rc >= LOD_G) {
-                float* lbase = v_local_feat + ((int64_t)chunk * CH + 4 * kk) * LOD_L + (rc - LOD_G);
-                if ((int64_t)chunk * CH + CH <= N) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) lbase[((r & 3) + 8 * (r >> 2)) * LOD_L] = d[r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row0 = (r & 3) + 8 * (r >> 2);
-                        if ((int64_t)chunk * CH + row0 + 4 * kk < N) lbase[row0 * LOD_L] = d[r];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = TC[4 * kk + (r & 3) + 8 * (r >> 2)];
-                    if (c >= 0 && d[r] != 0.f) unsafeAtomicAdd(v_global_feat + (int64_t)c * LOD_G + rc, d[r]);
-                }
-            }
-        }
-        nxt = request(chunk + (int)gridDim.x);   // lands while dW1 runs
-        // ---- dW1 += VZ^T X; last use of X
-        {
-            const float* kx = TX + kk * LOD_LDW + rc;
-            const float* kh = TH + kk * LOD_LDW + rc;
-#pragma unroll 8
-            for (int si = 0; si < 16; ++si) {
-                const float a = kh[2 * si * LOD_LDW];
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kx[2 * si * LOD_LDW], acc1, 0, 0, 0);
-                bs1 += a;
-            }
-        }
-        lds_fence(); // tiles are rewritten by the next chunk
-    }
-
-    // ---- one partial row per workgroup: dW1 | db1 | dW2 | db2
-    float* out = partials + (size_t)blockIdx.x * LOD_NW;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * kk) * LOD_IN + rc] = acc1[r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * q16 + r;
-        if (o < LOD_OUT) {
-            out[LOD_HID * LOD_IN + LOD_HID + o * LOD_HID + c16] = acc2a[r];
-            out[LOD_HID * LOD_IN + LOD_HID + o * LOD_HID + 16 + c16] = acc2b[r];
-        }
-    }
-    const float o1 = __shfl(bs1, (lane + 32) & 63);
-    if (lane < 32) out[LOD_HID * LOD_IN + lane] = bs1 + o1;
-    float t2 = bs2 + __shfl(bs2, (lane + 32) & 63);
-    t2 += __shfl(t2, (lane + 16) & 63);
-    if (lane < LOD_OUT) out[LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + lane] = t2;
-}
-
 // v_w[i] = sum_b partials[b][i]; 32 row-slices per column summed in a fixed order => deterministic
 #define LOD_RED_PARTS 32
 __global__ __launch_bounds__(1024) void lod_reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
@@ -1019,9 +750,6 @@ extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_
     ADK_RETURN_LAST_ERROR();
 }
 
-#ifndef ADK_LOD_BWD_CHUNK_DEFAULT
-#define ADK_LOD_BWD_CHUNK_DEFAULT 64
-#endif
 #define LOD_BWD_MAX_BLOCKS 2048 // 8 resident single-wave workgroups (19.2 KB LDS each) per CU x 256 CUs
 extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)
 {
@@ -1056,25 +784,12 @@ extern "C" int adk_lod_params_bwd(int N, const float* xyz, const float* opacity_
     const int waves = (we && we[0] == '2') ? 2 : 1;   // default: one wave per chunk (the two-wave form measured 60 % slower, profiles/r04_ab_lod_waves.txt)
 #define ADK_LOD_ARGS N, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff, \
                      v_quat_eff, v_xyz_add, v_opacity_raw, v_scaling_raw, v_rotation, v_local_feat, v_global_feat, (float*)workspace, none
-    // ADK_LOD_BWD_CHUNK = 32 | 64: Gaussians per chunk (read per launch); 32 = lod_params_bwd32_kernel, ADK_LOD32_WAVES waves per SIMD
-    const char* ce = getenv("ADK_LOD_BWD_CHUNK");
-    const int chunk_rows = ce ? atoi(ce) : ADK_LOD_BWD_CHUNK_DEFAULT;
-    int rows = nb * waves;
-    if (chunk_rows == 32 && waves == 1) {
-        int nb32 = (int)adk::ceil_div(N, 32);
-        const int cap = 256 * 4 * ADK_LOD32_WAVES;   // every SIMD of the chip holds ADK_LOD32_WAVES one-wave workgroups
-        if (nb32 > cap) nb32 = cap;
-        if (nb32 > 2 * LOD_BWD_MAX_BLOCKS) nb32 = 2 * LOD_BWD_MAX_BLOCKS;   // the workspace's partial rows
-        rows = nb32;
-        hipLaunchKernelGGL(adk::lod_params_bwd32_kernel, dim3(nb32), dim3(64), 0, stream, N, xyz, opacity_raw, scaling_raw, rotation, local_feat,
-                           global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat, v_opac_eff, v_scale_eff, v_quat_eff, v_xyz_add, v_opacity_raw,
-                           v_scaling_raw, v_rotation, v_local_feat, v_global_feat, (float*)workspace);
-    } else if (waves == 2) hipLaunchKernelGGL((adk::lod_params_bwd_kernel<false, 2>), dim3(nb), dim3(128), 0, stream, ADK_LOD_ARGS);
+    if (waves == 2) hipLaunchKernelGGL((adk::lod_params_bwd_kernel<false, 2>), dim3(nb), dim3(128), 0, stream, ADK_LOD_ARGS);
     else hipLaunchKernelGGL((adk::lod_params_bwd_kernel<false, 1>), dim3(nb), dim3(64), 0, stream, ADK_LOD_ARGS);
 #undef ADK_LOD_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, rows, v_mlp);
+    hipLaunchKernelGGL(adk::lod_reduce_partials_kernel, dim3((LOD_NW + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, nb * waves, v_mlp);
     ADK_RETURN_LAST_ERROR();
 }
 

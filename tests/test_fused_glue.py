@@ -681,8 +681,8 @@ def test_lod_adam_inside_backward_is_bit_identical(N, dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [5000, 64 * 33, 32 * 41 + 7])
 def test_lod_backward_forms_match_the_default(N, dev, monkeypatch):
-    """ADK_LOD_BWD_WAVES=2 (two waves share a 64-Gaussian chunk; measured 60 % slower, DESIGN finding 32, kept selectable) and
-    ADK_LOD_BWD_CHUNK=32 (32-Gaussian chunks, three waves per SIMD) compute what the one-wave 64-Gaussian form computes: per-Gaussian gradients from the same products (the K = 32 contractions are the same), the weight gradients
+    """ADK_LOD_BWD_WAVES=2 (two waves share a 64-Gaussian chunk; measured 60 % slower, DESIGN finding 32, kept selectable) computes what the
+    one-wave form computes: per-Gaussian gradients from the same products (the K = 32 contractions are the same), the weight gradients
     up to the order of their partial sums, the voxel-feature gradient up to the atomics' order."""
     from artdeco_amd import _lib
     lib = _lib.load()
@@ -703,9 +703,8 @@ def test_lod_backward_forms_match_the_default(N, dev, monkeypatch):
     st = _lib.stream_of(xyz)
     ws = torch.empty(int(lib.adk_lod_params_bwd_workspace_bytes(N)), dtype=torch.uint8, device=dev)
     got = {}
-    for waves, rows in (("1", "64"), ("2", "64"), ("1", "32")):
+    for waves, rows in (("1", "64"), ("2", "64")):
         monkeypatch.setenv("ADK_LOD_BWD_WAVES", waves)
-        monkeypatch.setenv("ADK_LOD_BWD_CHUNK", rows)
         v_xyz = v_means.clone()
         v_o, v_s, v_r, v_lf = torch.empty_like(opacity), torch.empty_like(scaling), torch.empty_like(rotation), torch.empty_like(local)
         v_gf, v_mlp = torch.zeros_like(gfeat), torch.empty(1287, device=dev)
@@ -717,7 +716,7 @@ def test_lod_backward_forms_match_the_default(N, dev, monkeypatch):
         torch.cuda.synchronize()
         got[(waves, rows)] = dict(v_xyz=v_xyz, v_o=v_o, v_s=v_s, v_r=v_r, v_lf=v_lf, v_gf=v_gf, v_mlp=v_mlp)
     ref = got[("1", "64")]
-    for form in (("2", "64"), ("1", "32")):
+    for form in (("2", "64"),):
         for k, x in ref.items():
             y = got[form][k]
             assert float(x.abs().max()) > 0, k
