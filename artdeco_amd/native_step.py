@@ -220,6 +220,9 @@ def train_on_keyframe(scene, keyframe, is_important):
     cls_id, d_max = P["cls_id"]["val"], P["d_max"]["val"]
     sh_K = 1 + int(f_rest.shape[1]) if f_rest.dim() == 3 else 0
     deg = int(scene.active_sh_degree)
+    # a test keyframe's optimiser holds no exposure entry (keyframe.py:119-123): its zero_grad leaves exposure.grad alone and autograd keeps
+    # accumulating into it; only a parameter the keyframe steps must arrive with an empty .grad
+    e_stepped = any(pd.get("val") is E for pd in getattr(getattr(keyframe, "optimizer", None), "params", {}).values())
     layout_ok = (_ok32(xyz, (N, 3)) and _ok32(leaves[1], (N, 1)) and _ok32(leaves[2], (N, 3)) and _ok32(leaves[3], (N, 4))
                  and _ok32(leaves[4], (N, 16)) and _ok32(leaves[5], (V, 16)) and _ok32(leaves[6], (32, 32)) and _ok32(leaves[7], (32,))
                  and _ok32(leaves[8], (7, 32)) and _ok32(leaves[9], (7,)) and _ok32(f_dc, (N, 1, 3)) and _ok32(f_rest, (N, sh_K - 1, 3))
@@ -230,7 +233,7 @@ def train_on_keyframe(scene, keyframe, is_important):
                  # the next add_and_prune, h3dgsv3.py:964-965: their `.grad` then stays None, as the reference's would)
                  and all(x.requires_grad for x in leaves[1:3] + leaves[4:]) and f_dc.requires_grad and f_rest.requires_grad
                  and all(x.grad is None for x in leaves) and f_dc.grad is None and f_rest.grad is None
-                 and r6.grad is None and t.grad is None and E.grad is None)
+                 and r6.grad is None and t.grad is None and (E.grad is None or not e_stepped))
     if not layout_ok:
         STATS["fallback_layout"] += 1
         return None, None
@@ -322,7 +325,12 @@ def train_on_keyframe(scene, keyframe, is_important):
     if not cs:
         f_dc.grad, f_rest.grad = v_dc, v_rest
     if E.requires_grad:
-        E.grad = g["exposure"]
+        if e_stepped:
+            E.grad = g["exposure"]
+        elif E.grad is None:
+            E.grad = g["exposure"].clone()     # never the plan's buffer: this one is accumulated into, step after step
+        else:
+            E.grad.add_(g["exposure"])
     if pose_grad:
         if r6.requires_grad:
             r6.grad = g["r6"]

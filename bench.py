@@ -222,11 +222,15 @@ def main():
     # microseconds of stream bubble, so the full per-stage breakdown is taken in a second, untimed pass
     timer = rasterizer.StageTimer(only=("raster_bwd",))
     rasterizer.set_stage_timer(timer)
+    from artdeco_amd import native_step
     sync_all()
+    native_before = dict(native_step.STATS)
     t0 = time.perf_counter()
     timed = stream.run_stream(scene, frames[args.warmup:args.warmup + args.steps], start_index=args.warmup, **cadence)
     sync_all()
     elapsed = time.perf_counter() - t0
+    native_stats_timed = {k: native_step.STATS[k] - native_before[k] for k in native_before}
+    native_stats_timed["one_call_step_enabled"] = native_step.enabled() and not args.unfused_glue
     stages_timed = timer.summary_ms()
     rasterizer.set_stage_timer(None)
     frame_stages, stages = {}, {}
@@ -283,7 +287,10 @@ def main():
                        "new_gaussians_per_densified_frame": timed["gaussians_added"] / max(timed["densified_frames"], 1),
                        "gaussians_pruned_in_timed_region": int(timed["gaussians_start"] + timed["gaussians_added"] - timed["gaussians_end"]),
                        "intersections_I": I, "visible_V": V, "pixels_P": P, "gaussians_N": N_end,
-                       "render_glue": glue, "parallelism": f"scene-per-gpu x{world}"},
+                       "render_glue": glue, "parallelism": f"scene-per-gpu x{world}",
+                       # how the optimisation steps of the timed region were issued: adk_mapper_step (forward + loss + backward as ONE native call,
+                       # DESIGN finding 36) vs steps handed back to the per-stage chain (another layout / a frame that needs the global binning route)
+                       "optimisation_step_host_path": dict(native_stats_timed)},
             "ms_per_optimisation_step_incl_frame_overheads": elapsed_max / max(timed["steps"], 1) * 1e3,
             "raster_fwd_ms": stages.get("raster_fwd", {}).get("mean_ms"), "raster_bwd_ms": bwd_ms,
             "frame_stage_ms": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in frame_stages.items()},

@@ -197,6 +197,14 @@ def test_native_step_on_a_test_keyframe_leaves_the_map_alone(dev, monkeypatch):
     for k in ("f_dc", "f_rest"):
         g = sc.gaussian_params[k]["val"].grad
         assert g is not None and g.shape == sc.gaussian_params[k]["val"].shape and float(g.abs().max()) > 0
+    # the keyframe's optimiser has no exposure entry, so nothing clears exposure.grad: the next step on this keyframe must still be native,
+    # and the gradient accumulates as autograd's would (never into the plan's own buffer)
+    g1 = kf.exposure.grad.clone()
+    plan = next(iter(sc.__dict__["_adk_step_plans"].values()))
+    assert kf.exposure.grad.data_ptr() != plan.t["v_exposure"].data_ptr()
+    sc.optimization_step(1, is_important=True)
+    assert native_step.STATS["native"] == n0 + 2
+    assert torch.allclose(kf.exposure.grad, g1 + plan.grads["exposure"], rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.gpu
