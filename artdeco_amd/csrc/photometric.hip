@@ -24,6 +24,9 @@ namespace adk {
 #define PHOTO_THREADS 256
 #define PHOTO_MAX_BLOCKS 2048
 #define PHOTO_SSIM_BLOCKS 1024
+#ifndef ADK_PHOTO_V4
+#define ADK_PHOTO_V4 1
+#endif
 
 struct Exposure { float e[12]; };
 
@@ -129,6 +132,34 @@ __global__ __launch_bounds__(256) void photometric_loss_kernel(const float* __re
     }
 }
 
+// One pixel of the backward chain: gradients of the rasteriser's colour / depth / alpha at this pixel, and the pixel's 12 exposure terms.
+__device__ __forceinline__ void photo_pixel_bwd(const float4 col, float alpha, const float* b, const Exposure& X, const float g[3], float w, float mo,
+                                                bool mask_outliers, const float vs[3], float vl, float l1_coeff, float depth_coeff,
+                                                float4& v_col, float& v_alpha, float (&acc)[12])
+{
+    const PixFwd px = photo_pixel(col, alpha, b, X, g, w, mask_outliers);
+    float vu[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float ve = (l1_coeff * w * sgnf(px.e[i] * px.m - g[i] * px.m) + vs[i]) * vl * px.m;
+        vu[i] = (px.u[i] >= 0.f && px.u[i] <= 1.f) ? ve : 0.f; // clamp passes the gradient on [0,1]
+    }
+    float vc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vc[j] = X.e[j] * vu[0] + X.e[4 + j] * vu[1] + X.e[8 + j] * vu[2];
+    const float vinvd = depth_coeff * w * sgnf(px.invd * px.m - mo * px.m) * vl * px.m;
+    v_col = make_float4(vc[0], vc[1], vc[2], -vinvd * px.invd * px.invd);
+    v_alpha = -(vc[0] * b[0] + vc[1] * b[1] + vc[2] * b[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        acc[4 * i] += vu[i] * px.c[0]; acc[4 * i + 1] += vu[i] * px.c[1]; acc[4 * i + 2] += vu[i] * px.c[2]; acc[4 * i + 3] += vu[i];
+    }
+}
+
+// V4 (round 4): a thread takes FOUR consecutive pixels -- every planar input (gt x 3, rdk, mono, alphas, the SSIM gradient x 3) and the
+// alpha gradient move as one 16 B access per lane instead of four 4 B ones (1 KB instead of 256 B per wave instruction); needs P % 4 == 0
+// and 16 B-aligned planes, else the one-pixel form runs.  Same arithmetic per pixel; the 12 exposure sums add their pixels in another order.
+template <bool V4>
 __global__ __launch_bounds__(PHOTO_THREADS) void photometric_bwd_kernel(
     int64_t P, const float4* __restrict__ colors4, const float* __restrict__ alphas, const float* __restrict__ bg,
     const float* __restrict__ E, const float* __restrict__ gt, const float* __restrict__ mono, const float* __restrict__ rdk,
@@ -143,27 +174,38 @@ __global__ __launch_bounds__(PHOTO_THREADS) void photometric_bwd_kernel(
     for (int i = 0; i < 12; ++i) { X.e[i] = E[i]; acc[i] = 0.f; }
     const float b[3] = {bg[0], bg[1], bg[2]};
     const float vl = v_loss[0];
+    const bool mo_flag = mask_outliers != 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
-        const float g[3] = {gt[p], gt[P + p], gt[2 * P + p]};
-        const float w = rdk[p], mo = mono[p];
-        const float4 col = colors4[p];
-        const PixFwd px = photo_pixel(col, alphas[p], b, X, g, w, mask_outliers != 0);
-        float vu[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float ve = (l1_coeff * w * sgnf(px.e[i] * px.m - g[i] * px.m) + v_image_ssim[i * P + p]) * vl * px.m;
-            vu[i] = (px.u[i] >= 0.f && px.u[i] <= 1.f) ? ve : 0.f; // clamp passes the gradient on [0,1]
+    if (V4) {
+        const int64_t Q = P >> 2;
+        const float4* gt4 = reinterpret_cast<const float4*>(gt);
+        const float4* vs4 = reinterpret_cast<const float4*>(v_image_ssim);
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += stride) {
+            const float4 g0 = gt4[q], g1 = gt4[Q + q], g2 = gt4[2 * Q + q];
+            const float4 s0 = vs4[q], s1 = vs4[Q + q], s2 = vs4[2 * Q + q];
+            const float4 w4 = reinterpret_cast<const float4*>(rdk)[q], m4 = reinterpret_cast<const float4*>(mono)[q];
+            const float4 a4 = reinterpret_cast<const float4*>(alphas)[q];
+            const float4 c0 = colors4[4 * q], c1 = colors4[4 * q + 1], c2 = colors4[4 * q + 2], c3 = colors4[4 * q + 3];
+            float4 vc0, vc1, vc2, vc3, va;
+            { const float g[3] = {g0.x, g1.x, g2.x}, vs[3] = {s0.x, s1.x, s2.x};
+              photo_pixel_bwd(c0, a4.x, b, X, g, w4.x, m4.x, mo_flag, vs, vl, l1_coeff, depth_coeff, vc0, va.x, acc); }
+            { const float g[3] = {g0.y, g1.y, g2.y}, vs[3] = {s0.y, s1.y, s2.y};
+              photo_pixel_bwd(c1, a4.y, b, X, g, w4.y, m4.y, mo_flag, vs, vl, l1_coeff, depth_coeff, vc1, va.y, acc); }
+            { const float g[3] = {g0.z, g1.z, g2.z}, vs[3] = {s0.z, s1.z, s2.z};
+              photo_pixel_bwd(c2, a4.z, b, X, g, w4.z, m4.z, mo_flag, vs, vl, l1_coeff, depth_coeff, vc2, va.z, acc); }
+            { const float g[3] = {g0.w, g1.w, g2.w}, vs[3] = {s0.w, s1.w, s2.w};
+              photo_pixel_bwd(c3, a4.w, b, X, g, w4.w, m4.w, mo_flag, vs, vl, l1_coeff, depth_coeff, vc3, va.w, acc); }
+            v_colors4[4 * q] = vc0; v_colors4[4 * q + 1] = vc1; v_colors4[4 * q + 2] = vc2; v_colors4[4 * q + 3] = vc3;
+            reinterpret_cast<float4*>(v_alphas)[q] = va;
         }
-        float vc[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) vc[j] = X.e[j] * vu[0] + X.e[4 + j] * vu[1] + X.e[8 + j] * vu[2];
-        const float vinvd = depth_coeff * w * sgnf(px.invd * px.m - mo * px.m) * vl * px.m;
-        v_colors4[p] = make_float4(vc[0], vc[1], vc[2], -vinvd * px.invd * px.invd);
-        v_alphas[p] = -(vc[0] * b[0] + vc[1] * b[1] + vc[2] * b[2]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            acc[4 * i] += vu[i] * px.c[0]; acc[4 * i + 1] += vu[i] * px.c[1]; acc[4 * i + 2] += vu[i] * px.c[2]; acc[4 * i + 3] += vu[i];
+    } else {
+        for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+            const float g[3] = {gt[p], gt[P + p], gt[2 * P + p]};
+            const float vs[3] = {v_image_ssim[p], v_image_ssim[P + p], v_image_ssim[2 * P + p]};
+            float4 vc; float va;
+            photo_pixel_bwd(colors4[p], alphas[p], b, X, g, rdk[p], mono[p], mo_flag, vs, vl, l1_coeff, depth_coeff, vc, va, acc);
+            v_colors4[p] = vc;
+            v_alphas[p] = va;
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -318,9 +360,19 @@ extern "C" int adk_photometric_bwd(int W, int H, const float* colors4, const flo
     if (P == 0) return 0;
     if (!colors4 || !alphas || !bg || !exposure || !gt_image || !mono_idepth || !rdk || !v_image_ssim || !v_loss || !v_colors4 || !v_alphas) return ADK_EINVAL;
     if (((uintptr_t)colors4 | (uintptr_t)v_colors4) & 15) return ADK_EINVAL;
-    hipLaunchKernelGGL(adk::photometric_bwd_kernel, dim3(photo_grid(P)), dim3(PHOTO_THREADS), 0, stream, P, (const float4*)colors4,
-                       alphas, bg, exposure, gt_image, mono_idepth, rdk, mask_outliers, v_image_ssim, v_loss,
-                       (1.f - lambda_dssim) / (float)(3 * P), depth_weight / (float)P, (float4*)v_colors4, v_alphas, v_exposure);
+    const bool v4 = ADK_PHOTO_V4 && (P & 3) == 0 &&
+                    ((((uintptr_t)alphas | (uintptr_t)gt_image | (uintptr_t)mono_idepth | (uintptr_t)rdk | (uintptr_t)v_image_ssim | (uintptr_t)v_alphas) & 15) == 0);
+    const float l1c = (1.f - lambda_dssim) / (float)(3 * P), dc = depth_weight / (float)P;
+    if (v4) {
+        // four pixels per thread; half as many workgroups as the one-pixel form would get (each ends in 12 same-address atomics)
+        int64_t nb = adk::ceil_div(P >> 2, (int64_t)PHOTO_THREADS);
+        nb = nb > PHOTO_MAX_BLOCKS / 2 ? PHOTO_MAX_BLOCKS / 2 : (nb < 1 ? 1 : nb);
+        hipLaunchKernelGGL(adk::photometric_bwd_kernel<true>, dim3((unsigned)nb), dim3(PHOTO_THREADS), 0, stream, P, (const float4*)colors4, alphas, bg,
+                           exposure, gt_image, mono_idepth, rdk, mask_outliers, v_image_ssim, v_loss, l1c, dc, (float4*)v_colors4, v_alphas, v_exposure);
+    } else {
+        hipLaunchKernelGGL(adk::photometric_bwd_kernel<false>, dim3(photo_grid(P)), dim3(PHOTO_THREADS), 0, stream, P, (const float4*)colors4, alphas, bg,
+                           exposure, gt_image, mono_idepth, rdk, mask_outliers, v_image_ssim, v_loss, l1c, dc, (float4*)v_colors4, v_alphas, v_exposure);
+    }
     ADK_RETURN_LAST_ERROR();
 }
 
