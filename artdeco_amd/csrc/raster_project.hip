@@ -386,8 +386,11 @@ __device__ __forceinline__ void color_adam_elem(float* __restrict__ p_ptr, float
 // where (s_x, s_y) = sum over pixels of v_sigma * (mean2d - pixel): the raster backward leaves the multiplication by the
 // conic, v_mean2d = conic (s_x, s_y)^T, to this kernel (once per Gaussian instead of once per (splat, pixel)).
 // cam_grad[16]: v_R (9, row-major) | v_t (3) | v_campos (3) | pad, accumulated with atomics.
+#ifndef ADK_PROJECT_BWD_WAVES
+#define ADK_PROJECT_BWD_WAVES 4
+#endif
 template <int SH_DEG, bool FUSE_ADAM>
-__global__ __launch_bounds__(256) void project_bwd_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ADK_PROJECT_BWD_WAVES, 8))) void project_bwd_kernel(
     int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* colors_in, const float* sh_rest, int sh_K, int color_mode,
     const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height,
