@@ -231,6 +231,7 @@ def main():
     elapsed = time.perf_counter() - t0
     native_stats_timed = {k: native_step.STATS[k] - native_before[k] for k in native_before}
     native_stats_timed["one_call_step_enabled"] = native_step.enabled() and not args.unfused_glue
+    native_stats_timed["rank"] = rank   # this rank's own steps (every rank runs its own scene)
     stages_timed = timer.summary_ms()
     rasterizer.set_stage_timer(None)
     frame_stages, stages = {}, {}
