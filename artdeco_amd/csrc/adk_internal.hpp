@@ -15,6 +15,16 @@ int project_fwd_launch(int N, const float* means, const float* quats, const floa
                        float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth, float* rec, int32_t* radii,
                        uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, const ProjectMasks* masks, hipStream_t stream);
 
+// adk_lod_params_fwd + adk_project_fwd (SH colours in ARTDECO's split f_dc / f_rest layout, gsplat's "RGB+D") as ONE kernel: the activated
+// parameters (opac_eff, scale_eff, quat_eff, selected) are written for the backward but not re-read by the projection.
+int lod_project_fwd_launch(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw, const float* rotation,
+                           const float* local_feat, const float* global_feat, const int64_t* cls_id, const float* d_max, const float* W1,
+                           const float* b1, const float* W2, const float* b2, float* opac_eff, float* scale_eff, float* quat_eff,
+                           uint8_t* selected, const float* f_dc, const float* f_rest, int sh_K, int sh_degree, const float* viewmat,
+                           const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                           float* rec, int32_t* radii, uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss,
+                           const ProjectMasks* masks, hipStream_t stream);
+
 // adk_pose6d_fwd + zero fill of up to two byte spans in the same launch.
 int pose6d_fwd_clear(const float* r6, const float* t, float* Rt, void* a, int64_t na, void* b, int64_t nb, hipStream_t stream);
 

@@ -23,35 +23,9 @@
 //     the forward) are scattered with hardware fp32 atomics.
 //   * Only Gaussians that received a gradient (visible ones) do any backward work.
 #include "adk_common.hpp"
+#include "lod_core.hpp"
 
 namespace adk {
-
-#define LOD_G 16   // global_feat_dim (run.sh --global_feat_dim 16)
-#define LOD_L 16   // local_feat_dim  (run.sh --local_feat_dim 16)
-#define LOD_IN 32
-#define LOD_HID 32
-#define LOD_OUT 7
-#define LOD_NW (LOD_HID * LOD_IN + LOD_HID + LOD_OUT * LOD_HID + LOD_OUT) // 1287 mlp parameters
-
-struct CamCentre { float c[3]; };
-
-__device__ __forceinline__ CamCentre cam_centre_of(const float* __restrict__ V) {
-    // -R^-1 t via the adjugate, same as raster_project.hip:load_cam
-    float R[3][3], t[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i][j] = V[i * 4 + j]; t[i] = V[i * 4 + 3]; }
-    const float c00 = R[1][1] * R[2][2] - R[1][2] * R[2][1], c01 = R[0][2] * R[2][1] - R[0][1] * R[2][2], c02 = R[0][1] * R[1][2] - R[0][2] * R[1][1];
-    const float c10 = R[1][2] * R[2][0] - R[1][0] * R[2][2], c11 = R[0][0] * R[2][2] - R[0][2] * R[2][0], c12 = R[0][2] * R[1][0] - R[0][0] * R[1][2];
-    const float c20 = R[1][0] * R[2][1] - R[1][1] * R[2][0], c21 = R[0][1] * R[2][0] - R[0][0] * R[2][1], c22 = R[0][0] * R[1][1] - R[0][1] * R[1][0];
-    const float id = 1.0f / ((R[0][0] * c00 + R[0][1] * c10) + R[0][2] * c20);
-    CamCentre o;
-    o.c[0] = -((c00 * t[0] + c01 * t[1] + c02 * t[2]) * id);
-    o.c[1] = -((c10 * t[0] + c11 * t[1] + c12 * t[2]) * id);
-    o.c[2] = -((c20 * t[0] + c21 * t[1] + c22 * t[2]) * id);
-    return o;
-}
-
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ---- sparse Adam of the five per-Gaussian tensors, applied INSIDE the backward (round 4) ---------------------------------------------
 // SparseGaussianAdam.step (Reconstruct/scene/optimizers.py:106-161) runs adamUpdate on xyz / opacity / scaling / rotation / local_feat
@@ -78,88 +52,7 @@ __device__ __forceinline__ void lod_adam_elem(float& p, float g, float& m, float
     p += step;
 }
 
-// x[32] = [global_feat[cls], local_feat[g]]
-__device__ __forceinline__ void load_features(const float* __restrict__ global_feat, const float* __restrict__ local_feat,
-                                              int64_t cls, int64_t g, float* x)
-{
-    const float4* gf = reinterpret_cast<const float4*>(global_feat + cls * LOD_G);
-    const float4* lf = reinterpret_cast<const float4*>(local_feat + g * LOD_L);
-#pragma unroll
-    for (int i = 0; i < LOD_G / 4; ++i) { const float4 v = gf[i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; }
-#pragma unroll
-    for (int i = 0; i < LOD_L / 4; ++i) { const float4 v = lf[i]; x[LOD_G + 4 * i] = v.x; x[LOD_G + 4 * i + 1] = v.y; x[LOD_G + 4 * i + 2] = v.z; x[LOD_G + 4 * i + 3] = v.w; }
-}
-
-// h = relu(W1 x + b1) ; y = W2 h + b2.  Weight indices are wave-uniform => scalar loads.
-__device__ __forceinline__ void mlp_forward(const float* __restrict__ W1, const float* __restrict__ b1,
-                                            const float* __restrict__ W2, const float* __restrict__ b2,
-                                            const float* x, float* h, float* y)
-{
-#pragma unroll
-    for (int i = 0; i < LOD_HID; ++i) {
-        float a = b1[i];
-#pragma unroll
-        for (int j = 0; j < LOD_IN; ++j) a += W1[i * LOD_IN + j] * x[j];
-        h[i] = fmaxf(a, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < LOD_OUT; ++o) {
-        float a = b2[o];
-#pragma unroll
-        for (int i = 0; i < LOD_HID; ++i) a += W2[o * LOD_HID + i] * h[i];
-        y[o] = a;
-    }
-}
-
-struct LodGeom { float dist, alpha_ratio, inv_dmax; bool selected, fading; float dir[3]; };
-
-__device__ __forceinline__ LodGeom lod_geometry_of(float px, float py, float pz, float dm, const CamCentre& cc);
-__device__ __forceinline__ LodGeom lod_geometry(const float* __restrict__ xyz, const float* __restrict__ d_max, int64_t g, const CamCentre& cc) {
-    return lod_geometry_of(xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], d_max[g], cc);
-}
-__device__ __forceinline__ LodGeom lod_geometry_of(float px, float py, float pz, float dm, const CamCentre& cc) {
-    LodGeom L;
-    const float dx = px - cc.c[0], dy = py - cc.c[1], dz = pz - cc.c[2];
-    L.dist = sqrtf(dx * dx + dy * dy + dz * dz);
-    L.selected = L.dist < 2.f * dm;
-    L.fading = (L.dist > dm) && (L.dist < 2.f * dm);
-    L.inv_dmax = 1.0f / dm;
-    L.alpha_ratio = L.fading ? (2.f * dm - L.dist) * L.inv_dmax : 1.0f;
-    const float id = L.dist > 0.f ? 1.0f / L.dist : 0.f;
-    L.dir[0] = dx * id; L.dir[1] = dy * id; L.dir[2] = dz * id;
-    return L;
-}
-
-__global__ __launch_bounds__(256) void lod_params_fwd_kernel(
-    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
-    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
-    const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
-    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
-    const float* __restrict__ viewmat, float* __restrict__ opac_eff, float* __restrict__ scale_eff,
-    float* __restrict__ quat_eff, uint8_t* __restrict__ selected)
-{
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    const CamCentre cc = cam_centre_of(viewmat);
-    const LodGeom L = lod_geometry(xyz, d_max, g, cc);
-    selected[g] = L.selected ? 1 : 0;
-    if (!L.selected) { // never rendered: opacity 0 is culled by the projection (opacity < 1/255)
-        opac_eff[g] = 0.f;
-        scale_eff[3 * g] = 1.f; scale_eff[3 * g + 1] = 1.f; scale_eff[3 * g + 2] = 1.f;
-        reinterpret_cast<float4*>(quat_eff)[g] = make_float4(1.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    float x[LOD_IN], h[LOD_HID], y[LOD_OUT];
-    load_features(global_feat, local_feat, cls_id[g], g, x);
-    mlp_forward(W1, b1, W2, b2, x, h, y);
-    opac_eff[g] = sigmoidf(opacity_raw[g]) * L.alpha_ratio;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) scale_eff[3 * g + k] = __expf(scaling_raw[3 * g + k]) * sigmoidf(y[k]);
-    const float4 q = reinterpret_cast<const float4*>(rotation)[g];
-    // F.normalize(rotation * scale_rot[:,3:]) -- the projection normalises again (idempotent), so the
-    // un-normalised product is handed over and the normalisation Jacobian lives in one place.
-    reinterpret_cast<float4*>(quat_eff)[g] = make_float4(q.x * y[3], q.y * y[4], q.z * y[5], q.w * y[6]);
-}
+// (the forward kernel lives in raster_project.hip, next to the fused LoD + projection forward that shares its body: lod_core.hpp)
 
 // ---- backward -------------------------------------------------------------------------------------
 // One wavefront per workgroup walks 64-Gaussian chunks.  Every dense contraction of the chunk runs on
@@ -732,23 +625,6 @@ __global__ __launch_bounds__(256) void lod_visible_count_kernel(int N, const flo
 }
 
 } // namespace adk
-
-extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
-                                  const float* rotation, const float* local_feat, const float* global_feat,
-                                  const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
-                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
-                                  float* opac_eff, float* scale_eff, float* quat_eff, uint8_t* selected, hipStream_t stream)
-{
-    if (N < 0) return ADK_EINVAL;
-    if (local_dim != LOD_L || global_dim != LOD_G || hidden_dim != LOD_HID) return ADK_EUNSUPPORTED;
-    if (N == 0) return 0;
-    if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 || !viewmat || !opac_eff || !scale_eff || !quat_eff || !selected) return ADK_EINVAL;
-    if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)quat_eff) & 15) return ADK_EINVAL;
-    hipLaunchKernelGGL(adk::lod_params_fwd_kernel, dim3((unsigned)adk::ceil_div(N, 256)), dim3(256), 0, stream, N, xyz,
-                       opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat,
-                       opac_eff, scale_eff, quat_eff, selected);
-    ADK_RETURN_LAST_ERROR();
-}
 
 #define LOD_BWD_MAX_BLOCKS 2048 // 8 resident single-wave workgroups (19.2 KB LDS each) per CU x 256 CUs
 extern "C" int64_t adk_lod_params_bwd_workspace_bytes(int N)

@@ -81,6 +81,9 @@ struct StageScope {
 
 } // namespace adk
 
+#ifndef ADK_STEP_FUSE_FWD
+#define ADK_STEP_FUSE_FWD 1
+#endif
 #define ADK_STAGE_ENUM(n) STAGE_##n,
 enum { ADK_MAPPER_STAGES(ADK_STAGE_ENUM) STAGE_COUNT };
 static_assert(STAGE_COUNT == ADK_MAPPER_N_STAGES, "ADK_MAPPER_N_STAGES out of date");
@@ -144,6 +147,22 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
     // the voxel-feature gradient: the LoD backward), instead of a ~4 us launch each
     ADK_STEP_TRY(STAGE_lod_params_fwd, adk::pose6d_fwd_clear(cf(A->r6), cf(A->t), f(A->viewmat), A->gvis, (int64_t)A->V, A->v_global_feat,
                                                              (int64_t)A->V * 16 * sizeof(float), stream));
+#if ADK_STEP_FUSE_FWD
+    {
+        // LoD / mlp_cov forward and projection forward as ONE kernel (adk_internal.hpp): timed as the projection's stage
+        adk::StageScope ts(A, STAGE_project_fwd, stream);
+        const adk::ProjectMasks masks = {static_cast<const int64_t*>(A->cls_id), (int64_t)A->V, static_cast<uint8_t*>(A->vis),
+                                         static_cast<uint8_t*>(A->gvis)};
+        ADK_STEP_TRY(STAGE_project_fwd,
+                     adk::lod_project_fwd_launch(N, cf(A->xyz), cf(A->opacity_raw), cf(A->scaling_raw), cf(A->rotation), cf(A->local_feat),
+                                                 cf(A->global_feat), static_cast<const int64_t*>(A->cls_id), cf(A->d_max), cf(A->W1), cf(A->b1),
+                                                 cf(A->W2), cf(A->b2), f(A->opac), f(A->scale), f(A->quat), static_cast<uint8_t*>(A->sel),
+                                                 cf(A->f_dc), cf(A->f_rest), A->sh_K, A->sh_degree, cf(A->viewmat), cf(A->Kmat), W, H, A->eps2d,
+                                                 A->near_plane, A->far_plane, A->radius_clip, f(A->rec), static_cast<int32_t*>(A->radii),
+                                                 static_cast<uint32_t*>(A->depth_keys), static_cast<uint32_t*>(A->gauss_ids),
+                                                 static_cast<int32_t*>(A->tiles_per_gauss), &masks, stream));
+    }
+#else
     {
         adk::StageScope ts(A, STAGE_lod_params_fwd, stream);
         ADK_STEP_TRY(STAGE_lod_params_fwd,
@@ -163,6 +182,7 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
                                              A->radius_clip, 0, f(A->rec), static_cast<int32_t*>(A->radii), static_cast<uint32_t*>(A->depth_keys),
                                              static_cast<uint32_t*>(A->gauss_ids), static_cast<int32_t*>(A->tiles_per_gauss), &masks, stream));
     }
+#endif
     {
         adk::StageScope ts(A, STAGE_bin_count, stream);
         ADK_STEP_TRY(STAGE_bin_count,

@@ -19,6 +19,7 @@
 // radius path is evaluated in fp64 and rounded (one per Gaussian; free on an HBM-bound kernel).
 #include "adk_common.hpp"
 #include "adk_internal.hpp"
+#include "lod_core.hpp"
 #include "pose6d.hpp"
 
 namespace adk {
@@ -252,26 +253,16 @@ __device__ __forceinline__ void tile_range(float mx, float my, float rx, float r
 //   [4] conic a   [5] conic b   [6] conic c  [7] radius_y
 //   [8] r         [9] g         [10] b       [11] depth      (channels per `color_mode`)
 // color_mode: 0 = SH -> rgb (+depth in ch 3); 1 = colors_in[N,3] copied (+depth); 2 = depth only in ch 0.
+// One Gaussian of the forward: everything after its inputs are in registers (the stand-alone kernel loads them; the fused LoD + projection
+// kernel of the one-call step has just computed them).
 template <int SH_DEG>
-__global__ __launch_bounds__(256) void project_fwd_kernel(
-    int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
-    const float* __restrict__ opacities, const float* __restrict__ colors_in, const float* __restrict__ sh_rest,
-    int sh_K, int color_mode,
-    const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height, int tile_w, int tile_h,
-    float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth,
-    float* __restrict__ rec, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
-    uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss, const ProjectMasks masks)
+__device__ __forceinline__ void project_fwd_one(
+    const int g, const Cam& cam, const float x, const float y, const float z, const float (&q)[4], const float (&s)[3], const float opac,
+    const float* __restrict__ colors_in, const float* __restrict__ sh_rest, int sh_K, int color_mode, int width, int height, int tile_w,
+    int tile_h, float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth, float* __restrict__ rec,
+    int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss,
+    const ProjectMasks& masks)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    const Cam cam = load_cam(viewmat, Kmat);
-
-    const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
-    const float4 q4 = reinterpret_cast<const float4*>(quats)[g];
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    const float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
-    const float opac = opacities[g];
-
     Proj P;
     bool valid = project_core(cam, x, y, z, q, s, width, height, eps2d, near_plane, far_plane, P);
     float rad_x = 0.f, rad_y = 0.f;
@@ -359,6 +350,92 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     r4[0] = make_float4(P.m2x, P.m2y, opac, rad_x);
     r4[1] = make_float4(P.ca, P.cb, P.cc, rad_y);
     r4[2] = make_float4(col[0], col[1], col[2], col[3]);
+}
+
+template <int SH_DEG>
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ opacities, const float* __restrict__ colors_in, const float* __restrict__ sh_rest,
+    int sh_K, int color_mode,
+    const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height, int tile_w, int tile_h,
+    float eps2d, float near_plane, float far_plane, float radius_clip, int inv_depth,
+    float* __restrict__ rec, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
+    uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss, const ProjectMasks masks)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const Cam cam = load_cam(viewmat, Kmat);
+
+    const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+    const float4 q4 = reinterpret_cast<const float4*>(quats)[g];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    const float opac = opacities[g];
+    project_fwd_one<SH_DEG>(g, cam, x, y, z, q, s, opac, colors_in, sh_rest, sh_K, color_mode, width, height, tile_w, tile_h, eps2d, near_plane,
+                            far_plane, radius_clip, inv_depth, rec, radii, depth_keys, gauss_ids, tiles_per_gauss, masks);
+}
+
+// The stand-alone LoD / mlp_cov forward (adk_lod_params_fwd): here rather than in lod_params.hip so that it and the fused kernel below call ONE
+// compiled lod_forward_one.
+__global__ __launch_bounds__(256) void lod_params_fwd_kernel(
+    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
+    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
+    const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ viewmat, float* __restrict__ opac_eff, float* __restrict__ scale_eff,
+    float* __restrict__ quat_eff, uint8_t* __restrict__ selected)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const LodOut o = lod_forward_one(g, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat);
+    selected[g] = o.selected ? 1 : 0;
+    opac_eff[g] = o.opac;
+    scale_eff[3 * g] = o.scale[0]; scale_eff[3 * g + 1] = o.scale[1]; scale_eff[3 * g + 2] = o.scale[2];
+    reinterpret_cast<float4*>(quat_eff)[g] = o.quat;
+}
+
+// LoD / mlp_cov forward + projection forward of ONE Gaussian in one kernel (the one-call step; SH colours in ARTDECO's split layout).  The first
+// phase is 1 248 FMAs per Gaussian on scalar-cache weights, the second streams 260 B per Gaussian: run back to back as two kernels they
+// cannot overlap, inside one the waves of a SIMD are in different phases.  The activated parameters are still written (the backward reads
+// them) but never re-read, and the arithmetic of each phase is its own file's (lod_core.hpp pins the contraction mode of lod_params.hip).
+#ifndef ADK_LOD_PROJECT_WAVES
+#define ADK_LOD_PROJECT_WAVES 6
+#endif
+template <int SH_DEG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ADK_LOD_PROJECT_WAVES, 8))) void lod_project_fwd_kernel(
+    int N, const float* __restrict__ xyz, const float* __restrict__ opacity_raw, const float* __restrict__ scaling_raw,
+    const float* __restrict__ rotation, const float* __restrict__ local_feat, const float* __restrict__ global_feat,
+    const int64_t* __restrict__ cls_id, const float* __restrict__ d_max, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ opac_eff, float* __restrict__ scale_eff,
+    float* __restrict__ quat_eff, uint8_t* __restrict__ selected,
+    const float* __restrict__ colors_in, const float* __restrict__ sh_rest, int sh_K,
+    const float* __restrict__ viewmat, const float* __restrict__ Kmat, int width, int height, int tile_w, int tile_h,
+    float eps2d, float near_plane, float far_plane, float radius_clip,
+    float* __restrict__ rec, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
+    uint32_t* __restrict__ gauss_ids, int32_t* __restrict__ tiles_per_gauss, const ProjectMasks masks)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const LodOut o = lod_forward_one(g, xyz, opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat);
+    selected[g] = o.selected ? 1 : 0;
+    opac_eff[g] = o.opac;
+    scale_eff[3 * g] = o.scale[0]; scale_eff[3 * g + 1] = o.scale[1]; scale_eff[3 * g + 2] = o.scale[2];
+    reinterpret_cast<float4*>(quat_eff)[g] = o.quat;
+
+    // The projection phase sees its inputs through values the optimiser cannot identify with the first phase's: both phases invert the view
+    // matrix and both read the position, and a product with two users is no longer folded into the first phase's FMAs -- the camera centre (and
+    // with it the fade factor of some Gaussians) would move by an ulp against the stand-alone LoD kernel.
+    const float* vm_proj = viewmat;
+    const float* xyz_proj = xyz;
+    asm volatile("" : "+s"(vm_proj), "+s"(xyz_proj));
+    float q[4] = {o.quat.x, o.quat.y, o.quat.z, o.quat.w};
+    float s[3] = {o.scale[0], o.scale[1], o.scale[2]};
+    float opac = o.opac;
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(opac));
+    const Cam cam = load_cam(vm_proj, Kmat);
+    const float x = xyz_proj[3 * g], y = xyz_proj[3 * g + 1], z = xyz_proj[3 * g + 2];
+    project_fwd_one<SH_DEG>(g, cam, x, y, z, q, s, opac, colors_in, sh_rest, sh_K, 0, width, height, tile_w, tile_h, eps2d, near_plane, far_plane,
+                            radius_clip, 0, rec, radii, depth_keys, gauss_ids, tiles_per_gauss, masks);
 }
 
 // Optional in-kernel optimiser for the SH coefficients (see adk_project_bwd_adam): the gradient of coefficient
@@ -754,6 +831,52 @@ int adk::project_fwd_launch(int N, const float* means, const float* quats, const
                                             scales, opacities, colors_in, sh_rest, sh_K, color_mode, viewmat, Kmat, width, height,
                                             tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, inv_depth, rec, radii,
                                             depth_keys, gauss_ids, tiles_per_gauss, masks));
+    ADK_RETURN_LAST_ERROR();
+}
+
+extern "C" int adk_lod_params_fwd(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw,
+                                  const float* rotation, const float* local_feat, const float* global_feat,
+                                  const int64_t* cls_id, const float* d_max, int local_dim, int global_dim, int hidden_dim,
+                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* viewmat,
+                                  float* opac_eff, float* scale_eff, float* quat_eff, uint8_t* selected, hipStream_t stream)
+{
+    if (N < 0) return ADK_EINVAL;
+    if (local_dim != LOD_L || global_dim != LOD_G || hidden_dim != LOD_HID) return ADK_EUNSUPPORTED;
+    if (N == 0) return 0;
+    if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 || !viewmat || !opac_eff || !scale_eff || !quat_eff || !selected) return ADK_EINVAL;
+    if (((uintptr_t)rotation | (uintptr_t)local_feat | (uintptr_t)global_feat | (uintptr_t)quat_eff) & 15) return ADK_EINVAL;
+    hipLaunchKernelGGL(adk::lod_params_fwd_kernel, dim3((unsigned)adk::ceil_div(N, 256)), dim3(256), 0, stream, N, xyz,
+                       opacity_raw, scaling_raw, rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, viewmat,
+                       opac_eff, scale_eff, quat_eff, selected);
+    ADK_RETURN_LAST_ERROR();
+}
+
+int adk::lod_project_fwd_launch(int N, const float* xyz, const float* opacity_raw, const float* scaling_raw, const float* rotation,
+                                const float* local_feat, const float* global_feat, const int64_t* cls_id, const float* d_max, const float* W1,
+                                const float* b1, const float* W2, const float* b2, float* opac_eff, float* scale_eff, float* quat_eff,
+                                uint8_t* selected, const float* f_dc, const float* f_rest, int sh_K, int sh_degree, const float* viewmat,
+                                const float* Kmat, int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                                float* rec, int32_t* radii, uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss,
+                                const ProjectMasks* masks_in, hipStream_t stream)
+{
+    if (N < 0 || width <= 0 || height <= 0) return ADK_EINVAL;
+    if (N == 0) return 0;
+    if (!xyz || !opacity_raw || !scaling_raw || !rotation || !local_feat || !global_feat || !cls_id || !d_max || !W1 || !b1 || !W2 || !b2 ||
+        !opac_eff || !scale_eff || !quat_eff || !selected || !f_dc || !f_rest || !viewmat || !Kmat || !rec || !radii || !depth_keys ||
+        !gauss_ids || !tiles_per_gauss) return ADK_EINVAL;
+    if (sh_degree < 0 || sh_degree > 3 || sh_K < 2 || sh_K < (sh_degree + 1) * (sh_degree + 1)) return ADK_EINVAL;
+    if (((uintptr_t)rotation | (uintptr_t)quat_eff | (uintptr_t)rec | (uintptr_t)local_feat | (uintptr_t)global_feat) & 15) return ADK_EINVAL;
+    ProjectMasks masks = {nullptr, 0, nullptr, nullptr};
+    if (masks_in) {
+        masks = *masks_in;
+        if (!masks.vis || (masks.gvis && (!masks.cls_id || masks.V <= 0))) return ADK_EINVAL;
+    }
+    const int tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
+    const dim3 grid((unsigned)adk::ceil_div(N, 256)), block(256);
+    ADK_DISPATCH_SH(sh_degree, hipLaunchKernelGGL((adk::lod_project_fwd_kernel<SH_DEG>), grid, block, 0, stream, N, xyz, opacity_raw, scaling_raw,
+                                                  rotation, local_feat, global_feat, cls_id, d_max, W1, b1, W2, b2, opac_eff, scale_eff, quat_eff,
+                                                  selected, f_dc, f_rest, sh_K, viewmat, Kmat, width, height, tile_w, tile_h, eps2d, near_plane,
+                                                  far_plane, radius_clip, rec, radii, depth_keys, gauss_ids, tiles_per_gauss, masks));
     ADK_RETURN_LAST_ERROR();
 }
 

@@ -246,6 +246,9 @@ def main():
         rasterizer.set_stage_timer(None)
         stages = detail.summary_ms()
     stages["raster_bwd"] = stages_timed["raster_bwd"]
+    if "project_fwd" in stages and "lod_params_fwd" not in stages:
+        # the one-call step runs the LoD / mlp_cov forward and the projection forward as ONE kernel (timed as its projection stage)
+        stages["lod_project_fwd"] = stages.pop("project_fwd")
 
     # workload size seen by the kernels (a render of the newest keyframe): N Gaussians, I intersections, V visible, P pixels
     with torch.no_grad():
@@ -370,6 +373,9 @@ def roofline_stages(stages, N, V, I, P, W, H):
         "ssim_fwd": 24.0 * P * 3, "ssim_bwd": 28.0 * P * 3,
         "adam_multi": 28.0 * 27 * V + N,                            # the remaining 27 floats per visible Gaussian + the mask
         "lod_params_fwd": 190.0 * N, "photometric_fwd": 64.0 * P, "photometric_bwd": 72.0 * P,
+        # LoD forward + projection forward as one kernel: the two formulas minus the 32 B per Gaussian (opacity, scale, quaternion) the
+        # projection no longer reads back
+        "lod_project_fwd": 190.0 * N + 76.0 * N + 216.0 * V - 32.0 * N,
     }
     ms = {k: v["mean_ms"] for k, v in stages.items()}
     if all(k in ms for k in ("bin_count", "bin_scatter", "bin_sort")):

@@ -37,6 +37,11 @@ def test_roofline_stages_follow_the_survey_formulas():
             assert abs(v["frac"] - v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3, k
     total_ms = sum(v["mean_ms"] for v in st.values())
     assert abs(r["whole_step"]["ms_sum_of_stages"] - total_ms) < 1e-3                                # every stage's time, also those without a formula
+    # the one-call step's fused LoD + projection forward: both formulas minus the 32 B per Gaussian the projection no longer reads back
+    fused = {k: v for k, v in st.items() if k not in ("project_fwd", "lod_params_fwd")}
+    fused["lod_project_fwd"] = {"mean_ms": 0.11}
+    r2 = bench.roofline_stages(fused, N, V, I, P, W, H)
+    assert r2["lod_project_fwd"]["alg_bytes"] == 190.0 * N + 76.0 * N + 216.0 * V - 32.0 * N and "project_fwd" not in r2 and "lod_params_fwd" not in r2
 
 
 def test_project_bwd_bytes_do_not_count_the_traffic_the_fused_colour_adam_removed():

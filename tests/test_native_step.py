@@ -231,4 +231,5 @@ def test_stage_timer_sees_the_stages_inside_the_native_call(dev, monkeypatch):
     finally:
         rasterizer.set_stage_timer(None)
     from artdeco_amd import native_step
-    assert set(native_step.STAGES) <= set(s) and "adam_multi" in s and all(v["count"] == 1 for v in s.values())
+    # the LoD forward and the projection forward are ONE kernel inside the call, timed as the projection's stage
+    assert set(native_step.STAGES) - {"lod_params_fwd"} <= set(s) and "adam_multi" in s and all(v["count"] == 1 for v in s.values())

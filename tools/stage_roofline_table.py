@@ -9,11 +9,11 @@ import json
 import sys
 
 STAGE_KERNELS = {
-    "project_fwd": ["project_fwd_kernel"],
+    "project_fwd": ["adk::project_fwd_kernel"], "lod_project_fwd": ["adk::lod_project_fwd_kernel"],
     "binning": ["bin_count_kernel", "bin_colscan_kernel", "bin_tilescan_kernel", "bin_scatter_kernel", "bin_tile_sort_"],
     "raster_fwd": ["raster_fwd_kernel"], "raster_bwd": ["raster_bwd_kernel"], "project_bwd": ["project_bwd_kernel"],
     "ssim_fwd": ["ssim_fwd_kernel"], "ssim_bwd": ["ssim_bwd_kernel"], "adam_multi": ["adam_multi_kernel"],
-    "lod_params_fwd": ["lod_params_fwd_kernel"], "lod_params_bwd": ["lod_params_bwd_kernel", "lod_reduce_partials_kernel"],
+    "lod_params_fwd": ["adk::lod_params_fwd_kernel"], "lod_params_bwd": ["lod_params_bwd_kernel", "lod_reduce_partials_kernel"],
     "photometric_fwd": ["photometric_fwd_kernel"], "photometric_bwd": ["photometric_bwd_kernel"],
 }
 
