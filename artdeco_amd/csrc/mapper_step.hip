@@ -3,7 +3,7 @@
 // Mirrors the order of SceneModel.optimization_step between zero_grad and the optimiser steps (Reconstruct/scene/scene_models/
 // h3dgsv3.py:418-455) on the stages this library already exports one by one; nothing here computes, it sequences (three tiny launches
 // ride in a neighbour's: the two zero fills in the pose's, the visibility masks in the projection's, the pose backward in the camera
-// gradient's finalisation -- adk_internal.hpp).  The point is the
+// gradient's finalisation; and the LoD forward and the projection forward are one kernel -- adk_internal.hpp).  The point is the
 // step's single host wait (the intersection count sizes the tile lists, as upstream's isect_tiles -> n_isects read does): with the
 // stages driven from Python the host needs ~0.1 ms between that wait and the forward rasteriser's launch on a fast box and several
 // times that on a slow one (DESIGN finding 34), during which the GPU has only the pre-launched scatter to run.  Here the wait, the

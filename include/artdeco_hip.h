@@ -592,7 +592,8 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
  * one host call: pose6d_fwd, lod_params_fwd, project_fwd, tile-local binning (count | scatter | sort), raster_fwd, visibility masks,
  * photometric_fwd, fused_ssim_fwd_sums, photometric_loss_sums, fused_ssim_bwd, photometric_bwd, raster_bwd, project_bwd (with the SH
  * colours' sparse-Adam step when color_adam != 0), lod_params_bwd, pose6d_bwd (the masks, two zero fills and the pose backward ride in a
- * neighbouring launch each: same arithmetic, three launches less).  The optimiser steps that follow (Keyframe.step,
+ * neighbouring launch each, and lod_params_fwd + project_fwd are one kernel: same arithmetic, bit-identical results, four launches less).
+ * The optimiser steps that follow (Keyframe.step,
  * SparseGaussianAdam.step: h3dgsv3.py:456-462) stay with the caller: they belong to ARTDECO's optimiser objects and consume the
  * gradient buffers this call filled (adk_adam_update_multi_betas, one launch).
  *
