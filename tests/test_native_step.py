@@ -118,6 +118,48 @@ def test_every_reuse_of_the_plan_matches_the_per_stage_chain(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_fused_forward_of_the_native_step_is_bit_identical_to_the_two_kernels(dev, monkeypatch):
+    """Inside adk_mapper_step the LoD / mlp_cov forward and the projection forward are ONE kernel (DESIGN finding 39); the per-stage chain runs the
+    two stand-alone kernels.  Effective opacity / scale / quaternion, the packed splat records, the radii and the rendered image must agree to the
+    BIT over consecutive steps from synchronised states: the poses move every step, and the first builds of the fused kernel differed by an ulp in
+    the fade factor of a few Gaussians at SOME poses only (an FMA formed in one kernel and not in the other)."""
+    from test_fused_glue import _sync_state
+    from artdeco_amd import fused, rasterizer
+    a, b = _scene(dev, N=6000, seed=4), _scene(dev, N=6000, seed=4)
+    assert fused.patch_scene_model(a) and fused.patch_scene_model(b)
+    stash = {}
+    lod_fwd, ras_fwd = fused.FusedLodParams.forward, rasterizer.RasterizeGaussians.forward
+
+    def lod_spy(ctx, *args):
+        out = lod_fwd(ctx, *args)
+        stash["opac"], stash["scale"], stash["quat"] = out[0].clone(), out[1].clone(), out[2].clone()
+        return out
+
+    def ras_spy(ctx, *args):
+        out = ras_fwd(ctx, *args)
+        stash["render_colors"], stash["radii"], stash["rec"] = out[0].clone(), out[2].clone(), out[3].clone()
+        return out
+    monkeypatch.setattr(fused.FusedLodParams, "forward", staticmethod(lod_spy))
+    monkeypatch.setattr(rasterizer.RasterizeGaussians, "forward", staticmethod(ras_spy))
+    for i in range(10):
+        _sync_state(a, b)
+        imp, kid = i % 3 != 0, i % 2
+        monkeypatch.setenv("ARTDECO_AMD_NATIVE_STEP", "1")
+        torch.manual_seed(40 + i)
+        a.optimization_step(kid, is_important=imp)
+        plan = next(iter(a.__dict__["_adk_step_plans"].values()))
+        native = {k: plan.t[k][:plan.n].clone() for k in ("opac", "scale", "quat", "rec", "radii")}
+        native["render_colors"] = plan.t["render_colors"].clone()
+        stash.clear()
+        monkeypatch.setenv("ARTDECO_AMD_NATIVE_STEP", "0")
+        torch.manual_seed(40 + i)
+        b.optimization_step(kid, is_important=imp)
+        assert set(stash) == set(native)
+        for k, x in native.items():
+            assert torch.equal(x.view(torch.int32), stash[k].view(torch.int32)), (i, k, int((x.view(torch.int32) != stash[k].view(torch.int32)).sum()))
+
+
+@pytest.mark.gpu
 def test_native_step_grows_its_lists_and_retries(dev, monkeypatch):
     """A frame with more intersections than the plan's capacity: ADK_STEP_ECAPACITY before anything was modified, lists grown, same step again."""
     from artdeco_amd import fused, native_step
