@@ -250,6 +250,34 @@ def test_native_step_on_a_test_keyframe_leaves_the_map_alone(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_the_plan_follows_a_growing_map(dev, monkeypatch):
+    """The frame loop with densification: the map grows on every important frame.  A step plan is sized by capacity (N rounded up), so most
+    densifications keep it and only re-point the leaves' `.grad` at shorter / longer views; crossing a capacity line builds a new one.  With the
+    capacity grain shrunk to 512 Gaussians both happen within sixteen frames; every optimisation step stays on the one-call path and trains."""
+    from artdeco_amd import fused, native_step
+    from harness import mapper, stream
+    monkeypatch.setenv("ARTDECO_AMD_NATIVE_STEP", "1")
+    monkeypatch.setattr(native_step, "_N_GRAIN", 512)
+    monkeypatch.setattr(native_step, "_V_GRAIN", 64)
+    sc = mapper.build_synthetic_mapper(6000, 160, 112, dev, seed=1, n_keyframes=0, targets="random")
+    assert fused.patch_scene_model(sc)
+    frames = stream.synthetic_frames(sc, 16, seed=3, texture=0.08, slam_hw=(56, 80))
+    before = dict(native_step.STATS)
+    out = stream.run_stream(sc, frames, start_index=0)
+    torch.cuda.synchronize()
+    d = {k: native_step.STATS[k] - before[k] for k in before}
+    assert out["steps"] > 100 and d["native"] == out["steps"] and d["fallback_layout"] == 0 and d["fallback_route"] == 0
+    assert out["gaussians_added"] > 0 and sc.xyz.shape[0] != 6000
+    plan = next(iter(sc.__dict__["_adk_step_plans"].values()))
+    assert 2 <= d["plans_built"] < out["densified_frames"] + 2          # rebuilt when a capacity line was crossed, not on every densification
+    assert plan.N >= plan.n == sc.xyz.shape[0] and plan.N % 512 == 0
+    for k in ("xyz", "opacity", "scaling", "local_feat"):
+        g = sc.gaussian_params[k]["val"].grad
+        assert g is not None and g.shape == sc.gaussian_params[k]["val"].shape and bool(torch.isfinite(g).all())
+    assert all(bool(torch.isfinite(pd["val"]).all()) for pd in sc.optimizer.params.values() if pd["val"].is_floating_point())
+
+
+@pytest.mark.gpu
 def test_stage_timer_sees_the_stages_inside_the_native_call(dev, monkeypatch):
     from artdeco_amd import fused, rasterizer
     monkeypatch.setenv("ARTDECO_AMD_NATIVE_STEP", "1")
