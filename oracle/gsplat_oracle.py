@@ -62,12 +62,13 @@ def _dot3(a0, b0, a1, b1, a2, b2):
 
 
 def project(means, quats, scales, opacities, viewmat, K, width, height, eps2d=0.3,
-            near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+            near_plane=0.01, far_plane=1e10, radius_clip=0.0, force_valid=None):
     """fully_fused_projection (non-packed, one camera).  All inputs one dtype (fp32 for the
     bit-exact integer outputs, fp64 + requires_grad for the gradient reference).
 
     Returns dict: radii int32 [N,2], means2d [N,2], depths [N], conics [N,3], valid bool [N].
-    Culled Gaussians have radii 0 and zeros elsewhere.
+    Culled Gaussians have radii 0 and zeros elsewhere.  force_valid (bool [N]): the cull decisions of ANOTHER pass (the fp32 integer
+    pass) decide which rows are zeroed in the outputs -- a high-precision pass must not drop a Gaussian that sits on the fp32 lists.
     """
     dt = means.dtype
     R = [[viewmat[i, j] for j in range(3)] for i in range(3)]
@@ -152,6 +153,8 @@ def project(means, quats, scales, opacities, viewmat, K, width, height, eps2d=0.
         radii = torch.stack([rad_x, rad_y], -1)
         radii = torch.where(valid[:, None], radii, torch.zeros_like(radii)).to(torch.int32)
 
+    if force_valid is not None:
+        valid = force_valid
     zero = torch.zeros_like(m2x)
     means2d = torch.stack([torch.where(valid, m2x, zero), torch.where(valid, m2y, zero)], -1)
     depths = torch.where(valid, mc[2], zero)
@@ -286,6 +289,55 @@ class _one_thread:
         torch.set_num_threads(self.n)
 
 
+def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, knife_eps=None):
+    """ONE tile of rasterize_to_pixels_fwd (App. A item 4), vectorised over [n splats in list order, P pixels], autograd-capable.
+
+    m2 [n,2], cn [n,3], col [n,CDIM], op [n] of the tile's list (depth order); px, py [P] pixel centres; first_index = position of the
+    list's first entry in the sorted intersection list.  Returns (colour [P,CDIM], T_final [P], last index int32 [P], extras or None);
+    extras = (knife bool [P], main list position int64 [P] (-1: none), main_w [P], second_w [P], touch bool [n,P]) -- `touch` marks the
+    (splat, pixel) pairs that either contribute (alpha T > 0) or sit on a decision within knife_eps while the pixel is still live: the
+    pairs whose gradients move if that pixel's decisions fall differently."""
+    dt = m2.dtype
+    eps = KNIFE_EPS if knife_eps is None else knife_eps
+    thr_alpha = torch.tensor(ALPHA_THRESHOLD, dtype=torch.float32).to(dt)
+    n, P = m2.shape[0], px.shape[0]
+    dx = m2[:, 0][:, None] - px[None, :]  # [n, P]
+    dy = m2[:, 1][:, None] - py[None, :]
+    sigma = 0.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) + cn[:, 1:2] * dx * dy
+    alpha = torch.clamp_max(op[:, None] * torch.exp(-sigma), MAX_ALPHA)
+    keep = ~((sigma < 0) | (alpha < thr_alpha))
+    a = torch.where(keep, alpha, torch.zeros_like(alpha))
+    one_m = 1.0 - a
+    T_incl = torch.cumprod(one_m, dim=0)  # T after splat k
+    T_excl = torch.cat([torch.ones(1, P, dtype=dt), T_incl[:-1]], 0)
+    # a kept splat whose next_T <= 1e-4 terminates the pixel BEFORE being added; since T is
+    # monotone, every later kept splat also fails the test, so the mask is simply:
+    live = keep & (T_incl.detach() > TRANSMITTANCE_EPS)
+    w = torch.where(live, a * T_excl, torch.zeros_like(a))  # alpha * T
+    colour = (w[:, :, None] * col[:, None, :]).sum(0)  # [P, cdim]
+    T_final = torch.prod(torch.where(live, one_m, torch.ones_like(one_m)), dim=0)
+    idx = torch.arange(first_index, first_index + n, dtype=torch.int32)[:, None].expand(-1, P)
+    lastk = torch.where(live, idx, torch.zeros_like(idx)).max(0).values
+    extras = None
+    if want_extras:
+        with torch.no_grad():
+            ov = (op[:, None] * torch.exp(-sigma)).detach()
+            Ti, Te = T_incl.detach(), T_excl.detach()
+            reached = Te > TRANSMITTANCE_EPS * (1.0 - eps)
+            near = ((ov * 255.0 - 1.0).abs() <= eps) | ((ov - MAX_ALPHA).abs() <= eps * MAX_ALPHA) \
+                | (sigma.detach().abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= eps * TRANSMITTANCE_EPS))
+            knife = (near & reached).any(0)
+            wd = w.detach()
+            k = min(2, n)
+            top = torch.topk(wd, k, dim=0)
+            w1 = top.values[0]
+            w2 = top.values[1] if k > 1 else torch.zeros_like(w1)
+            first = (wd == w1[None, :]).to(torch.int8).argmax(0)  # first list position holding the maximum
+            main = torch.where(w1 > 0, first, torch.full_like(first, -1))
+            extras = (knife, main, w1, w2, (wd > 0) | (near & reached))
+    return colour, T_final, lastk, extras
+
+
 def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isects, backgrounds=None, tile_window=None,
                         extras=None):
     """Per-tile vectorised, autograd-capable restatement of rasterize_to_pixels_fwd (App. A item 4).
@@ -314,7 +366,6 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isect
     out_T = torch.ones(Hp, Wp, dtype=dt)
     last = torch.zeros(Hp, Wp, dtype=torch.int32)
     ys, xs = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
-    thr_alpha = torch.tensor(ALPHA_THRESHOLD, dtype=torch.float32).to(dt)
     if extras is not None:
         ex_knife = torch.zeros(Hp, Wp, dtype=torch.bool)
         ex_main = torch.full((Hp, Wp), -1, dtype=torch.int32)
@@ -333,46 +384,19 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isect
         g = flat[s:e]
         px = (tx * TILE + xs).reshape(-1).to(dt) + 0.5  # [256]
         py = (ty * TILE + ys).reshape(-1).to(dt) + 0.5
-        dx = means2d[g, 0][:, None] - px[None, :]  # [n, 256]
-        dy = means2d[g, 1][:, None] - py[None, :]
-        cn = conics[g]
-        sigma = 0.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) + cn[:, 1:2] * dx * dy
-        alpha = torch.clamp_max(opacities[g][:, None] * torch.exp(-sigma), MAX_ALPHA)
-        keep = ~((sigma < 0) | (alpha < thr_alpha))
-        a = torch.where(keep, alpha, torch.zeros_like(alpha))
-        one_m = 1.0 - a
-        T_incl = torch.cumprod(one_m, dim=0)  # T after splat k
-        T_excl = torch.cat([torch.ones(1, 256, dtype=dt), T_incl[:-1]], 0)
-        # a kept splat whose next_T <= 1e-4 terminates the pixel BEFORE being added; since T is
-        # monotone, every later kept splat also fails the test, so the mask is simply:
-        live = keep & (T_incl.detach() > TRANSMITTANCE_EPS)
-        w = torch.where(live, a * T_excl, torch.zeros_like(a))  # alpha * T
-        col = (w[:, :, None] * colors[g][:, None, :]).sum(0)  # [256, cdim]
-        T_final = torch.prod(torch.where(live, one_m, torch.ones_like(one_m)), dim=0)
-        idx = torch.arange(s, e, dtype=torch.int32)[:, None].expand(-1, 256)
-        lastk = torch.where(live, idx, torch.zeros_like(idx)).max(0).values
+        col, T_final, lastk, ex = composite_tile(means2d[g], conics[g], colors[g], opacities[g], px, py, first_index=s,
+                                                 want_extras=extras is not None)
         sl = (slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE))
         out_c[sl] = col.reshape(TILE, TILE, cdim)
         out_T[sl] = T_final.reshape(TILE, TILE)
         last[sl] = lastk.reshape(TILE, TILE)
         if extras is not None:
-            with torch.no_grad():
-                ov = (opacities[g][:, None] * torch.exp(-sigma)).detach()
-                Ti, Te = T_incl.detach(), T_excl.detach()
-                reached = Te > TRANSMITTANCE_EPS * (1.0 - KNIFE_EPS)
-                near = ((ov * 255.0 - 1.0).abs() <= KNIFE_EPS) | ((ov - MAX_ALPHA).abs() <= KNIFE_EPS * MAX_ALPHA) \
-                    | (sigma.detach().abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= KNIFE_EPS * TRANSMITTANCE_EPS))
-                ex_knife[sl] = (near & reached).any(0).reshape(TILE, TILE)
-                wd = w.detach()
-                k = min(2, wd.shape[0])
-                top = torch.topk(wd, k, dim=0)
-                w1 = top.values[0]
-                w2 = top.values[1] if k > 1 else torch.zeros_like(w1)
-                first = (wd == w1[None, :]).to(torch.int8).argmax(0)  # first list position holding the maximum
-                mid = torch.where(w1 > 0, g[first].to(torch.int32), torch.full_like(first, -1, dtype=torch.int32))
-                ex_main[sl] = mid.reshape(TILE, TILE)
-                ex_w1[sl] = w1.reshape(TILE, TILE)
-                ex_w2[sl] = w2.reshape(TILE, TILE)
+            knife, main, w1, w2, _ = ex
+            ex_knife[sl] = knife.reshape(TILE, TILE)
+            mid = torch.where(main >= 0, g[main.clamp_min(0)].to(torch.int32), torch.full_like(main, -1, dtype=torch.int32))
+            ex_main[sl] = mid.reshape(TILE, TILE)
+            ex_w1[sl] = w1.reshape(TILE, TILE)
+            ex_w2[sl] = w2.reshape(TILE, TILE)
     threads.__exit__()
     out_c, out_T, last = out_c[:height, :width], out_T[:height, :width], last[:height, :width]
     if extras is not None:

@@ -178,6 +178,84 @@ def test_real_scene_model_steps_bit_identically_to_the_mirror(ref_module, monkey
     assert torch.equal(real.gaussian_params["f_rest"]["exp_avg_sq"], mirror.gaussian_params["f_rest"]["exp_avg_sq"])
 
 
+def test_step_oracle_is_pinned_to_the_real_scene_model(ref_module, monkeypatch):
+    """oracle/step_oracle.py (the fp64 restatement of the WHOLE optimisation step that the GPU tests hold `adk_mapper_step` to at the
+    BASELINE sizes) against the reference's REAL `SceneModel.optimization_step` executed here on CPU with the natives bound to the fp32
+    oracles: loss, both visibility masks, the inverse depth and every gradient the real class leaves in `.grad` (fp32 vs fp64: 2e-5)."""
+    import test_mapper_host_logic as H
+    from harness import mapper
+    from oracle import step_oracle as SO
+    monkeypatch.setenv("ARTDECO_AMD_AUTOFUSE", "0")
+    mod = ref_module()
+    opt_mod = sys.modules["Reconstruct.scene.optimizers"]
+    monkeypatch.setattr(mod, "gsplat", types.SimpleNamespace(rendering=types.SimpleNamespace(rasterization=H._rasterization)))
+    monkeypatch.setattr(mod, "fused_ssim", H._fused_ssim)
+    for m in (opt_mod, mapper):           # the keyframes are the mirror's Keyframe objects (their BaseAdam calls mapper.adamUpdateBasic)
+        monkeypatch.setattr(m, "adamUpdate", H._adam_update)
+        monkeypatch.setattr(m, "adamUpdateBasic", H._adam_update_basic)
+    monkeypatch.setattr(mod, "torch", H._TorchNoCuda())
+
+    W, Hh = 48, 32
+    mirror = H._scene(mapper, seed=2)
+    fx = W / (2 * mirror.tanfovx)
+    real = mod.SceneModel(W, Hh, _K(W, Hh, fx), _args(scaling_reg_factor=0.05), device="cpu")
+    P = mirror.gaussian_params
+    N = P["xyz"]["val"].shape[0]
+    g = torch.Generator().manual_seed(4)
+    ext = {k: P[k]["val"].detach().clone() for k in ("cls_id", "d_max", "xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation",
+                                                     "local_feat", "global_feat")}
+    ext["local_feat"] = 0.5 * torch.randn(N, 16, generator=g)
+    ext["global_feat"] = 0.5 * torch.randn(ext["global_feat"].shape[0], 16, generator=g)
+    dist = ext["xyz"].norm(dim=1, keepdim=True)
+    ext["d_max"] = dist * (0.45 + 0.6 * torch.rand(N, 1, generator=g))       # some culled (dist >= 2 d_max), some fading, some plain
+    ext["id"] = torch.zeros(N, 1, dtype=torch.long)
+    real.optimizer.add_and_prune(ext, torch.ones(0, dtype=torch.bool))
+    with torch.no_grad():
+        for pr, pm in zip(real.mlp_cov.parameters(), mirror.mlp_cov.parameters()):
+            pr.copy_(pm + 0.2 * torch.randn(pm.shape, generator=g))
+    real.keyframes = []
+    for i, kf in enumerate(mirror.keyframes):
+        k2 = mapper.Keyframe(kf.image_pyr[0].clone(), kf.idepth_pyr[0].clone(), kf.get_Rt().detach().clone(), "cpu")
+        with torch.no_grad():
+            k2.rW2C.add_(0.01 * torch.randn(3, 2, generator=g))
+            k2.exposure.add_(0.03 * torch.randn(3, 4, generator=g))
+        k2.index = i
+        real.keyframes.append(k2)
+    real.valid_Rt_cache = torch.ones(len(real.keyframes), dtype=torch.bool)
+    real.last_trained_id = 0
+    real.lock = contextlib.nullcontext() if not hasattr(real, "lock") else real.lock
+    for step, important in enumerate((True, False)):
+        kid = step % 2
+        kf = real.keyframes[kid]
+        monkeypatch.setattr(real, "get_training_id", lambda kid=kid: kid, raising=False)
+        state, kfd, cfg = SO.snapshot(real, kid)
+        torch.manual_seed(200 + step)
+        bg = torch.rand(3)
+        o = SO.optimisation_step(state, kfd, cfg, bg, important, workers=1)
+        assert 0 < int(o["selected"].sum()) < N
+        got = {}
+        orig = real.optimizer.step
+
+        def spy(*a, _o=orig, **k):
+            got.update({kk: real.gaussian_params[kk]["val"].grad.clone() for kk in SO.GAUSS_KEYS})
+            got.update({"mlp." + n: p.grad.clone() for n, p in real.mlp_cov.named_parameters()})
+            got.update({"kf." + n: getattr(kf, n).grad.clone() for n in ("rW2C", "tW2C", "exposure")})
+            got["vis"], got["gvis"] = a[0].clone(), a[2].clone()
+            return _o(*a, **k)
+        monkeypatch.setattr(real.optimizer, "step", spy, raising=False)
+        torch.manual_seed(200 + step)
+        real.optimization_step(is_important=important)
+        monkeypatch.setattr(real.optimizer, "step", orig, raising=False)
+        assert torch.equal(got["vis"], o["visibility"]) and torch.equal(got["gvis"], o["global_visibility"])
+        inv = kf.latest_invdepth.double()
+        fin = torch.isfinite(o["invdepth"])
+        assert torch.equal(torch.isfinite(inv), fin) and float((inv - o["invdepth"])[fin].abs().max()) <= 1e-5 * float(o["invdepth"][fin].abs().max())
+        for k in SO.GAUSS_KEYS + SO.MLP_KEYS + SO.KF_KEYS:
+            x, y = got[k].double(), o["grads"][k]
+            assert x.shape == y.shape and float(y.abs().max()) > 0, k
+            assert float((x - y).norm() / y.norm()) <= 2e-5 and float((x - y).abs().max() / y.abs().max()) <= 2e-5, (step, k)
+
+
 def test_autofuse_refuses_a_host_method_that_moved(ref_module, monkeypatch, tmp_path, capsys):
     """A perturbed copy of the reference module (one constant of optimization_step changed): the post-import hook must leave
     the whole "step" group as ARTDECO wrote it -- natives only -- warn once, and still install the untouched "densify" group."""
