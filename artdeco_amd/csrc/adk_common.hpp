@@ -252,4 +252,55 @@ __device__ __forceinline__ Reduce20 wave_reduce20(const float (&A)[10], const fl
     return o;
 }
 
+// ROWS FIRST (round 5): the same 20 -> 2 transposing butterfly with the stages in the opposite order.  v_permlane32_swap / v_permlane16_swap
+// exchange between lane halves / row pairs AND keep their own half in one instruction, so a swap + one plain add folds TWO values; the
+// bank-masked DPP stages cost two cross-lane instructions per surviving value.  wave_reduce20 spends its 30 bank-masked DPP adds while there
+// are 20 and 10 values and its swaps on the last 5; here the swaps run on 20 and 10 values and the DPP stages on 5 -> 3 -> 2:
+//   stage 1  v_permlane32_swap(A[k], B[k]) + add      20 -> 10   lanes 0-31 keep splat A's value k, lanes 32-63 splat B's       (10 swaps + 10 adds)
+//   stage 2  v_permlane16_swap(R[k], R[k + 5]) + add  10 -> 5    rows 0 / 1 / 2 / 3 keep A_k / A_(k+5) / B_k / B_(k+5)          (5 swaps + 5 adds)
+//   stage 3  row_mirror, bank-masked adds              5 -> 3                                                                    (5 DPP adds)
+//   stage 4  row_half_mirror, bank-masked              3 -> 2                                                                    (3 DPP adds)
+//   stage 5,6  in-quad all-reduce of the 2 survivors                                                                             (4 DPP adds)
+// = 27 cross-lane instructions + 15 plain adds per PAIR against 39 + 7.  Result, lane = 16 r + 4 b + l: splat (r >> 1),
+//   z0 = the total of value (r & 1) * 5 + {0, 2, 1, 3}[b],   z1 = the total of value (r & 1) * 5 + 4   (in every lane of the bank).
+// Checked against a float64 sum by tools/lab/reduce_lab.py (variant 3).  EXEC must be all ones.
+__device__ __forceinline__ Reduce20 wave_reduce20_rows_first(const float (&A)[10], const float (&B)[10]) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    float R[10], Wv[5];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const u32x2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(A[k]), __float_as_uint(B[k]), false, false);
+        R[k] = __uint_as_float(s.x) + __uint_as_float(s.y);      // lanes 0-31: A[k] over both halves, lanes 32-63: B[k]
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[k]), __float_as_uint(R[k + 5]), false, false);
+        Wv[k] = __uint_as_float(s.x) + __uint_as_float(s.y);     // rows: A_k | A_(k+5) | B_k | B_(k+5), 16 per-lane partials each
+    }
+    float x0, x1, x2, y0, y1;
+    // one asm block per DPP stage (hipcc's hazard recogniser does not look into inline asm: a DPP read needs 2 wait states after a VALU write
+    // of the same register -- the s_nop 1 in front of each block; inside a block no instruction reads what the block wrote)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0xc"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2)
+        : "v"(Wv[0]), "v"(Wv[1]), "v"(Wv[2]), "v"(Wv[3]), "v"(Wv[4]));
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(y0), "=&v"(y1)
+        : "v"(x0), "v"(x1), "v"(x2));
+    // y0: bank 0 -> W0, bank 1 -> W2, bank 2 -> W1, bank 3 -> W3 (4 partials each); y1: every bank -> W4
+    y0 = dpp_add<0xB1>(y0); y1 = dpp_add<0xB1>(y1);   // quad_perm [1,0,3,2]
+    y0 = dpp_add<0x4E>(y0); y1 = dpp_add<0x4E>(y1);   // quad_perm [2,3,0,1]
+    Reduce20 o;
+    o.z0 = y0; o.z1 = y1;
+    return o;
+}
+
 } // namespace adk

@@ -11,6 +11,7 @@
 // caller's bookkeeping around one call.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -127,7 +128,7 @@ extern "C" int64_t adk_mapper_step_timings(double* sum_ms, double* min_ms, int64
 extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out, adk_stream_t stream)
 {
     if (A == nullptr || out == nullptr) return ADK_EINVAL;
-    out->n_isects = 0; out->max_tile = 0; out->stage = -1; out->reserved = 0;
+    out->n_isects = 0; out->max_tile = 0; out->stage = -1; out->reserved = 0; out->wait_ns = 0;
     const int N = A->N, W = A->width, H = A->height, tpw = A->tile_px_w, tph = A->tile_px_h;
     if (N <= 0 || A->V <= 0 || W <= 0 || H <= 0 || A->isect_capacity <= 0) return ADK_EINVAL;
     if (!adk_bin_local_supported_t(W, H, tpw, tph)) return ADK_STEP_EROUTE;
@@ -199,15 +200,20 @@ extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out
                                              static_cast<const int32_t*>(A->tiles_per_gauss), cf(A->rec), W, H, tpw, tph,
                                              static_cast<const int32_t*>(A->offsets), table, table_bytes, A->pairs, stream));
     }
+    const auto wait_t0 = std::chrono::steady_clock::now();
     if (hipEventSynchronize(slot->ready) != hipSuccess) { out->stage = STAGE_bin_count; return ADK_EINVAL; }   // the one host wait of the step
+    out->wait_ns = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - wait_t0).count();
     const int64_t n_isects = slot->host[0], max_tile = slot->host[1];
     out->n_isects = n_isects; out->max_tile = max_tile;
-    if (max_tile > 8192) return ADK_STEP_EROUTE;            // nothing of the caller's has been modified yet
+    // a tile list above 8 192 entries takes the long-list sort (round 5), which needs the second key buffer; only a list beyond ITS limit
+    // (4 M entries on one tile) still leaves for the global route.  Nothing of the caller's has been modified yet.
+    if (max_tile > 8192 && (A->pairs2 == nullptr || max_tile > adk_bin_local_sort_long_max())) return ADK_STEP_EROUTE;
     if (n_isects > A->isect_capacity) return ADK_STEP_ECAPACITY;
     {
         adk::StageScope ts(A, STAGE_bin_sort, stream);
-        ADK_STEP_TRY(STAGE_bin_sort, adk_bin_local_sort_t(n_isects, max_tile, W, H, tpw, tph, static_cast<const int32_t*>(A->offsets), A->pairs,
-                                                          static_cast<int32_t*>(A->flatten_ids), nullptr, stream));
+        ADK_STEP_TRY(STAGE_bin_sort, adk_bin_local_sort_long_t(n_isects, max_tile, W, H, tpw, tph, static_cast<const int32_t*>(A->offsets), A->pairs,
+                                                               A->pairs2, A->pairs2 ? A->isect_capacity * 8 : 0, static_cast<int32_t*>(A->flatten_ids),
+                                                               nullptr, stream));
     }
     {
         adk::StageScope ts(A, STAGE_raster_fwd, stream);

@@ -593,6 +593,136 @@ __global__ __launch_bounds__(512) void bin_tile_sort_merge_kernel(const unsigned
     }
 }
 
+// ---- lists ABOVE 8192 entries (round 5): no cliff.  gsplat's radix sort has no list-length limit (h3dgsv3.py:664-680 -> isect_tiles + sort),
+// and a trained map seen from close by, or any frame whose splats are several pixels wide, puts tens of thousands of entries on a tile; until
+// round 4 ONE such tile sent the whole frame to the global radix route and the step back to the per-stage Python chain.  Here one workgroup
+// per long tile sorts its segment by RECURSIVE MSD PARTITION ON THE KEY RANGE, ping-ponging between `pairs` and a scratch buffer of the
+// same size: a segment of more than 1 024 keys finds its smallest / largest 64-bit key, picks NB = the power of two >= count / 512 buckets
+// (4 .. 1 024) that split [min, max] evenly -- bucket = (key - min) >> shift --, counts (LDS atomics), scans, and scatters every key to its
+// bucket's region in the OTHER buffer; buckets of <= 1 024 keys are then sorted by one wave each in registers (the same bitonic networks as
+// every other list) straight into `flatten_ids`, larger ones go on an LDS stack and are partitioned again.  Deterministic termination: the
+// keys are unique, so max > min, the shift leaves at least log2(NB) - 1 significant bits of the range and the buckets of `min` and `max`
+// differ -- every child is strictly smaller than its parent, whatever the depth distribution (equal depths included: the ids split them).
+// Unique keys also make the result THE (tile, depth, id) order, bit for bit.  Writes by one wave are read by others of the same workgroup
+// through global memory: release fence, barrier, acquire fence (the vector L1 is not coherent with other CUs' stores, nor with this
+// workgroup's own rewrite of a buffer it read a level earlier).  Pending segments hold > 1 024 keys each, so a list of n keys never has more
+// than n / 1 024 of them on the stack: 4 096 slots = lists of up to 4 194 304 entries (BIN_SORT_LONG_MAX; the host knows the fullest tile).
+#define BIN_LONG_NB 1024
+#define BIN_LONG_STACK 4096
+#define BIN_SORT_LONG_MAX (BIN_LONG_STACK * 1024)
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long u = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        v = u < v ? u : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long u = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void wave_sort_any(const unsigned long long* buf, int64_t abs, int n, int lane, uint32_t t,
+                                              int32_t* __restrict__ flatten_ids, uint32_t* __restrict__ tile_ids)
+{
+    if (n <= 128) wave_sort_tile<2>(buf, abs, n, lane, t, flatten_ids, tile_ids);
+    else if (n <= 256) wave_sort_tile<4>(buf, abs, n, lane, t, flatten_ids, tile_ids);
+    else if (n <= 512) wave_sort_tile<8>(buf, abs, n, lane, t, flatten_ids, tile_ids);
+    else wave_sort_tile<16>(buf, abs, n, lane, t, flatten_ids, tile_ids);
+}
+
+__global__ __launch_bounds__(512) void bin_tile_sort_long_kernel(unsigned long long* pairs, unsigned long long* scratch, const int32_t* __restrict__ offsets,
+                                                                 int n_tiles, int64_t n_isects, int32_t* __restrict__ flatten_ids,
+                                                                 uint32_t* __restrict__ tile_ids)
+{
+    __shared__ uint32_t cnt[BIN_LONG_NB];          // bucket counts, then the scatter's cursors
+    __shared__ uint32_t off[BIN_LONG_NB + 1];      // bucket starts inside the segment
+    __shared__ uint32_t stk_start[BIN_LONG_STACK]; // pending segments: start inside the tile's list ...
+    __shared__ uint32_t stk_count[BIN_LONG_STACK]; // ... and count | buffer << 31 (0: pairs, 1: scratch)
+    __shared__ unsigned long long red_min[8], red_max[8];
+    __shared__ uint32_t wsum[8];
+    __shared__ int sp;
+    const int t = blockIdx.x;
+    const int64_t s = offsets[t];
+    const int64_t e = (t == n_tiles - 1) ? n_isects : (int64_t)offsets[t + 1];
+    const int64_t n64 = e - s;
+    if (n64 <= BIN_SORT_BIG || n64 > BIN_SORT_LONG_MAX) return; // workgroup-uniform; shorter lists belong to the other kernels
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if (tid == 0) { stk_start[0] = 0u; stk_count[0] = (uint32_t)n64; sp = 1; }
+    __syncthreads();
+    while (true) {
+        const int top = sp;                          // uniform: read between barriers
+        if (top == 0) break;
+        const uint32_t seg0 = stk_start[top - 1], cw = stk_count[top - 1];
+        __syncthreads();                             // everyone has read the entry before it is overwritten
+        if (tid == 0) sp = top - 1;
+        const int count = (int)(cw & 0x7FFFFFFFu);
+        const unsigned long long* src = ((cw >> 31) ? scratch : pairs) + s + seg0;
+        unsigned long long* const dst_base = (cw >> 31) ? pairs : scratch;
+        unsigned long long* dst = dst_base + s + seg0;
+        // -- key range of the segment
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (int i = tid; i < count; i += 512) { const unsigned long long k = src[i]; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+        lo = wave_min_u64(lo); hi = wave_max_u64(hi);
+        if (lane == 0) { red_min[wv] = lo; red_max[wv] = hi; }
+        int nb_log = 2;
+        while ((1 << nb_log) < BIN_LONG_NB && (512 << nb_log) < count) ++nb_log;
+        const int NB = 1 << nb_log;
+        for (int b = tid; b < NB; b += 512) cnt[b] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { lo = red_min[w] < lo ? red_min[w] : lo; hi = red_max[w] > hi ? red_max[w] : hi; }
+        const unsigned long long range = hi - lo;    // >= 1: the keys are unique and count > 1
+        const int bits = 64 - __clzll((long long)range);
+        const int shift = bits > nb_log ? bits - nb_log : 0;
+        // -- count, scan
+        for (int i = tid; i < count; i += 512) atomicAdd(&cnt[(uint32_t)((src[i] - lo) >> shift)], 1u);
+        __syncthreads();
+        {   // exclusive scan of cnt[0 .. NB): thread tid owns entries 2 tid, 2 tid + 1 (NB <= 1024 = 2 x 512)
+            const uint32_t a = 2 * tid < NB ? cnt[2 * tid] : 0u, b = 2 * tid + 1 < NB ? cnt[2 * tid + 1] : 0u;
+            uint32_t x = a + b;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += u; }
+            if (lane == 63) wsum[wv] = x;
+            __syncthreads();
+            uint32_t base = x - (a + b);
+            for (int w = 0; w < wv; ++w) base += wsum[w];
+            if (2 * tid < NB) { off[2 * tid] = base; cnt[2 * tid] = base; }
+            if (2 * tid + 1 < NB) { off[2 * tid + 1] = base + a; cnt[2 * tid + 1] = base + a; }
+            if (tid == 0) off[NB] = (uint32_t)count;
+        }
+        __syncthreads();
+        // -- scatter to the other buffer (order inside a bucket is arbitrary: it is sorted or partitioned next)
+        for (int i = tid; i < count; i += 512) {
+            const unsigned long long k = src[i];
+            dst[atomicAdd(&cnt[(uint32_t)((k - lo) >> shift)], 1u)] = k;
+        }
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+        // -- children: small ones are sorted now (bucket b by wave b mod 8), large ones are pushed (thread 0, in bucket order)
+        if (tid == 0) {
+            int p = sp;
+            for (int b = 0; b < NB; ++b) {
+                const uint32_t c = off[b + 1] - off[b];
+                if (c > BIN_SORT_WAVE) { stk_start[p] = seg0 + off[b]; stk_count[p] = c | ((cw >> 31) ? 0u : 0x80000000u); ++p; }
+            }
+            sp = p;
+        }
+        for (int b = wv; b < NB; b += 8) {
+            const int c = (int)(off[b + 1] - off[b]);
+            if (c > 0 && c <= BIN_SORT_WAVE) wave_sort_any(dst_base, s + seg0 + off[b], c, lane, (uint32_t)t, flatten_ids, tile_ids);
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace adk
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -808,6 +938,29 @@ extern "C" int adk_bin_local_sort_t(int64_t n_isects, int64_t max_tile, int widt
     }
     ADK_RETURN_LAST_ERROR();
 }
+// adk_bin_local_sort_t for ANY list length up to 4 194 304 entries per tile: the same kernels for the tiles of up to 8 192 entries, and
+// bin_tile_sort_long_kernel for the longer ones.  `pairs` is read AND overwritten (the long tiles ping-pong between it and `scratch`,
+// adk_bin_local_pairs_bytes(capacity of pairs) bytes, 8 B aligned); the other tiles' segments are left as they were.
+extern "C" int adk_bin_local_sort_long_t(int64_t n_isects, int64_t max_tile, int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets,
+                                         void* pairs, void* scratch, int64_t scratch_bytes, int32_t* flatten_ids, uint32_t* tile_ids, hipStream_t stream)
+{
+    using namespace adk;
+    if (n_isects < 0 || width <= 0 || height <= 0 || !offsets || !tile_shape_ok(tile_px_w, tile_px_h)) return ADK_EINVAL;
+    if (n_isects == 0) return 0;
+    if (max_tile > BIN_SORT_LONG_MAX || n_isects >= ((int64_t)1 << 31)) return ADK_EUNSUPPORTED;
+    if (!pairs || !flatten_ids) return ADK_EINVAL;
+    const int rc = adk_bin_local_sort_t(n_isects, max_tile < BIN_SORT_BIG ? max_tile : BIN_SORT_BIG, width, height, tile_px_w, tile_px_h, offsets, pairs,
+                                        flatten_ids, tile_ids, stream);
+    if (rc != 0 || max_tile <= BIN_SORT_BIG) return rc;
+    if (!scratch || ((uintptr_t)scratch & 7) || scratch_bytes < n_isects * 8) return ADK_EWORKSPACE;
+    const WideGrid g = wide_grid(width, height, tile_px_w, tile_px_h);
+    const int n_tiles = g.wide_w * g.wide_h;
+    hipLaunchKernelGGL(bin_tile_sort_long_kernel, dim3(n_tiles), dim3(512), 0, stream, (unsigned long long*)pairs, (unsigned long long*)scratch, offsets,
+                       n_tiles, n_isects, flatten_ids, tile_ids);
+    ADK_RETURN_LAST_ERROR();
+}
+extern "C" int64_t adk_bin_local_sort_long_max(void) { return BIN_SORT_LONG_MAX; }
+
 extern "C" int adk_bin_local_sort(int64_t n_isects, int64_t max_tile, int width, int height, const int32_t* offsets, const void* pairs,
                                   int32_t* flatten_ids, uint32_t* tile_ids, hipStream_t stream)
 {

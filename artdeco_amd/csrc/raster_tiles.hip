@@ -58,6 +58,12 @@ namespace adk {
 #ifndef ADK_BWD_LEAN
 #define ADK_BWD_LEAN 1
 #endif
+// Round 5: the paired reduction with its row stages (permlane swaps: one cross-lane instruction per TWO values) in front of the in-row DPP
+// stages (two per surviving value) instead of behind them: 27 cross-lane instructions + 15 adds per pair against 39 + 7 (adk_common.hpp:
+// wave_reduce20_rows_first).  0 = round 4's order.
+#ifndef ADK_BWD_ROWS_FIRST
+#define ADK_BWD_ROWS_FIRST 1
+#endif
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
@@ -388,9 +394,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
     {
         const int r = lane >> 4, b = (lane >> 2) & 3, l = lane & 3;
         pk_use_z1 = (l == 1);
+#if ADK_BWD_ROWS_FIRST
+        // after wave_reduce20_rows_first: row r serves splat r >> 1 and sums (r & 1) * 5 + ..., bank b holds sum {0, 2, 1, 3}[b] (z0) and sum 4 (z1)
+        pk_active = (l == 0) || (l == 1 && b == 0);
+        pk_is_b = (r >> 1) != 0;
+        const int slot = (r & 1) * 5 + (pk_use_z1 ? 4 : ((b == 1) ? 2 : (b == 2 ? 1 : b)));
+#else
         pk_active = (l == 0) || (l == 1 && r == 0);
         pk_is_b = (b >> 1) != 0;
         const int slot = (b & 1) * 5 + (pk_use_z1 ? 4 : ((r == 1) ? 2 : (r == 2 ? 1 : r)));
+#endif
         pk_dword = acc_to_rec(slot);
         pk_is_opacity = pk_dword == 2;
         pk_scale = pk_dword >= 8 ? 1.0f : ((pk_dword == 4 || pk_dword == 6) ? -0.5f : -1.0f);
@@ -596,7 +609,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
                 if (eval_splat(t2, acc2, inv_opac2)) { paired = true; break; }
             }
             if (paired) {
+#if ADK_BWD_ROWS_FIRST
+                const Reduce20 red = wave_reduce20_rows_first(acc, acc2);
+#else
                 const Reduce20 red = wave_reduce20(acc, acc2);
+#endif
                 touched_mask |= (1ull << t) | (1ull << t2);
                 if (pk_active) {
                     const float v = pk_use_z1 ? red.z1 : red.z0;

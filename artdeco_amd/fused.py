@@ -1175,6 +1175,15 @@ def freeze_gc(force: bool = True) -> None:
     _GC_FROZEN = True
 
 
+def unfreeze_gc() -> None:
+    """Undo freeze_gc(): the permanent generation goes back to the oldest one (a host program that wants to compare the two)."""
+    global _GC_FROZEN
+    if _GC_FROZEN:
+        import gc
+        gc.unfreeze()
+        _GC_FROZEN = False
+
+
 def _centre_is_image_centre(scene) -> bool:
     """fused_add_new_gaussians back-projects with the principal point ((W - 1) / 2, (H - 1) / 2), which is what SceneModel.__init__
     puts into `self.centre` (h3dgsv3.py:89) -- a constructor the source pins do not cover.  One host read, once per patched scene:

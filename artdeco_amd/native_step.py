@@ -9,7 +9,8 @@ bit-identical to the per-stage chain (tests/test_native_step.py).  The optimiser
 stay with `fused._apply_steps`: they read the gradients from `.grad`, which this module points at the plan's buffers.
 
 Falls back to the per-stage chain (returns None, nothing modified) when a tensor is not in run.sh's layout, when a leaf already
-carries a gradient (the chain accumulates), or when the frame needs the global binning route (a tile list above 8 192 entries).
+carries a gradient (the chain accumulates), or when the frame needs the global binning route (a tile list above 4 194 304 entries: lists
+above 8 192 take the long-list sort inside the call since round 5).
 `ARTDECO_AMD_NATIVE_STEP=0` disables it.
 """
 from __future__ import annotations
@@ -47,7 +48,8 @@ class StepArgs(ctypes.Structure):
 
 
 class StepOut(ctypes.Structure):
-    _fields_ = [("n_isects", ctypes.c_int64), ("max_tile", ctypes.c_int64), ("stage", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+    _fields_ = [("n_isects", ctypes.c_int64), ("max_tile", ctypes.c_int64), ("stage", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("wait_ns", ctypes.c_int64)]
 
 
 _checked = False
@@ -74,7 +76,7 @@ def _round_cap(n: int) -> int:
 
 
 _NW = 32 * 32 + 32 + 7 * 32 + 7
-STATS = {"native": 0, "fallback_layout": 0, "fallback_route": 0, "capacity_retries": 0, "plans_built": 0}
+STATS = {"native": 0, "fallback_layout": 0, "fallback_route": 0, "capacity_retries": 0, "plans_built": 0, "long_list_steps": 0, "wait_ns": 0}
 
 
 _N_GRAIN = int(os.environ.get("ARTDECO_AMD_PLAN_GRAIN", 1 << 16))   # 1 = exact sizes (a plan per N: the lab's A/B)
@@ -160,8 +162,10 @@ class StepPlan:
     def set_capacity(self, capacity: int) -> None:
         cap = _round_cap(capacity)
         self.t["pairs"] = torch.empty(cap, dtype=torch.int64, device=self.dev)
+        self.t["pairs2"] = torch.empty(cap, dtype=torch.int64, device=self.dev)   # tile lists above 8 192 entries ping-pong between the two
         self.t["flatten_ids"] = torch.empty(cap, dtype=torch.int32, device=self.dev)
         self.args.pairs = self.t["pairs"].data_ptr()
+        self.args.pairs2 = self.t["pairs2"].data_ptr()
         self.args.flatten_ids = self.t["flatten_ids"].data_ptr()
         self.args.isect_capacity = cap
 
@@ -312,6 +316,9 @@ def train_on_keyframe(scene, keyframe, is_important):
         _lib.check(rc, f"adk_mapper_step (stage {stage})")
     plan.route_miss = 0
     STATS["native"] += 1
+    STATS["wait_ns"] += int(plan.out.wait_ns)
+    if plan.out.max_tile > 8192:
+        STATS["long_list_steps"] += 1      # a tile list above 8 192 entries: sorted by the long-list kernel inside the call (round 5)
     n_isects = int(plan.out.n_isects)
     rasterizer._CAPACITY_HINT[(dev.index, W, H, tile_px[0])] = n_isects
     rasterizer.LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=tile_px)

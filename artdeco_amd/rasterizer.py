@@ -186,7 +186,8 @@ def _isect_capacity_guess(dev: torch.device, N: int, W: int, H: int, tpw: int = 
 
 def _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids, tiles_per_gauss, dev, stream, i32):
     """The global route: radix sort of the N depth keys, emit in depth order, stable radix sort by tile (raster_bin.hip).  Used when
-    the tile histogram does not fit LDS (> 32768 tiles), when a tile holds more than 8192 entries, or with ADK_BIN_LOCAL=0."""
+    the tile histogram does not fit LDS (> 32768 tiles), when a tile holds more than 4 194 304 entries (lists above 8 192 take the long-list
+    sort of the tile-local route since round 5; ADK_BIN_LONG=0 sends them here as before), or with ADK_BIN_LOCAL=0."""
     # The list size only depends on the projection: count it now, start its copy to pinned host memory,
     # and read it AFTER the depth sort has been enqueued -- the host waits for the count (an event), not
     # for the sort, so the stream never drains (upstream syncs on n_isects after isect_tiles).
@@ -258,8 +259,8 @@ def _bin_lists(lib, cfg, tile_px, want_tile_ids, N, W, H, rec, depth_keys, gauss
         count_ready.synchronize()  # the one host wait of the pipeline
         n_isects, max_tile = int(host_count[0]), int(host_count[1])
         _CAPACITY_HINT[(dev.index, W, H, tpw)] = n_isects   # keyed on the image only: one entry per resolution however the map grows
-        if max_tile > 8192:
-            use_local = False      # a tile list too long for the in-LDS sort: global route below (16x16 lists)
+        if max_tile > int(lib.adk_bin_local_sort_long_max()) or (max_tile > 8192 and os.environ.get("ADK_BIN_LONG", "1") == "0"):
+            use_local = False      # beyond the long-list sort's limit (4 M entries on one tile): global route below (16x16 lists)
             tpw, tph = 16, 16
         else:
             if n_isects > pairs.numel():   # the estimate was too small (first call / the map grew by > 25 %): scatter again
@@ -271,10 +272,12 @@ def _bin_lists(lib, cfg, tile_px, want_tile_ids, N, W, H, rec, depth_keys, gauss
                 LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(tpw, tph))
             flatten_ids = _empty_rounded(n_isects, **i32)
             tile_ids = _empty_rounded(n_isects, **i32) if want_tile_ids else None
+            # tile lists above 8 192 entries are sorted by recursive partition between `pairs` and a second buffer (round 5: no list-length cliff)
+            scratch = _empty_rounded(n_isects, dtype=torch.int64, device=dev) if max_tile > 8192 else None
             with _stage("bin_sort"):
-                rc = lib.adk_bin_local_sort_t(n_isects, max_tile, W, H, tpw, tph, offsets.data_ptr(), pairs.data_ptr(),
-                                              flatten_ids.data_ptr(), _lib.ptr(tile_ids), stream)
-            _lib.check(rc, "adk_bin_local_sort")
+                rc = lib.adk_bin_local_sort_long_t(n_isects, max_tile, W, H, tpw, tph, offsets.data_ptr(), pairs.data_ptr(), _lib.ptr(scratch),
+                                                   0 if scratch is None else scratch.numel() * 8, flatten_ids.data_ptr(), _lib.ptr(tile_ids), stream)
+            _lib.check(rc, "adk_bin_local_sort_long")
     if not use_local:
         flatten_ids, tile_ids, offsets, n_isects = _bin_global(lib, cfg, N, W, H, (W + 15) // 16, (H + 15) // 16, rec, depth_keys, gauss_ids,
                                                                tiles_per_gauss, dev, stream, i32)

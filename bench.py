@@ -208,10 +208,13 @@ def main():
     glue = "torch (unchanged host code)"
     if not args.unfused_glue and fused.patch_scene_model(scene):
         glue = "artdeco_amd.fused (HIP kernels behind render / optimization_step / add_new_gaussians / add_and_prune / update_voxel)"
-    fused.freeze_gc()   # the host program's own choice (DESIGN finding 5b); the library never does it on its own
+    # `value` is measured with the interpreter as an unmodified run_system.py leaves it: NO gc.freeze() (the library never freezes on its
+    # own; DESIGN finding 5b prices what a generation-2 collection costs).  `with_gc_freeze` below times the next
+    # frames of the same sequence after fused.freeze_gc(), the host program's one-line opt-in (ARTDECO_AMD_GC_FREEZE=1 does the same).
     cadence = dict(kf_every=args.kf_every, slam_every=args.slam_every, test_hold=args.test_hold)
     n_detail = 10 if world == 1 else 0
-    frames = stream.synthetic_frames(scene, args.warmup + args.steps + n_detail, seed=rank, texture=args.texture)  # resident in HBM
+    n_frozen = args.steps if world == 1 else 0
+    frames = stream.synthetic_frames(scene, args.warmup + args.steps + n_frozen + n_detail, seed=rank, texture=args.texture)  # resident in HBM
 
     def sync_all():
         multigpu.barrier(dev)
@@ -235,9 +238,16 @@ def main():
     stages_timed = timer.summary_ms()
     rasterizer.set_stage_timer(None)
     frame_stages, stages = {}, {}
+    frozen = None
+    if n_frozen:
+        fused.freeze_gc()
+        k0 = args.warmup + args.steps
+        frozen = stream.run_stream(scene, frames[k0:k0 + n_frozen], start_index=k0, **cadence)
+        fused.unfreeze_gc()   # everything reported after this runs with the interpreter's default again
     if n_detail:
         # untimed: the loop's stages bracketed by device synchronisations, then the kernels of the optimisation step by HIP events
-        frame_stages = stream.run_stream(scene, frames[args.warmup + args.steps:], start_index=args.warmup + args.steps, breakdown=True,
+        k0 = args.warmup + args.steps + n_frozen
+        frame_stages = stream.run_stream(scene, frames[k0:], start_index=k0, breakdown=True,
                                          **cadence)["stage_ms"]
         detail = rasterizer.StageTimer()
         rasterizer.set_stage_timer(detail)
@@ -279,10 +289,11 @@ def main():
                                    "optimisation steps); frames observe the map itself plus unexplained texture; one independent scene per GPU",
                        "gaussians_start": int(timed["gaussians_start"]), "gaussians_end": int(timed["gaussians_end"]),
                        "width": args.width, "height": args.height, "pyr_levels": 1,
-                       "keyframes_at_start": args.warmup,   # the timed frames are frames [warmup, warmup + steps) of a FRESH sequence; see `late_windows`
+                       "keyframes_at_start": args.warmup,   # the timed frames are frames [warmup, warmup + steps) of a FRESH sequence; see `full_sequence`
                        "sequence_position": f"frames {args.warmup}-{args.warmup + args.steps} of a fresh sequence (the cheapest part of it: the reference script's "
-                                            "per-keyframe SLAM pose loop, run_system.py:194-227, grows with the number of keyframes -- `late_windows` has the "
-                                            "same loop at frames 280-300 and 980-1000)",
+                                            "per-keyframe SLAM pose loop, run_system.py:194-227, grows with the number of keyframes -- `full_sequence` runs "
+                                            "BASELINE's 300- and 1 000-frame sequences start to finish)",
+                       "python_gc": "default (no gc.freeze()): what an unmodified run_system.py gets; see `with_gc_freeze`",
                        "cadence": {**cadence, "use_all_frames": True, "num_key_iterations": 20, "num_common_iterations": 10},
                        "important_frame_fraction": sum(f["is_important"] for f in flags) / len(flags),
                        "densified_frames": sum(f["is_important"] and not f["is_test"] for f in flags),
@@ -322,14 +333,18 @@ def main():
                 busy = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / (1024 * bwd_ms * 1e-3 * 2.4e9)
                 out["roofline_valu"]["valu_busy"] = busy
                 out["roofline_valu"]["cycles_per_valu_inst"] = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / valu
+        if frozen is not None:
+            out["with_gc_freeze"] = {"frames_per_s": frozen["frames"] / frozen["seconds"], "frames": frozen["frames"],
+                                     "sequence_position": f"frames {args.warmup + args.steps}-{args.warmup + args.steps + n_frozen} of the same sequence",
+                                     "note": "after fused.freeze_gc() (the host program's opt-in, ARTDECO_AMD_GC_FREEZE=1): no generation-2 "
+                                             "collection walks the process's long-lived objects between optimisation steps"}
         del scene, frames
         torch.cuda.empty_cache()
         if not args.no_extra_configs and world == 1:
+            out["full_sequence"] = full_sequence(args, dev)
             out["other_configs"] = extra_configs(args, dev)
         if world == 1:
             out["frame_delivery"] = frame_delivery(args, dev, elapsed_max / args.steps * 1e3)
-        if not args.no_extra_configs and world == 1:
-            out["late_windows"] = late_windows(args, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, timed["steps"] / args.steps)
             out["psnr_proxy"] = psnr_proxy(dev)
@@ -497,52 +512,46 @@ def _stream_fps(n, w, h, dev, use_fused, lod, args, pyr_levels=1, warm=6, timed=
     return res
 
 
-def _late_window(n, w, h, dev, args, keyframes_at_start, timed=20, warm=2, batched=False, pyr_levels=1):
-    """frames/s of the mapper loop LATE in a sequence: the scene already holds `keyframes_at_start` keyframes (with --use_all_frames
-    every mapped frame so far is one, run_system.py:230), then `warm` untimed and `timed` timed frames with the headline's cadence,
-    frame indices continuing from `keyframes_at_start`.  What grows with the sequence is the reference script's own SLAM-keyframe
-    loop (run_system.py:194-227: every keyframe's pose re-read, three 4x4 inversions each), which no drop-in reaches; `batched` =
-    the same loop as ONE batched call (artdeco_amd/keyframe_poses.py), i.e. what the INTEGRATION section 3c edit of run_system.py gives."""
+def _full_sequence(n, w, h, dev, args, n_frames, batched, distinct=48):
+    """The reference's FPS over a WHOLE sequence (run_system.py:139,276 + h3dgsv3.py:1129-1132: len(dataset) / wall-seconds of the mapper
+    loop), frame 0 to frame n_frames - 1 of a fresh scene, nothing fast-forwarded: every Keyframe build, every SLAM-keyframe pose re-read
+    over ALL keyframes so far (run_system.py:194-227, linear in the sequence position), every densification, 20 / 10 optimisation steps per
+    frame.  The synthetic stream cycles through `distinct` pre-rendered frames (resident in HBM; building 1 000 distinct ones would take longer
+    than the run).  batched = the SLAM-keyframe loop as ONE batched call (artdeco_amd/keyframe_poses.py, the INTEGRATION section 3c edit)."""
     from artdeco_amd import fused
     from harness import mapper, stream
     scene = mapper.build_synthetic_mapper(n, w, h, dev, seed=0, n_keyframes=0, targets="random")
     fused.patch_scene_model(scene)
     cadence = dict(kf_every=args.kf_every, slam_every=args.slam_every, test_hold=args.test_hold)
-    frames = stream.synthetic_frames(scene, warm + timed, seed=0, texture=args.texture)
+    base = stream.synthetic_frames(scene, min(distinct, n_frames), seed=0, texture=args.texture)
+    frames = [base[j % len(base)] for j in range(n_frames)]
     np.random.seed(0)
     stream.warm_process(dev)
-    stream.fast_forward(scene, frames, keyframes_at_start, start_index=0, pyr_levels=pyr_levels, **cadence)
-    k0 = keyframes_at_start
-    stream.run_stream(scene, frames[:warm], start_index=k0, pyr_levels=pyr_levels, batched_slam_update=batched, **cadence)
-    r = stream.run_stream(scene, frames[warm:], start_index=k0 + warm, pyr_levels=pyr_levels, batched_slam_update=batched, breakdown=False, **cadence)
-    flags = [stream.frame_flags(i, **cadence) for i in range(k0 + warm, k0 + warm + timed)]
-    # one more SLAM-keyframe pose update, timed alone (device-synchronised): what ONE such frame pays at this sequence length
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    (stream.slam_pose_update_batched if batched else stream.slam_pose_update)(scene, seed=1)
-    torch.cuda.synchronize()
-    slam_ms = (time.perf_counter() - t0) * 1e3
-    res = {"keyframes_at_start": k0 + warm, "frames": r["frames"], "frames_per_s": r["frames"] / r["seconds"],
-           "ms_per_frame": r["seconds"] / r["frames"] * 1e3, "slam_keyframes_in_window": sum(f["is_slam_keyframe"] for f in flags),
-           "optimisation_steps": r["steps"], "slam_pose_update_ms_per_slam_keyframe": slam_ms,
+    r = stream.run_stream(scene, frames, start_index=0, batched_slam_update=batched, marks_every=20, **cadence)
+    marks = [0.0] + r["marks"]
+    per_100 = [round(100 / (marks[i + 5] - marks[i]), 2) for i in range(0, len(marks) - 5, 5)]
+    res = {"frames": r["frames"], "seconds": r["seconds"], "frames_per_s": r["frames"] / r["seconds"],
+           "frames_per_s_per_100_frames": per_100, "frames_per_s_last_20_frames": 20 / (marks[-1] - marks[-2]),
+           "optimisation_steps": r["steps"], "important_frames": r["important_frames"], "densified_frames": r["densified_frames"],
+           "gaussians_start": r["gaussians_start"], "gaussians_end": r["gaussians_end"], "gaussians_added": r["gaussians_added"],
+           "keyframes_at_end": len(scene.keyframes), "python_gc": "default (no gc.freeze())" if not fused._GC_FROZEN else "frozen earlier in this process",
            "slam_pose_update": "batched (requires the INTEGRATION section 3c edit of run_system.py)" if batched else "run_system.py:194-227 as written (per-keyframe loop)"}
-    del scene, frames
+    del scene, frames, base
     torch.cuda.empty_cache()
     return res
 
 
-def late_windows(args, dev):
-    """Where in the sequence `value` was measured matters (DESIGN finding 27): BASELINE configs name 300 (PINGPONG), 1 000 and 2 000
-    frames.  The same frame loop on windows that END where those sequences end, as ARTDECO's script runs it and with its SLAM-keyframe
-    loop batched."""
+def full_sequence(args, dev):
+    """`value` times frames 8-48 of a fresh sequence; BASELINE's configs name 300 (PINGPONG, configs[1]) and 1 000 frames (configs[2]).  Here
+    both sequences run START TO FINISH, once with the reference script's per-keyframe SLAM loop as written and once with it batched."""
     res = {}
-    cases = [("north-star target 1M Gaussians 512x384, frames 280-300 of PINGPONG's 300", 1_000_000, 512, 384, 278),
-             (f"headline config {args.gaussians} Gaussians {args.width}x{args.height}, frames 980-1000 of configs[2]'s 1 000", args.gaussians, args.width, args.height, 978)]
-    for name, n, w, h, k0 in cases:
+    cases = [("configs[1] / north-star: PINGPONG's 300 frames, 1M Gaussians 512x384", 1_000_000, 512, 384, 300),
+             (f"configs[2]: 1 000 frames, {args.gaussians} Gaussians {args.width}x{args.height}", args.gaussians, args.width, args.height, 1000)]
+    for name, n, w, h, nf in cases:
         for batched in (False, True):
             key = name + (" -- SLAM-keyframe loop BATCHED (requires the INTEGRATION 3c edit)" if batched else "")
             try:
-                res[key] = _late_window(n, w, h, dev, args, k0, batched=batched)
+                res[key] = _full_sequence(n, w, h, dev, args, nf, batched)
             except Exception as e:  # report, never hide
                 res[key] = {"error": repr(e)[:300]}
     return res

@@ -205,9 +205,12 @@ def fast_forward(scene, frames, n_keyframes, *, start_index=0, test_hold=8, pyr_
     torch.cuda.synchronize()
 
 
-def run_stream(scene, frames, *, start_index=0, breakdown=False, kf_every=5, slam_every=15, test_hold=8, pyr_levels=1, **kw):
-    """Feed `frames` through the loop.  Returns dict(seconds, frames, steps, important, added, stage_ms (breakdown only))."""
+def run_stream(scene, frames, *, start_index=0, breakdown=False, kf_every=5, slam_every=15, test_hold=8, pyr_levels=1, marks_every=0, **kw):
+    """Feed `frames` through the loop.  Returns dict(seconds, frames, steps, important, added, stage_ms (breakdown only)).
+    marks_every = k: also `marks` = host wall-seconds since the start after every k-th frame (no synchronisation: the host is never more
+    than one optimisation step ahead of the device, since every step waits for its intersection count)."""
     clock = StageClock(breakdown)
+    marks = []
     n0 = scene.xyz.shape[0]
     steps = important = densified = 0
     added = [0]
@@ -226,6 +229,8 @@ def run_stream(scene, frames, *, start_index=0, breakdown=False, kf_every=5, sla
         steps += run_frame(scene, fr, len(scene.keyframes), fl, clock, pyr_levels=pyr_levels, **kw)
         important += int(fl["is_important"])
         densified += int(fl["is_important"] and not fl["is_test"])
+        if marks_every and (j + 1) % marks_every == 0:
+            marks.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     opt.add_and_prune = inner
@@ -233,4 +238,6 @@ def run_stream(scene, frames, *, start_index=0, breakdown=False, kf_every=5, sla
                gaussians_start=n0, gaussians_end=int(scene.xyz.shape[0]), gaussians_added=added[0])
     if breakdown:
         out["stage_ms"] = clock.summary_ms(len(frames))
+    if marks_every:
+        out["marks"] = marks
     return out

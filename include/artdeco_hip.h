@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 16
+#define ADK_ABI_VERSION 17
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -214,6 +214,14 @@ int adk_bin_local_scatter_t(int N, int64_t capacity, const uint32_t* depth_keys,
                             int64_t workspace_bytes, void* pairs, adk_stream_t stream);
 int adk_bin_local_sort_t(int64_t n_isects, int64_t max_tile, int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets,
                          const void* pairs, int32_t* flatten_ids, uint32_t* tile_ids, adk_stream_t stream);
+/* adk_bin_local_sort_t WITHOUT the 8 192-entry limit (round 5; gsplat's isect_tiles + radix sort have none, h3dgsv3.py:664-680): tiles of up to
+ * 8 192 entries as before, longer ones -- up to adk_bin_local_sort_long_max() = 4 194 304 entries per tile -- by one workgroup each that
+ * partitions the tile's segment recursively on the key range, ping-ponging between `pairs` and `scratch`, and sorts the pieces in registers.
+ * `pairs` is therefore READ AND OVERWRITTEN; scratch: scratch_bytes >= 8 * n_isects, 8 B aligned (NULL allowed while max_tile <= 8 192).
+ * Same (tile, depth, id) order, bit for bit.  max_tile above the limit: ADK_EUNSUPPORTED (global route). */
+int adk_bin_local_sort_long_t(int64_t n_isects, int64_t max_tile, int width, int height, int tile_px_w, int tile_px_h, const int32_t* offsets,
+                              void* pairs, void* scratch, int64_t scratch_bytes, int32_t* flatten_ids, uint32_t* tile_ids, adk_stream_t stream);
+int64_t adk_bin_local_sort_long_max(void);
 /* Optional: rebuild upstream's sorted int64 isect_ids for meta['isect_ids']. */
 int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int32_t* flatten_ids,
                            const uint32_t* depth_keys, int64_t* isect_ids, adk_stream_t stream);
@@ -613,10 +621,12 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
  *                gradients v_* the optimisers read: v_means (= gradient of xyz, LoD fade term included), v_opacity_raw, v_scaling_raw,
  *                v_rotation, v_local_feat, v_global_feat, v_mlp [1287] = dW1 | db1 | dW2 | db2, v_exposure [12], v_r6 [6], v_t [3];
  *                v_dc / v_rest only without color_adam.  cam_grad: 16 floats zeroed once by the caller (left zeroed by the call);
- *                pairs [isect_capacity] 8 B keys, flatten_ids [isect_capacity]; bin_table: adk_bin_local_workspace_bytes_t + 256 bytes.
+ *                pairs [isect_capacity] 8 B keys, pairs2 [isect_capacity] (the long tile lists' ping-pong buffer, adk_bin_local_sort_long_t; may be
+ *                NULL), flatten_ids [isect_capacity]; bin_table: adk_bin_local_workspace_bytes_t + 256 bytes.
  * Return: ADK_OK; ADK_STEP_ECAPACITY when the frame has more intersections than isect_capacity (out->n_isects says how many: grow
- * pairs / flatten_ids and call again); ADK_STEP_EROUTE when a tile list is too long for the tile-local sort (out->max_tile > 8192:
- * use the per-stage calls with the global route).  Both are decided BEFORE anything the caller owns has been modified.  Any other
+ * pairs / pairs2 / flatten_ids and call again); ADK_STEP_EROUTE when a tile list is too long for the tile-local sort (out->max_tile above
+ * adk_bin_local_sort_long_max(), or above 8 192 with pairs2 == NULL: use the per-stage calls with the global route).  Both are decided
+ * BEFORE anything the caller owns has been modified.  Any other
  * negative value: the failing stage's own code, out->stage = its index in ADK_MAPPER_STAGES.
  * ssim_grad_scale = -lambda_dssim / (3 W H), formed by the caller in double precision as the per-stage binding does (adk_fused_ssim_bwd's
  * dL_scalar).  time_mask: bit s set = bracket stage s with a pair of events (adk_mapper_step_timings folds and frees them). */
@@ -628,7 +638,7 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
     P(f_dc) P(f_rest) P(exp_avg_dc) P(exp_avg_sq_dc) P(exp_avg_rest) P(exp_avg_sq_rest) P(lr_dc) P(lr_rest) \
     P(loss) P(invdepth) \
     P(viewmat) P(opac) P(scale) P(quat) P(sel) P(rec) P(radii) P(depth_keys) P(gauss_ids) P(tiles_per_gauss) \
-    P(offsets) P(bin_stats) P(bin_table) P(pairs) P(flatten_ids) \
+    P(offsets) P(bin_stats) P(bin_table) P(pairs) P(pairs2) P(flatten_ids) \
     P(render_colors) P(render_alphas) P(final_T) P(last_ids) P(vis) P(gvis) \
     P(image) P(gt_used) P(dm) P(parts) P(ssim_sums) P(photo_ws) P(v_img) P(v_col) P(v_alpha) P(v_exposure) \
     P(v_rec) P(v_means) P(v_quats) P(v_scales) P(v_opac) P(v_dc) P(v_rest) P(cam_grad) P(v_viewmat) \
@@ -645,7 +655,8 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
 #define ADK_FIELD_I(n) int32_t n;
 #define ADK_FIELD_F(n) float n;
 typedef struct AdkMapperStepArgs { ADK_MAPPER_STEP_FIELDS(ADK_FIELD_P, ADK_FIELD_L, ADK_FIELD_I, ADK_FIELD_F) } AdkMapperStepArgs;
-typedef struct AdkMapperStepOut { int64_t n_isects; int64_t max_tile; int32_t stage; int32_t reserved; } AdkMapperStepOut;
+/* wait_ns: host nanoseconds spent inside the call's ONE wait (the intersection count): wall time of a step minus this is the host's own work */
+typedef struct AdkMapperStepOut { int64_t n_isects; int64_t max_tile; int32_t stage; int32_t reserved; int64_t wait_ns; } AdkMapperStepOut;
 int64_t adk_mapper_step_args_bytes(void);   /* sizeof(AdkMapperStepArgs): a binding checks its own layout against it */
 int adk_mapper_step(const AdkMapperStepArgs* args, AdkMapperStepOut* out, adk_stream_t stream);
 /* Folds the event pairs recorded under time_mask since the last call (waits for them): per stage the sum and the minimum of the

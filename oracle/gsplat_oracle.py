@@ -289,14 +289,36 @@ class _one_thread:
         torch.set_num_threads(self.n)
 
 
-def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, knife_eps=None):
+def _tile_decisions(m2, cn, op, px, py):
+    """(keep, live, ov, T_incl, T_excl, sigma) of one tile in the dtype of the inputs, no autograd: which (splat, pixel) pairs pass
+    `sigma >= 0 and alpha >= 1/255`, and which of those are blended before the pixel terminates."""
+    dt = m2.dtype
+    thr_alpha = torch.tensor(ALPHA_THRESHOLD, dtype=torch.float32).to(dt)
+    P = px.shape[0]
+    dx = m2[:, 0][:, None] - px[None, :]
+    dy = m2[:, 1][:, None] - py[None, :]
+    sigma = 0.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) + cn[:, 1:2] * dx * dy
+    ov = op[:, None] * torch.exp(-sigma)
+    alpha = torch.clamp_max(ov, MAX_ALPHA)
+    keep = ~((sigma < 0) | (alpha < thr_alpha))
+    one_m = 1.0 - torch.where(keep, alpha, torch.zeros_like(alpha))
+    T_incl = torch.cumprod(one_m, dim=0)
+    T_excl = torch.cat([torch.ones(1, P, dtype=dt), T_incl[:-1]], 0)
+    live = keep & (T_incl > TRANSMITTANCE_EPS)
+    return keep, live, ov, T_incl, T_excl, sigma
+
+
+def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, knife_eps=None, decide=None):
     """ONE tile of rasterize_to_pixels_fwd (App. A item 4), vectorised over [n splats in list order, P pixels], autograd-capable.
 
     m2 [n,2], cn [n,3], col [n,CDIM], op [n] of the tile's list (depth order); px, py [P] pixel centres; first_index = position of the
     list's first entry in the sorted intersection list.  Returns (colour [P,CDIM], T_final [P], last index int32 [P], extras or None);
     extras = (knife bool [P], main list position int64 [P] (-1: none), main_w [P], second_w [P], touch bool [n,P]) -- `touch` marks the
     (splat, pixel) pairs that either contribute (alpha T > 0) or sit on a decision within knife_eps while the pixel is still live: the
-    pairs whose gradients move if that pixel's decisions fall differently."""
+    pairs whose gradients move if that pixel's decisions fall differently.
+    decide = (m2, cn, op) in float32: the per-pixel DECISIONS (skip below 1/255, terminate at T <= 1e-4) are taken by a single-precision
+    evaluation of these -- the values an fp32 rasteriser decides on -- and the differentiable arithmetic of the call's own dtype runs ON
+    them (the knife band of `extras` is then measured on the fp32 values too: where ANOTHER fp32 evaluation may still decide otherwise)."""
     dt = m2.dtype
     eps = KNIFE_EPS if knife_eps is None else knife_eps
     thr_alpha = torch.tensor(ALPHA_THRESHOLD, dtype=torch.float32).to(dt)
@@ -305,14 +327,20 @@ def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, kn
     dy = m2[:, 1][:, None] - py[None, :]
     sigma = 0.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) + cn[:, 1:2] * dx * dy
     alpha = torch.clamp_max(op[:, None] * torch.exp(-sigma), MAX_ALPHA)
-    keep = ~((sigma < 0) | (alpha < thr_alpha))
+    dec = None
+    if decide is not None:
+        with torch.no_grad():
+            dec = _tile_decisions(decide[0], decide[1], decide[2], px.to(decide[0].dtype), py.to(decide[0].dtype))
+        keep = dec[0]
+    else:
+        keep = ~((sigma < 0) | (alpha < thr_alpha))
     a = torch.where(keep, alpha, torch.zeros_like(alpha))
     one_m = 1.0 - a
     T_incl = torch.cumprod(one_m, dim=0)  # T after splat k
     T_excl = torch.cat([torch.ones(1, P, dtype=dt), T_incl[:-1]], 0)
     # a kept splat whose next_T <= 1e-4 terminates the pixel BEFORE being added; since T is
     # monotone, every later kept splat also fails the test, so the mask is simply:
-    live = keep & (T_incl.detach() > TRANSMITTANCE_EPS)
+    live = dec[1] if dec is not None else keep & (T_incl.detach() > TRANSMITTANCE_EPS)
     w = torch.where(live, a * T_excl, torch.zeros_like(a))  # alpha * T
     colour = (w[:, :, None] * col[:, None, :]).sum(0)  # [P, cdim]
     T_final = torch.prod(torch.where(live, one_m, torch.ones_like(one_m)), dim=0)
@@ -321,11 +349,13 @@ def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, kn
     extras = None
     if want_extras:
         with torch.no_grad():
-            ov = (op[:, None] * torch.exp(-sigma)).detach()
-            Ti, Te = T_incl.detach(), T_excl.detach()
+            if dec is not None:
+                ov, Ti, Te, sg = dec[2], dec[3], dec[4], dec[5]
+            else:
+                ov, Ti, Te, sg = (op[:, None] * torch.exp(-sigma)).detach(), T_incl.detach(), T_excl.detach(), sigma.detach()
             reached = Te > TRANSMITTANCE_EPS * (1.0 - eps)
             near = ((ov * 255.0 - 1.0).abs() <= eps) | ((ov - MAX_ALPHA).abs() <= eps * MAX_ALPHA) \
-                | (sigma.detach().abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= eps * TRANSMITTANCE_EPS))
+                | (sg.abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= eps * TRANSMITTANCE_EPS))
             knife = (near & reached).any(0)
             wd = w.detach()
             k = min(2, n)

@@ -12,10 +12,11 @@ Restates, on the CPU, everything `SceneModel.optimization_step` differentiates
   loss                                  h3dgsv3.py:428-449   (outlier mask on unimportant frames -- incl. its `error_map[1]` used twice --,
                                                               radial-decay L1, 1 - fused_ssim, inverse-depth L1, scaling regulariser)
 
-Every integer / boolean DECISION (LoD selection and fade masks, cull, radii, tile lists, depth order) comes from an fp32 pass written
-with the reference's own torch operations; everything differentiable is then evaluated in float64 ON those decisions and differentiated
+Every integer / boolean DECISION (LoD selection and fade masks, cull, radii, tile lists, depth order, and per pixel: which splats pass
+alpha >= 1/255 and where the pixel terminates) comes from an fp32 pass written with the reference's own torch operations / App. A's
+expressions; everything differentiable is then evaluated in float64 ON those decisions and differentiated
 by torch autograd -- i.e. independently of every hand-derived backward in artdeco_amd/csrc.  The compositing is the per-tile function of
-oracle/gsplat_oracle.py (`composite_tile`), run tile by tile in a pool of forked workers: pass 1 renders the frame, the image-space chain
+oracle/gsplat_oracle.py (`composite_tile`), run tile by tile in a pool of worker processes: pass 1 renders the frame, the image-space chain
 gives dL/d(render, alpha), pass 2 re-runs each tile under autograd with that cotangent, and one last backward carries the per-splat
 gradients through projection / SH / mlp_cov / LoD / pose to the 15 leaves.  Cost: ~1e-7 core-seconds per (intersection x pixel), so a
 1 M-Gaussian 1080p frame is minutes on one core and seconds on a node's worth.
@@ -26,9 +27,15 @@ same state and compares loss, masks and every gradient with this file's (fp32 vs
 """
 from __future__ import annotations
 
+import atexit
+import json
 import math
 import multiprocessing as mp
 import os
+import shutil
+import sys
+import tempfile
+import time
 
 import numpy as np
 import torch
@@ -124,8 +131,39 @@ def _lod_and_params(st, Rt, decisions=None):
     return dict(xyz=xyz[sel], opacity=opacity.squeeze(-1), scaling=scaling, rotation=rotation, feats=feats), decisions
 
 
-# ----------------------------------------------------------------------------- tile passes (forked workers share _SH by copy-on-write)
+# ----------------------------------------------------------------------------- tile passes
+# The per-tile work runs in a pool of SPAWNED worker processes (fresh interpreters: a process that has run a backward pass with a GPU
+# present owns autograd device threads, and torch refuses autograd in its forked children; the test process is such a process).  The
+# frame's arrays travel as .npy files in a temporary directory that the workers map read-only; the pool outlives a call (importing torch
+# costs a worker ~2 s) and is torn down at interpreter exit.
 _SH: dict = {}
+_POOL = None
+_POOL_WORKERS = 0
+_WORKER_PREFIX = None
+_PASS1 = ("means2d", "conics", "feat", "opac", "flat", "offsets", "means2d32", "conics32", "opac32")
+_PASS2 = ("g_col", "g_T", "knife_px")
+
+
+def _publish(prefix, names):
+    for k in names:
+        v = _SH[k]
+        np.save(f"{prefix}.{k}.npy", v.numpy() if torch.is_tensor(v) else np.asarray(v))
+    with open(f"{prefix}.scalars.json", "w") as f:
+        json.dump({"n_isects": int(_SH["n_isects"]), "tile_w": int(_SH["tile_w"]), "knife_eps": float(_SH["knife_eps"])}, f)
+
+
+def _attach(prefix, names):
+    """Worker side: map the arrays of the frame `prefix` (cached: one frame at a time)."""
+    global _WORKER_PREFIX
+    if _WORKER_PREFIX != prefix:
+        _SH.clear()
+        _SH.update(json.load(open(f"{prefix}.scalars.json")))
+        _SH["grid"] = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
+        _WORKER_PREFIX = prefix
+    for k in names:
+        if k not in _SH:
+            a = np.load(f"{prefix}.{k}.npy", mmap_mode="c")   # copy-on-write: torch wants a writable array, nothing writes
+            _SH[k] = a if k == "offsets" else torch.from_numpy(np.asarray(a))
 
 
 def _tile_pixels(tid, dt):
@@ -139,7 +177,17 @@ def _span(tid):
     return int(off[tid]), (int(off[tid + 1]) if tid + 1 < off.shape[0] else _SH["n_isects"])
 
 
-def _fwd_chunk(tids):
+def _decide(g):
+    """The tile's fp32 projection outputs (what an fp32 rasteriser takes its per-pixel decisions on), or None for the all-fp64 form."""
+    if _SH.get("means2d32") is None:
+        return None
+    return _SH["means2d32"][g], _SH["conics32"][g], _SH["opac32"][g]
+
+
+def _fwd_chunk(task):
+    prefix, tids = task
+    if prefix is not None:
+        _attach(prefix, _PASS1)
     m2, cn, ft, op, flat = _SH["means2d"], _SH["conics"], _SH["feat"], _SH["opac"], _SH["flat"]
     out = []
     with torch.no_grad():
@@ -150,12 +198,15 @@ def _fwd_chunk(tids):
             g = flat[s:e]
             px, py, tx, ty = _tile_pixels(tid, m2.dtype)
             col, T, last, ex = go.composite_tile(m2[g], cn[g], ft[g], op[g], px, py, first_index=s, want_extras=True,
-                                                 knife_eps=_SH["knife_eps"])
+                                                 knife_eps=_SH["knife_eps"], decide=_decide(g))
             out.append((tid, col.numpy(), T.numpy(), ex[0].numpy()))
     return out
 
 
-def _bwd_chunk(tids):
+def _bwd_chunk(task):
+    prefix, tids = task
+    if prefix is not None:
+        _attach(prefix, _PASS1 + _PASS2)
     m2, cn, ft, op, flat = _SH["means2d"], _SH["conics"], _SH["feat"], _SH["opac"], _SH["flat"]
     g_col, g_T, knife = _SH["g_col"], _SH["g_T"], _SH["knife_px"]
     ids_all, grads_all, touched = [], [], []
@@ -168,7 +219,8 @@ def _bwd_chunk(tids):
         sl = (slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE))
         leaves = [t[g].clone().requires_grad_(True) for t in (m2, cn, ft, op)]
         kn = knife[sl].reshape(-1)
-        col, T, last, ex = go.composite_tile(*leaves, px, py, first_index=s, want_extras=bool(kn.any()), knife_eps=_SH["knife_eps"])
+        col, T, last, ex = go.composite_tile(*leaves, px, py, first_index=s, want_extras=bool(kn.any()), knife_eps=_SH["knife_eps"],
+                                             decide=_decide(g))
         scalar = (col * g_col[sl].reshape(-1, col.shape[1])).sum() + (T * g_T[sl].reshape(-1)).sum()
         scalar.backward()
         ids_all.append(g.numpy())
@@ -185,7 +237,7 @@ def _bwd_chunk(tids):
     return uniq, acc, (np.unique(np.concatenate(touched)) if touched else np.zeros(0, np.int64))
 
 
-def _chunks(n_tiles, workers):
+def _chunks(workers):
     """Tile ids in chunks of roughly equal work (list length), several chunks per worker."""
     off = _SH["offsets"]
     lens = np.diff(np.append(off, _SH["n_isects"])).astype(np.int64)
@@ -202,14 +254,43 @@ def _one_thread_worker():
     torch.set_num_threads(1)
 
 
-def _run(fn, chunks, workers):
-    """Inline (one intra-op thread: the per-tile tensors are far too small for OpenMP, see gsplat_oracle._one_thread) or in a pool of
-    FORKED workers, which read the frame's arrays from this module's _SH by copy-on-write and never touch a GPU context."""
-    if workers <= 1 or len(chunks) <= 1:
+def _pool(workers):
+    global _POOL, _POOL_WORKERS
+    if _POOL is None or _POOL_WORKERS != workers:
+        shutdown_pool()
+        # a spawned child re-imports the parent's __main__ (by path or by module name) before it unpickles its task: a test runner's or a
+        # script's main module must not run again in every worker, and the workers need nothing from it (their functions live in this
+        # module).  Hide it while the pool starts its processes.
+        main = sys.modules.get("__main__")
+        saved = {k: getattr(main, k) for k in ("__file__", "__spec__") if main is not None and hasattr(main, k)}
+        try:
+            if main is not None:
+                if hasattr(main, "__file__"):
+                    del main.__file__
+                main.__spec__ = None
+            _POOL = mp.get_context("spawn").Pool(workers, initializer=_one_thread_worker)
+        finally:
+            for k, v in saved.items():
+                setattr(main, k, v)
+        _POOL_WORKERS = workers
+        atexit.register(shutdown_pool)
+    return _POOL
+
+
+def shutdown_pool():
+    global _POOL
+    if _POOL is not None:
+        _POOL.terminate()
+        _POOL.join()
+        _POOL = None
+
+
+def _run(fn, chunks, workers, prefix):
+    """Inline (one intra-op thread: the per-tile tensors are far too small for OpenMP, see gsplat_oracle._one_thread) or in the pool."""
+    if prefix is None:
         with go._one_thread():
-            return [fn(c) for c in chunks]
-    with mp.get_context("fork").Pool(workers, initializer=_one_thread_worker) as pool:
-        return pool.map(fn, chunks, chunksize=1)
+            return [fn((None, c)) for c in chunks]
+    return _pool(workers).map(fn, [(prefix, c) for c in chunks], chunksize=1)
 
 
 def default_workers():
@@ -218,10 +299,14 @@ def default_workers():
 
 # ----------------------------------------------------------------------------- the step
 def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_targets=None, knife_eps=KNIFE_EPS,
-                      image_knife_tol=IMAGE_KNIFE_TOL, want_grads=True):
+                      image_knife_tol=IMAGE_KNIFE_TOL, want_grads=True, dtype=torch.float64, knife_rows_from="image", timings=None):
     """One `optimization_step` up to (not including) the optimisers.  state / kf / cfg: `snapshot()`.  bg: the step's random background
     [3].  adjust_targets(image [3,H,W] fp64, invdepth [1,H,W] fp64, gt, mono) -> (gt, mono): lets a TEST move its own targets off the
     loss's knife edges after it has seen the oracle's render (the targets used are returned).
+
+    dtype=torch.float32 evaluates the SAME chain in single precision (other operation order than any kernel's): the measure of what fp32
+    arithmetic itself leaves of a gradient on this workload.  knife_rows_from: "image" | "raster" | "both" (which knife pixels' contributors
+    `knife_rows` marks).  timings: a dict that receives the seconds of each phase.
 
     Returns dict: loss (float), image [3,H,W] (exposed, clamped), invdepth [1,H,W], visibility bool [N], global_visibility bool [Nvox],
     grads {15 leaves: GAUSS_KEYS, MLP_KEYS, KF_KEYS} fp64, raster_knife / image_knife bool [H,W], knife_rows bool [N] (Gaussians that
@@ -229,7 +314,14 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
     n_isects, selected."""
     W, H = cfg["width"], cfg["height"]
     workers = default_workers() if workers is None else workers
-    f32, f64 = torch.float32, torch.float64
+    f32, f64 = torch.float32, dtype
+    _t = [time.time()]
+
+    def lap(name):
+        if timings is not None:
+            now = time.time()
+            timings[name] = timings.get(name, 0.0) + now - _t[0]
+            _t[0] = now
     st32 = {k: (v.to(f32) if v.is_floating_point() else v) for k, v in state.items()}
     N = st32["xyz"].shape[0]
 
@@ -247,6 +339,7 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
         global_visibility = torch.zeros(st32["global_feat"].shape[0], dtype=torch.bool)
         global_visibility[st32["cls_id"][visibility].squeeze(-1)] = True
 
+    lap("A fp32 decisions")
     # ---- B. the differentiable chain in fp64 on those decisions
     leaves = {k: state[k].to(f64).clone().requires_grad_(want_grads) for k in GAUSS_KEYS + MLP_KEYS}
     kfl = {k: kf[k].to(f64).clone().requires_grad_(want_grads) for k in ("rW2C", "tW2C", "exposure")}
@@ -262,18 +355,25 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
         feat = torch.cat([rgb, p["depths"][:, None]], -1)
     ras_in = (p["means2d"], p["conics"], feat, par["opacity"])
 
+    lap("B projection graph")
     # ---- C. pass 1 over the tiles: the frame
     tile_w, tile_h = isects["tile_w"], isects["tile_h"]
     Hp, Wp = tile_h * TILE, tile_w * TILE
     _SH.clear()
+    _SH.update(means2d32=p32["means2d"], conics32=p32["conics"], opac32=par32["opacity"])     # the per-pixel decisions are taken on these
     _SH.update(means2d=ras_in[0].detach(), conics=ras_in[1].detach(), feat=ras_in[2].detach(), opac=ras_in[3].detach(),
                flat=torch.from_numpy(isects["flatten_ids"].astype(np.int64)), offsets=isects["offsets"].reshape(-1), n_isects=isects["n_isects"],
                tile_w=tile_w, grid=torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij"), knife_eps=knife_eps)
-    chunks = _chunks(tile_w * tile_h, workers)
+    chunks = _chunks(workers)
+    tmpdir = prefix = None
+    if workers > 1 and len(chunks) > 1:
+        tmpdir = tempfile.mkdtemp(prefix="adk_step_oracle_")
+        prefix = os.path.join(tmpdir, "frame")
+        _publish(prefix, _PASS1)
     render = torch.zeros(Hp, Wp, 4, dtype=f64)
     T_img = torch.ones(Hp, Wp, dtype=f64)
     raster_knife = torch.zeros(Hp, Wp, dtype=torch.bool)
-    for res in _run(_fwd_chunk, chunks, workers):
+    for res in _run(_fwd_chunk, chunks, workers, prefix):
         for tid, col, T, kn in res:
             ty, tx = divmod(tid, tile_w)
             sl = (slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE))
@@ -282,6 +382,7 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
             raster_knife[sl] = torch.from_numpy(kn).reshape(TILE, TILE)
     render, T_img, raster_knife = render[:H, :W].contiguous(), T_img[:H, :W].contiguous(), raster_knife[:H, :W]
 
+    lap("C tile pass 1")
     # ---- D. the image-space chain (h3dgsv3.py:682-686, 611-614, 428-449)
     render_l = render.clone().requires_grad_(want_grads)
     T_l = T_img.clone().requires_grad_(want_grads)
@@ -311,7 +412,7 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
         with torch.no_grad():
             first = image_chain(gt, mono)
             gt, mono = adjust_targets(first["image"], first["invdepth"], gt, mono)
-            gt, mono = gt.float().double(), mono.float().double()      # what an fp32 keyframe can hold: both sides train on THESE values
+            gt, mono = gt.float().to(f64), mono.float().to(f64)      # what an fp32 keyframe can hold: both sides train on THESE values
     with torch.set_grad_enabled(want_grads):
         img = image_chain(gt, mono)
         reg = par["scaling"].prod(dim=1).mean()
@@ -328,26 +429,35 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
                n_isects=isects["n_isects"], selected=sel, isects=isects, radii=p32["radii"])
     if not want_grads:
         _SH.clear()
+        if tmpdir:
+            shutil.rmtree(tmpdir, ignore_errors=True)
         return out
     g_render, g_T, g_exposure = torch.autograd.grad(img["loss_image"], [render_l, T_l, kfl["exposure"]])
 
+    lap("D image chain")
     # ---- E. pass 2 over the tiles: per-splat gradients of the compositing under that cotangent
     def pad(t):
         full = torch.zeros((Hp, Wp) + tuple(t.shape[2:]), dtype=t.dtype)
         full[:H, :W] = t
         return full
-    _SH.update(g_col=pad(g_render), g_T=pad(g_T), knife_px=pad(image_knife))
+    knife_px = {"image": image_knife, "raster": raster_knife, "both": image_knife | raster_knife}[knife_rows_from]
+    _SH.update(g_col=pad(g_render), g_T=pad(g_T), knife_px=pad(knife_px))
     n_sel = ras_in[0].shape[0]
     acc = torch.zeros(n_sel, 10, dtype=f64)
     knife_sel = torch.zeros(n_sel, dtype=torch.bool)
-    for res in _run(_bwd_chunk, chunks, workers):
+    if prefix is not None:
+        _publish(prefix, _PASS2)
+    for res in _run(_bwd_chunk, chunks, workers, prefix):
         if res is None:
             continue
         uniq, a, touched = res
-        acc.index_add_(0, torch.from_numpy(uniq), torch.from_numpy(a))
+        acc.index_add_(0, torch.from_numpy(uniq), torch.from_numpy(a).to(f64))
         knife_sel[torch.from_numpy(touched)] = True
     _SH.clear()
+    if tmpdir:
+        shutil.rmtree(tmpdir, ignore_errors=True)
 
+    lap("E tile pass 2")
     # ---- F. through projection / SH / mlp_cov / LoD / pose to the leaves
     torch.autograd.backward([ras_in[0], ras_in[1], ras_in[2], ras_in[3], reg],
                             [acc[:, 0:2], acc[:, 2:5], acc[:, 5:9], acc[:, 9], torch.tensor(cfg["scaling_reg_factor"], dtype=f64)])
@@ -356,6 +466,7 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
     knife_rows = torch.zeros(N, dtype=torch.bool)
     knife_rows[torch.nonzero(sel).squeeze(-1)[knife_sel]] = True
     out.update(grads=grads, knife_rows=knife_rows)
+    lap("F backward to the leaves")
     return out
 
 

@@ -39,6 +39,53 @@ def _targets(rays, seed):
     return pts.astype(np.float32), p_init
 
 
+def _full_size_inputs(h=384, w=512, seed=2024):
+    """The frontend's REAL size (hw = 196 608, VSLAM/utils_matching.py:152-179), built from operations that are bit-reproducible on any
+    IEEE machine: PCG64 INTEGER draws scaled by powers of two, single fp32 elementwise operations, explicit left-to-right sums (no
+    `standard_normal`, whose tails go through libm, and no `np.sum` / `linalg.norm`, whose order depends on the SIMD width).  The golden
+    file holds only the reference's OUTPUTS for these inputs plus a SHA-256 of the inputs (tests/golden/make_golden_ref_full.py)."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+
+    def noise(shape, pow2):     # uniform integers in [-2^15, 2^15) x 2^pow2: exact in fp32
+        return rng.integers(-32768, 32768, shape).astype(f32) * f32(2.0 ** pow2)
+
+    def unit(v):                # v / sqrt(v0^2 + v1^2 + ...), one IEEE operation at a time, left to right
+        acc = v[..., 0] * v[..., 0]
+        for k in range(1, v.shape[-1]):
+            acc = acc + v[..., k] * v[..., k]
+        return v / np.sqrt(acc)[..., None]
+
+    ys, xs = np.meshgrid(np.arange(h, dtype=f32), np.arange(w, dtype=f32), indexing="ij")
+    d = np.stack([(xs - f32(w / 2)) / f32(460.0), (ys - f32(h / 2)) / f32(460.0), np.ones_like(xs)], -1)
+    d = unit(d + noise(d.shape, -22))                                   # +- 0.0078 of direction noise
+    gx, gy = np.zeros_like(d), np.zeros_like(d)
+    gx[:, 1:-1] = (d[:, 2:] - d[:, :-2]) * f32(0.5)
+    gy[1:-1] = (d[2:] - d[:-2]) * f32(0.5)
+    rays = np.ascontiguousarray(np.concatenate([d, gx, gy], -1)[None])   # [1,h,w,9]
+    n = h * w
+    gu, gv = np.tile(np.arange(w), h), np.repeat(np.arange(h), w)
+    u = np.clip(gu + rng.integers(-6, 7, n), 0, w - 1)
+    v = np.clip(gv + rng.integers(-6, 7, n), 0, h - 1)
+    pts = np.ascontiguousarray(unit(d[v, u] + noise((n, 3), -24))[None])  # the rays of displaced pixels: what a true match looks like
+    p_init = np.ascontiguousarray((np.stack([gu, gv], -1).astype(f32) + noise((n, 2), -14))[None])   # +- 2 px, exercises the border clamp
+    D11 = unit(noise((h, w, 24), -15))
+    su = np.clip(gu + rng.integers(-5, 6, n), 0, w - 1)
+    sv = np.clip(gv + rng.integers(-5, 6, n), 0, h - 1)
+    D21 = D11[sv, su] + noise((n, 24), -20)                              # the neighbour's descriptor + ~0.03 of noise: near-ties matter
+    p1 = np.ascontiguousarray(np.stack([gu, gv], -1).astype(np.int64)[None])
+    return dict(rays=rays, pts=pts, p_init=p_init, D11=np.ascontiguousarray(D11.astype(np.float16)[None]),
+                D21=np.ascontiguousarray(D21.astype(np.float16)[None]), p1=p1)
+
+
+def _inputs_digest(inp):
+    import hashlib
+    hsh = hashlib.sha256()
+    for k in sorted(inp):
+        hsh.update(k.encode()); hsh.update(str(inp[k].dtype).encode()); hsh.update(str(inp[k].shape).encode()); hsh.update(inp[k].tobytes())
+    return hsh.hexdigest()
+
+
 def test_oracle_iter_proj_converges_on_identity():
     rays = _ray_image(1, 24, 32, 0)
     pts = rays[:, :, :, :3].reshape(1, -1, 3).copy()

@@ -184,26 +184,63 @@ def test_native_step_grows_its_lists_and_retries(dev, monkeypatch):
         assert float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)) <= 1e-5, k
 
 
+def _pile_up(sc, dev, n_pile):
+    """Pile n_pile Gaussians into a pixel or two in front of keyframe 0; the rest keep covering the frame."""
+    with torch.no_grad():
+        kf = sc.keyframes[0]
+        Rt = kf.get_Rt().detach()
+        centre = -Rt[:3, :3].T @ Rt[:3, 3]
+        fwd = Rt[2, :3]
+        g = torch.Generator().manual_seed(1)
+        sc.gaussian_params["xyz"]["val"][:n_pile] = (centre + 3.0 * fwd)[None] + 2e-3 * torch.randn(n_pile, 3, generator=g).to(dev)
+
+
 @pytest.mark.gpu
-def test_frames_that_need_the_global_route_fall_back_untouched(dev, monkeypatch):
-    """More than 8 192 Gaussians on one tile: the tile-local sort cannot take the list, adk_mapper_step says so BEFORE it has modified
-    anything, and the per-stage chain (global radix route) runs the step."""
+def test_tile_lists_above_8192_entries_stay_on_the_native_step(dev, monkeypatch):
+    """More than 8 192 Gaussians on one tile.  Until round 4 adk_mapper_step handed such a frame back (ADK_STEP_EROUTE) and the per-stage
+    chain ran it through the global radix route; since round 5 the list is sorted inside the call (bin_tile_sort_long_kernel) -- gsplat's
+    own sort has no list-length limit (h3dgsv3.py:664-680).  Same results as the per-stage chain, which ALSO takes the long-list sort now,
+    and as the per-stage chain on the old global route (ADK_BIN_LONG=0), which shares no sorting code with it."""
+    from artdeco_amd import fused, native_step
+    a, b, c = (_scene(dev, N=20000, seed=2, lod=False) for _ in range(3))
+    for sc in (a, b, c):
+        assert fused.patch_scene_model(sc)
+        _pile_up(sc, dev, 9000)
+    f0, n0, l0 = native_step.STATS["fallback_route"], native_step.STATS["native"], native_step.STATS["long_list_steps"]
+    ga = _one_step(a, monkeypatch, True, True, kid=0)
+    assert native_step.STATS["fallback_route"] == f0 and native_step.STATS["native"] == n0 + 1 and ga["native_calls"] == 1
+    assert native_step.STATS["long_list_steps"] == l0 + 1
+    plan = next(iter(a.__dict__["_adk_step_plans"].values()))
+    assert plan.out.max_tile > 8192
+    gb = _one_step(b, monkeypatch, False, True, kid=0)
+    monkeypatch.setenv("ADK_BIN_LONG", "0")
+    gc = _one_step(c, monkeypatch, False, True, kid=0)
+    monkeypatch.delenv("ADK_BIN_LONG")
+    for other in (gb, gc):
+        assert torch.equal(ga["loss"], other["loss"]) and torch.equal(ga["invdepth"], other["invdepth"])
+        for k, x in ga["grads"].items():
+            y = other["grads"][k]
+            assert float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)) <= 1e-5, k
+
+
+@pytest.mark.gpu
+def test_native_step_without_the_second_key_buffer_still_hands_long_lists_back(dev, monkeypatch):
+    """An ABI-v16 caller's plan has no `pairs2`: adk_mapper_step must decide ADK_STEP_EROUTE BEFORE it has modified anything, and the per-stage
+    chain runs the step (with the same random background)."""
     from artdeco_amd import fused, native_step
     a, b = _scene(dev, N=20000, seed=2, lod=False), _scene(dev, N=20000, seed=2, lod=False)
     for sc in (a, b):
         assert fused.patch_scene_model(sc)
-        with torch.no_grad():   # pile 9 000 of the 20 000 Gaussians into a pixel or two in front of keyframe 0; the rest keep covering the frame
-            kf = sc.keyframes[0]
-            Rt = kf.get_Rt().detach()
-            centre = -Rt[:3, :3].T @ Rt[:3, 3]
-            fwd = Rt[2, :3]
-            g = torch.Generator().manual_seed(1)
-            sc.gaussian_params["xyz"]["val"][:9000] = (centre + 3.0 * fwd)[None] + 2e-3 * torch.randn(9000, 3, generator=g).to(dev)
+        _pile_up(sc, dev, 9000)
+    real = native_step.StepPlan.set_capacity
+
+    def no_second_buffer(self, capacity):
+        real(self, capacity)
+        self.args.pairs2 = None
+    monkeypatch.setattr(native_step.StepPlan, "set_capacity", no_second_buffer)
     f0, n0 = native_step.STATS["fallback_route"], native_step.STATS["native"]
     ga = _one_step(a, monkeypatch, True, True, kid=0)
     assert native_step.STATS["fallback_route"] == f0 + 1 and native_step.STATS["native"] == n0 and ga["native_calls"] == 0
-    plan = next(iter(a.__dict__["_adk_step_plans"].values()))
-    assert plan.out.max_tile > 8192
     gb = _one_step(b, monkeypatch, False, True, kid=0)
     assert torch.equal(ga["loss"], gb["loss"]) and torch.equal(ga["invdepth"], gb["invdepth"])
     for k, x in ga["grads"].items():

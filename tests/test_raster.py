@@ -273,6 +273,51 @@ def test_binning_is_bit_exact_at_northstar_sizes_on_every_route(N, W, H, route, 
     assert torch.equal(meta["conics"][0].cpu()[vis], p["conics"][vis])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["dense-northstar", "pile", "equal-depths"])
+def test_binning_is_bit_exact_beyond_8192_entries_per_tile(case, dev, monkeypatch):
+    """Tile lists ABOVE 8 192 entries stay on the tile-local route (round 5: bin_tile_sort_long_kernel, recursive partition on the key range
+    between two buffers); gsplat's isect_tiles + radix sort have no list-length limit (h3dgsv3.py:664-680).  Against the ORACLE, bit for bit:
+      dense-northstar  1 M Gaussians on 512x384 with sigma ~ 4 px (I / N ~ 10): EVERY interior tile list has 10-20 k entries;
+      pile             200 k Gaussians of which 120 k sit in front of one pixel: one list of > 120 k entries (several partition levels) next
+                       to medium lists (1 025 .. 8 192) in the same frame;
+      equal-depths     the pile with every z rounded to 1/8: thousands of EQUAL depth keys per list, which only the ids order."""
+    for k in ("ADK_BIN_BUCKET_SORT", "ADK_BIN_LOCAL", "ADK_BIN_LONG"):
+        monkeypatch.delenv(k, raising=False)
+    if case == "dense-northstar":
+        N, W, H = 1_000_000, 512, 384
+        sc = dict(_scene(N, W, H, 0, sigma_px=4.0), viewmat=_tilted_viewmat(1))
+    else:
+        N, W, H = 200_000, 256, 192
+        sc = dict(_scene(N, W, H, 3))
+        g = torch.Generator().manual_seed(9)
+        z = 2.0 + 3.0 * torch.rand(120_000, generator=g)
+        sc["means"][:120_000] = torch.stack([0.01 * torch.randn(120_000, generator=g), 0.01 * torch.randn(120_000, generator=g), z], -1)
+        if case == "equal-depths":
+            sc["means"][:, 2] = torch.round(sc["means"][:, 2] * 8) / 8
+    p = go.project(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["viewmat"], sc["K"], W, H, 0.01)
+    oi = go.isect_tiles(p["means2d"], p["radii"], p["depths"], W, H)
+    counts = np.diff(np.append(oi["offsets"].reshape(-1), oi["n_isects"]))
+    if case == "dense-northstar":
+        assert (counts > 8192).mean() > 0.6 and counts.max() < 40_000, ((counts > 8192).mean(), counts.max())
+    else:
+        assert counts.max() > 100_000 and ((counts > 1024) & (counts <= 8192)).any(), counts.max()
+        if case == "equal-depths":
+            assert np.unique(p["depths"][p["valid"]].numpy()).size < 64
+    r, a, meta, _ = _run_hip(sc, dev)
+    assert torch.equal(meta["radii"][0].cpu(), p["radii"])
+    assert np.array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), oi["tiles_per_gauss"])
+    assert meta["isect_ids"].numel() == oi["n_isects"]
+    assert np.array_equal(meta["isect_offsets"][0].cpu().numpy(), oi["offsets"])
+    assert np.array_equal(meta["flatten_ids"].cpu().numpy(), oi["flatten_ids"])
+    assert np.array_equal(meta["isect_ids"].cpu().numpy(), oi["isect_ids"])
+    # and the old way out of such a frame (ADK_BIN_LONG=0: global radix route) still produces the same bytes
+    monkeypatch.setenv("ADK_BIN_LONG", "0")
+    r2, a2, meta2, _ = _run_hip(sc, dev)
+    assert torch.equal(meta2["flatten_ids"], meta["flatten_ids"]) and torch.equal(meta2["isect_offsets"], meta["isect_offsets"])
+    assert torch.equal(r2, r) and torch.equal(a2, a)
+
+
 def _binning_outputs(meta):
     return {k: meta[k].cpu().numpy() for k in ("isect_ids", "flatten_ids", "isect_offsets", "tiles_per_gauss")}
 

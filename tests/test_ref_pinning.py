@@ -144,3 +144,66 @@ def test_hip_matching_equals_reference_golden(dev):
     assert np.array_equal(be.refine_matches(D11, D21, p1, 4, 5)[0].cpu().numpy(), g["rf_out_r4d5"])
     assert np.array_equal(be.refine_matches(D11, D21, p1, 2, 2)[0].cpu().numpy(), g["rf_out_r2d2"])
     assert np.array_equal(be.refine_matches(D11.float(), D21.float(), p1, 3, 2)[0].cpu().numpy(), g["rf32_out_r3d2"])
+
+
+# ------------------------------------------------------------------------------------------- FULL SIZE (round 5)
+def _full():
+    return np.load(os.path.join(GOLD, "ref_full.npz"))
+
+
+def test_full_size_inputs_are_bit_reproducible_here():
+    """tests/golden/ref_full.npz holds the reference's OUTPUTS at 1 x 384 x 512 and a SHA-256 of the inputs it was run on; the inputs are
+    rebuilt wherever the tests run (integer draws, single fp32 operations: tests/test_matching.py:_full_size_inputs).  If this fails on a
+    host, the full-size comparisons on that host would compare different problems -- they check the digest themselves too."""
+    import hashlib
+    from test_knn import _clouds
+    from test_matching import _full_size_inputs, _inputs_digest
+    g = _full()
+    assert _inputs_digest(_full_size_inputs()) == str(g["matching_inputs_sha256"])
+    assert hashlib.sha256(_clouds("uniform", 1_000_000, 11).tobytes()).hexdigest() == str(g["knn_points_sha256"])
+
+
+def test_matching_oracle_equals_the_reference_at_full_size():
+    """iter_proj (10 iterations) on all 196 608 pixels and refine_matches (radius 4, 5 dilation levels, fp16) on a 24 576-query slice: the
+    numpy oracles against the reference's own kernels' outputs at the frontend's real size."""
+    from test_matching import _full_size_inputs
+    g, inp = _full(), _full_size_inputs()
+    p, c = mo.iter_proj_oracle(inp["rays"], inp["pts"], inp["p_init"], 10, 1e-8, 1e-6)
+    assert np.array_equal(p, g["ip_p"]) and np.array_equal(np.packbits(c), g["ip_conv"])
+    assert 0.2 < c.mean() < 1.0
+    sl = slice(70_000, 70_000 + 24_576)
+    q = mo.refine_matches_oracle(inp["D11"], inp["D21"][:, sl], inp["p1"][:, sl], 4, 5)
+    assert np.array_equal(q.astype(np.int16), g["rf_out"][:, sl])
+
+
+@pytest.mark.gpu
+def test_hip_matching_equals_the_reference_at_full_size(dev):
+    """a9 / a10 at hw = 196 608 (VSLAM/utils_matching.py:152-179), bit for bit against matching_kernels.cu:119-316 / :25-116 compiled for the
+    host: every pixel's refined position and convergence flag, every query's refined integer match (fp16 accumulation included)."""
+    import mast3r_slam_backends as be
+    from test_matching import _full_size_inputs, _inputs_digest
+    g, inp = _full(), _full_size_inputs()
+    assert _inputs_digest(inp) == str(g["matching_inputs_sha256"]), "the full-size inputs are not reproduced bit for bit on this host"
+    t = lambda a: torch.from_numpy(a).to(dev)
+    p, c = be.iter_proj(t(inp["rays"]), t(inp["pts"]), t(inp["p_init"]), 10, 1e-8, 1e-6)
+    assert np.array_equal(p.cpu().numpy(), g["ip_p"])
+    assert np.array_equal(np.packbits(c.cpu().numpy()), g["ip_conv"])
+    (q,) = be.refine_matches(t(inp["D11"]), t(inp["D21"]), t(inp["p1"]), 4, 5)
+    assert q.dtype == torch.int64 and np.array_equal(q.cpu().numpy().astype(np.int16), g["rf_out"])
+    assert float((q.cpu() != torch.from_numpy(inp["p1"])).any(-1).float().mean()) > 0.5     # the search moved most matches
+
+
+@pytest.mark.gpu
+def test_hip_knn_equals_the_reference_at_a_million_points(dev):
+    """a5 at 10^6 points, K = 3: 20 000 rows of the reference's own run (simple_knn.cu:468-522 compiled for the host, 18 minutes of CPU),
+    distances bit-equal, neighbour sets equal up to exact distance ties at the K-th place."""
+    import hashlib
+    from simple_knn._C import distIndex2
+    from test_knn import _clouds
+    g = _full()
+    pts = _clouds("uniform", 1_000_000, 11)
+    assert hashlib.sha256(pts.tobytes()).hexdigest() == str(g["knn_points_sha256"])
+    d, i = distIndex2(torch.from_numpy(pts).to(dev), 3)
+    rows = g["knn_rows"].astype(np.int64)
+    assert rows.size >= 10_000
+    assert _same_rows(d.view(-1, 3)[rows].cpu().numpy(), i.view(-1, 3)[rows].cpu().numpy(), g["knn_dists"], g["knn_idx"])

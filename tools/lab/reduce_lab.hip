@@ -63,6 +63,12 @@ __global__ __launch_bounds__(64) void reduce_lab_kernel(int iters, float* __rest
         if (VARIANT == 0) {
             const adk::Reduce10 r = adk::wave_reduce10(a, lane);
             acc += r.is_owner ? r.value * (float)(r.slot + 1) : 0.f;
+        } else if (VARIANT == 3) {   // round 5: the same pair, rows first (adk::wave_reduce20_rows_first)
+            float b[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) b[k] = seed * (float)(k + 2) - (float)it * 0.25f;
+            const adk::Reduce20 r = adk::wave_reduce20_rows_first(a, b);
+            acc += r.z0 + 0.5f * r.z1;
         } else if (VARIANT == 2) {   // round 4: two splats' 20 sums in one butterfly (adk::wave_reduce20); one iteration = TWO (10 fma + reduction)
             float b[10];
 #pragma unroll
@@ -108,9 +114,24 @@ extern "C" int reduce20_lab_check(const float* in, float* z0, float* z1, hipStre
     hipLaunchKernelGGL(reduce20_check_kernel, dim3(1), dim3(64), 0, st, in, z0, z1);
     return (int)hipGetLastError();
 }
+__global__ __launch_bounds__(64) void reduce20s_check_kernel(const float* __restrict__ in /* [20][64] */, float* __restrict__ z0, float* __restrict__ z1)
+{
+    const int lane = threadIdx.x;
+    float a[10], b[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { a[k] = in[k * 64 + lane]; b[k] = in[(10 + k) * 64 + lane]; }
+    const adk::Reduce20 r = adk::wave_reduce20_rows_first(a, b);
+    z0[lane] = r.z0; z1[lane] = r.z1;
+}
+extern "C" int reduce20s_lab_check(const float* in, float* z0, float* z1, hipStream_t st)
+{
+    hipLaunchKernelGGL(reduce20s_check_kernel, dim3(1), dim3(64), 0, st, in, z0, z1);
+    return (int)hipGetLastError();
+}
 
 extern "C" int reduce_lab_time(int variant, int blocks, int iters, float* out, hipStream_t st)
 {
+    if (variant == 3) { hipLaunchKernelGGL(reduce_lab_kernel<3>, dim3(blocks), dim3(64), 0, st, iters, out); return (int)hipGetLastError(); }
     if (variant == 2) { hipLaunchKernelGGL(reduce_lab_kernel<2>, dim3(blocks), dim3(64), 0, st, iters, out); return (int)hipGetLastError(); }
     if (variant == 0) hipLaunchKernelGGL(reduce_lab_kernel<0>, dim3(blocks), dim3(64), 0, st, iters, out);
     else hipLaunchKernelGGL(reduce_lab_kernel<1>, dim3(blocks), dim3(64), 0, st, iters, out);

@@ -45,10 +45,23 @@ for l in range(64):
     if abs(float(z0[l]) - float(want20[k0])) > 1e-4 or abs(float(z1[l]) - float(want20[k1])) > 1e-4:
         bad2.append((l, k0, float(z0[l]), float(want20[k0]), k1, float(z1[l]), float(want20[k1])))
 print("paired reduce20: mismatches", bad2[:4])
+# round 5: adk::wave_reduce20_rows_first -- lane = 16 r + 4 b + l: splat r >> 1, z0 = total of (r & 1) * 5 + {0, 2, 1, 3}[b], z1 = total of (r & 1) * 5 + 4
+z0, z1 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+assert lib.reduce20s_lab_check(P(x20), P(z0), P(z1), st()) == 0
+torch.cuda.synchronize()
+bad3 = []
+for l in range(64):
+    r, b = l // 16, (l % 16) // 4
+    k0 = 10 * (r >> 1) + (r & 1) * 5 + [0, 2, 1, 3][b]
+    k1 = 10 * (r >> 1) + (r & 1) * 5 + 4
+    if abs(float(z0[l]) - float(want20[k0])) > 1e-4 or abs(float(z1[l]) - float(want20[k1])) > 1e-4:
+        bad3.append((l, k0, float(z0[l]), float(want20[k0]), k1, float(z1[l]), float(want20[k1])))
+print("paired reduce20, rows first: mismatches", bad3[:4])
 blocks, iters = 256 * 4 * 4, 4000          # 4 waves on every SIMD
 out = torch.zeros(blocks * 64, device=dev)
 for variant, name in ((0, "shipped (in-row DPP stages first)"), (1, "rows first (permlane swaps, then DPP)"),
-                      (2, "paired reduce20, per PAIR (2 x (10 fma + reduction))")):
+                      (2, "paired reduce20, per PAIR (2 x (10 fma + reduction))"),
+                      (3, "paired reduce20 ROWS FIRST, per PAIR")):
     for _ in range(2):
         lib.reduce_lab_time(variant, blocks, iters, P(out), st())
     torch.cuda.synchronize()
