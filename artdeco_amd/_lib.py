@@ -68,6 +68,10 @@ _lib = None
 _protos = None
 
 
+def is_loaded() -> bool:
+    return _lib is not None
+
+
 def load():
     """Load the shared library (once) and attach argtypes/restype from the header."""
     global _lib, _protos

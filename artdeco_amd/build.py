@@ -37,8 +37,6 @@ EXTRA_FLAGS = {
     "knn.hip": ["-ffp-contract=off"],
     "tracker.hip": ["-ffp-contract=off"],
     "densify.hip": ["-ffp-contract=off"],  # sample positions / resize weights follow torch's operation sequence (a fused u*k-1 moves a grid_sample position by 1e-7 of the map)
-    # raster_bwd's first-touch form leaves its ten sums uninitialised on purpose (never read before the first quadrant has written them)
-    "raster_tiles.hip": ["-Wno-uninitialized", "-Wno-sometimes-uninitialized"],
     "voxel.hip": ["-ffp-contract=off"],    # voxel indices are floor((p - min) / size): integer-deciding fp32 chain  # same arithmetic as the host-compiled test harness (tests/host/)
 }
 

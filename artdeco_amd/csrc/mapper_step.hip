@@ -52,7 +52,7 @@ static CountSlot* count_slot() {
     CountSlot s;
     s.device = dev;
     if (hipHostMalloc(reinterpret_cast<void**>(&s.host), 2 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(s.host); return nullptr; }
     slots.push_back(s);
     return &slots.back();
 }
@@ -61,6 +61,26 @@ static CountSlot* count_slot() {
 struct StageEvents { int stage; hipEvent_t a, b; };
 static std::mutex g_ev_lock;
 static std::vector<StageEvents> g_events;
+// A host that installs a timer and never folds it must not grow this without bound: beyond the cap the oldest pairs are destroyed.
+static constexpr size_t kMaxPendingStageEvents = 16384;
+// The pairs of the call in progress on this thread: published to g_events only when the call completes (a call that returns
+// ADK_STEP_ECAPACITY / ADK_STEP_EROUTE is repeated or replaced, and its forward stages must not be counted twice).
+static thread_local std::vector<StageEvents> t_call_events;
+static void drop_call_events() {
+    for (auto& e : t_call_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    t_call_events.clear();
+}
+static void publish_call_events() {
+    if (t_call_events.empty()) return;
+    std::lock_guard<std::mutex> g(g_ev_lock);
+    for (auto& e : t_call_events) g_events.push_back(e);
+    t_call_events.clear();
+    if (g_events.size() > kMaxPendingStageEvents) {
+        const size_t drop = g_events.size() - kMaxPendingStageEvents;
+        for (size_t i = 0; i < drop; ++i) { (void)hipEventDestroy(g_events[i].a); (void)hipEventDestroy(g_events[i].b); }
+        g_events.erase(g_events.begin(), g_events.begin() + (long)drop);
+    }
+}
 
 struct StageScope {
     hipStream_t stream;
@@ -75,8 +95,7 @@ struct StageScope {
     ~StageScope() {
         if (a == nullptr) return;
         (void)hipEventRecord(b, stream);
-        std::lock_guard<std::mutex> g(g_ev_lock);
-        g_events.push_back({stage, a, b});
+        t_call_events.push_back({stage, a, b});
     }
 };
 
@@ -98,10 +117,12 @@ extern "C" int64_t adk_mapper_step_timings(double* sum_ms, double* min_ms, int64
         std::lock_guard<std::mutex> g(adk::g_ev_lock);
         evs.swap(adk::g_events);
     }
+    int64_t seen[ADK_MAPPER_N_STAGES];
     for (int s = 0; s < ADK_MAPPER_N_STAGES; ++s) {
         if (sum_ms) sum_ms[s] = 0.0;
         if (min_ms) min_ms[s] = 0.0;
         if (count) count[s] = 0;
+        seen[s] = 0;
     }
     int64_t n = 0;
     for (auto& e : evs) {
@@ -109,7 +130,8 @@ extern "C" int64_t adk_mapper_step_timings(double* sum_ms, double* min_ms, int64
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.stage >= 0 &&
             e.stage < ADK_MAPPER_N_STAGES) {
             if (sum_ms) sum_ms[e.stage] += ms;
-            if (min_ms) min_ms[e.stage] = (count && count[e.stage] > 0) ? (ms < min_ms[e.stage] ? ms : min_ms[e.stage]) : ms;
+            if (min_ms) min_ms[e.stage] = seen[e.stage] > 0 ? (ms < min_ms[e.stage] ? ms : min_ms[e.stage]) : ms;
+            seen[e.stage] += 1;
             if (count) count[e.stage] += 1;
             ++n;
         }
@@ -125,7 +147,18 @@ extern "C" int64_t adk_mapper_step_timings(double* sum_ms, double* min_ms, int64
         if (rc_ != 0) { out->stage = (stage_id); return rc_; } \
     } while (0)
 
+static int mapper_step_impl(const AdkMapperStepArgs* A, AdkMapperStepOut* out, adk_stream_t stream);
+
 extern "C" int adk_mapper_step(const AdkMapperStepArgs* A, AdkMapperStepOut* out, adk_stream_t stream)
+{
+    adk::drop_call_events();
+    const int rc = mapper_step_impl(A, out, stream);
+    if (rc == ADK_OK) adk::publish_call_events();
+    else adk::drop_call_events();      // an aborted attempt's stage pairs are not part of any step's timing
+    return rc;
+}
+
+static int mapper_step_impl(const AdkMapperStepArgs* A, AdkMapperStepOut* out, adk_stream_t stream)
 {
     if (A == nullptr || out == nullptr) return ADK_EINVAL;
     out->n_isects = 0; out->max_tile = 0; out->stage = -1; out->reserved = 0; out->wait_ns = 0;

@@ -62,7 +62,7 @@ namespace adk {
 // stages (two per surviving value) instead of behind them: 27 cross-lane instructions + 15 adds per pair against 39 + 7 (adk_common.hpp:
 // wave_reduce20_rows_first).  0 = round 4's order.
 #ifndef ADK_BWD_ROWS_FIRST
-#define ADK_BWD_ROWS_FIRST 1
+#define ADK_BWD_ROWS_FIRST 0
 #endif
 #define MAX_ALPHA 0.999f
 #define ALPHA_THR (1.0f / 255.0f)
@@ -487,6 +487,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
 #endif
         // One staged splat against the quadrants it can reach: the 10 per-lane sums in acc, the splat's 1/opacity in inv_opac; false if
         // no pixel blended it (acc is then undefined and nothing is reduced or parked).
+        // (ADK_BWD_FIRST reads c0..c9 only after the first blending quadrant has written them -- `touched` --, which the compiler cannot see: the
+        // diagnostic is silenced for this lambda alone, not for the file)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
         auto eval_splat = [&](const int t, float (&acc)[NACC], float& inv_opac) -> bool {
 #if ADK_CULL_BALLOT_BWD
             const unsigned long long bit = 1ull << t;
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
 #endif
             return touched != 0;
         };
+#pragma clang diagnostic pop
         while (any) {
             const int t = __builtin_ctzll(any); // staged slot t holds list index batch_end - t (0 = furthest back)
             any &= any - 1;

@@ -40,11 +40,34 @@ def _parse_header():
     return fields, stages
 
 
-_FIELDS, STAGES = _parse_header()
+class _Lazy:
+    """The header is parsed on first use, not at import: `import artdeco_amd.fused` must work (and ARTDECO_AMD_NATIVE_STEP=0 must be
+    honoured) on an installation whose header is missing or older; `enabled()` then simply says no."""
+    fields = stages = args_type = None
+    error = None
 
 
-class StepArgs(ctypes.Structure):
-    _fields_ = [(name, _KIND[kind]) for kind, name in _FIELDS]
+def _ensure_parsed() -> bool:
+    if _Lazy.fields is not None:
+        return True
+    if _Lazy.error is not None:
+        return False
+    try:
+        fields, stages = _parse_header()
+    except (OSError, _lib.AdkError) as e:
+        _Lazy.error = e
+        return False
+    _Lazy.fields, _Lazy.stages = fields, stages
+    _Lazy.args_type = type("StepArgs", (ctypes.Structure,), {"_fields_": [(name, _KIND[kind]) for kind, name in fields]})
+    return True
+
+
+def __getattr__(name):      # module attributes that need the header: _FIELDS, STAGES, StepArgs
+    if name in ("_FIELDS", "STAGES", "StepArgs"):
+        if not _ensure_parsed():
+            raise _Lazy.error
+        return {"_FIELDS": _Lazy.fields, "STAGES": _Lazy.stages, "StepArgs": _Lazy.args_type}[name]
+    raise AttributeError(name)
 
 
 class StepOut(ctypes.Structure):
@@ -59,16 +82,17 @@ def _check_layout(lib) -> None:
     global _checked
     if _checked:
         return
-    if int(lib.adk_mapper_step_args_bytes()) != ctypes.sizeof(StepArgs):
+    if int(lib.adk_mapper_step_args_bytes()) != ctypes.sizeof(_Lazy.args_type):
         raise _lib.AdkError(f"AdkMapperStepArgs: the library's struct has {int(lib.adk_mapper_step_args_bytes())} bytes, the binding's "
-                            f"{ctypes.sizeof(StepArgs)} (header and library out of step: rebuild)")
+                            f"{ctypes.sizeof(_Lazy.args_type)} (header and library out of step: rebuild)")
     _checked = True
 
 
 def enabled() -> bool:
     """On unless ARTDECO_AMD_NATIVE_STEP=0, or ARTDECO_AMD_LOD_ADAM=1 asks for the (slower, opt-in) Gaussian Adam inside the LoD backward,
     which only the per-stage chain offers."""
-    return os.environ.get("ARTDECO_AMD_NATIVE_STEP", "1") != "0" and os.environ.get("ARTDECO_AMD_LOD_ADAM", "0") != "1"
+    return (os.environ.get("ARTDECO_AMD_NATIVE_STEP", "1") != "0" and os.environ.get("ARTDECO_AMD_LOD_ADAM", "0") != "1"
+            and _ensure_parsed())
 
 
 def _round_cap(n: int) -> int:
@@ -76,7 +100,8 @@ def _round_cap(n: int) -> int:
 
 
 _NW = 32 * 32 + 32 + 7 * 32 + 7
-STATS = {"native": 0, "fallback_layout": 0, "fallback_route": 0, "capacity_retries": 0, "plans_built": 0, "long_list_steps": 0, "wait_ns": 0}
+STATS = {"native": 0, "fallback_layout": 0, "fallback_route": 0, "capacity_retries": 0, "plans_built": 0, "long_list_steps": 0, "wait_ns": 0,
+         "plan_bytes": 0}    # plan_bytes: device memory held by the step plans of the most recently stepped scene (shared buffers counted once)
 
 
 _N_GRAIN = int(os.environ.get("ARTDECO_AMD_PLAN_GRAIN", 1 << 16))   # 1 = exact sizes (a plan per N: the lab's A/B)
@@ -93,14 +118,24 @@ class StepPlan:
     million keeps the plan -- no allocation of new sizes (each a hipMalloc, a stall of the whole stream), only new views of the same buffers
     for the leaves' `.grad` (`set_sizes`)."""
 
-    def __init__(self, lib, dev, N, V, W, H, tile_px, capacity):
+    #: buffers whose size depends on the map only (N Gaussians, V voxels): ONE set per scene, shared by the plans of all its resolutions
+    #: (pyramid levels, densification renders): ~330 B per Gaussian + the LoD workspace that every extra plan used to duplicate
+    PER_MAP = frozenset(("opac", "scale", "quat", "sel", "rec", "radii", "depth_keys", "gauss_ids", "tiles_per_gauss", "vis", "gvis", "v_rec",
+                         "v_means", "v_quats", "v_scales", "v_opac", "v_opacity_raw", "v_scaling_raw", "v_rotation", "v_local_feat",
+                         "v_global_feat", "lod_ws", "v_dc", "v_rest"))
+
+    def __init__(self, lib, dev, N, V, W, H, tile_px, capacity, shared=None):
         self.n, self.v = -1, -1
         N, V = _round_up(N, _N_GRAIN), _round_up(V, _V_GRAIN)
+        if shared is None or shared.get("key") != (dev, N, V):
+            shared = {"key": (dev, N, V), "t": {}}
+        self.shared = shared
         self.dev, self.N, self.V, self.W, self.H, self.tile_px = dev, N, V, W, H, tile_px
-        self.args = StepArgs()
+        self.args = _Lazy.args_type()
         self.out = StepOut()
         self.t: dict[str, torch.Tensor] = {}
-        self.bound: tuple = ()          # the tensors whose pointers the block currently holds (kept alive, compared with `is`)
+        self.bound: tuple = ()          # the tensors whose pointers the block currently holds (kept alive, compared with `is`) ...
+        self.bound_ptrs: tuple = ()     # ... and their data_ptr()s: a storage swap that keeps the tensor's identity (`.data = ...`, `set_`, `module.to()`)
         self.route_miss = 0
         self.skip_until = 0
         self.calls = 0
@@ -110,7 +145,13 @@ class StepPlan:
         tpw, tph = tile_px
         tile_w, tile_h = (W + tpw - 1) // tpw, (H + tph - 1) // tph
         n_sums = int(lib.adk_fused_ssim_fwd_sums_count(1, 3, H, W))
-        e = lambda name, *shape, **kw: self.t.__setitem__(name, torch.empty(*shape, **kw))
+        def e(name, *shape, **kw):
+            if name in self.PER_MAP:
+                if name not in shared["t"]:
+                    shared["t"][name] = torch.empty(*shape, **kw)
+                self.t[name] = shared["t"][name]
+            else:
+                self.t[name] = torch.empty(*shape, **kw)
         e("viewmat", 4, 4, **f32); e("opac", N, **f32); e("scale", N, 3, **f32); e("quat", N, 4, **f32)
         e("sel", N, dtype=torch.bool, device=dev); e("rec", N, 12, **f32); e("radii", N, 2, **i32)
         e("depth_keys", N, **i32); e("gauss_ids", N, **i32); e("tiles_per_gauss", N, **i32)
@@ -172,8 +213,11 @@ class StepPlan:
     def color_grads(self, f_dc, f_rest):
         """Gradient buffers of the SH colours: only a test keyframe's step needs them (no colour Adam inside the projection backward)."""
         if "v_dc" not in self.t or self.t["v_rest"].shape[1:] != f_rest.shape[1:]:
-            self.t["v_dc"] = torch.empty((self.N,) + tuple(f_dc.shape[1:]), dtype=torch.float32, device=self.dev)
-            self.t["v_rest"] = torch.empty((self.N,) + tuple(f_rest.shape[1:]), dtype=torch.float32, device=self.dev)
+            st = self.shared["t"]
+            if "v_dc" not in st or st["v_rest"].shape[1:] != f_rest.shape[1:]:
+                st["v_dc"] = torch.empty((self.N,) + tuple(f_dc.shape[1:]), dtype=torch.float32, device=self.dev)
+                st["v_rest"] = torch.empty((self.N,) + tuple(f_rest.shape[1:]), dtype=torch.float32, device=self.dev)
+            self.t["v_dc"], self.t["v_rest"] = st["v_dc"], st["v_rest"]
             self.grads["f_dc"], self.grads["f_rest"] = self.t["v_dc"][:self.n], self.t["v_rest"][:self.n]
         self.args.v_dc, self.args.v_rest = self.t["v_dc"].data_ptr(), self.t["v_rest"].data_ptr()
         return self.grads["f_dc"], self.grads["f_rest"]
@@ -191,8 +235,20 @@ def _plan_for(scene, lib, dev, N, V, W, H, tile_px):
         hint = rasterizer._CAPACITY_HINT.get((dev.index, W, H, tile_px[0]))
         cap = int(hint * 1.25) if hint else (plan.args.isect_capacity if plan is not None else 4 * N)
         skip = plan.skip_until - plan.calls if plan is not None else 0
-        plan = plans[key] = StepPlan(lib, dev, N, V, W, H, tile_px, cap)
+        plans.pop(key, None)            # the superseded plan goes NOW (its image-sized buffers; the leaves' .grad may still hold views of the per-map set)
+        plan = None
+        # the per-map buffers of the scene's most recent plan: reused when the capacities agree (another resolution of the same map)
+        shared = scene.__dict__.get("_adk_step_shared")
+        plan = plans[key] = StepPlan(lib, dev, N, V, W, H, tile_px, cap, shared)
+        scene.__dict__["_adk_step_shared"] = plan.shared
         plan.skip_until = max(skip, 0)
+        seen, total = set(), 0
+        for pl in plans.values():
+            for ten in pl.t.values():
+                if ten.data_ptr() not in seen:
+                    seen.add(ten.data_ptr())
+                    total += ten.numel() * ten.element_size()
+        STATS["plan_bytes"] = total
     plan.set_sizes(N, V)
     return plan
 
@@ -261,7 +317,8 @@ def train_on_keyframe(scene, keyframe, is_important):
     # ---- pointers of the scene's / keyframe's own tensors: rewritten only when one of the objects changed
     cs = color_state
     bound = leaves + (cls_id, d_max, f_dc, f_rest, r6, t, E, gt, mono, rdk, K) + ((cs["m_dc"], cs["v_dc"], cs["m_rest"], cs["v_rest"], cs["lr_dc"], cs["lr_rest"]) if cs else ())
-    if len(bound) != len(plan.bound) or any(a is not b for a, b in zip(bound, plan.bound)):
+    ptrs = tuple(x.data_ptr() for x in bound)
+    if ptrs != plan.bound_ptrs or len(bound) != len(plan.bound) or any(a is not b for a, b in zip(bound, plan.bound)):
         (A.xyz, A.opacity_raw, A.scaling_raw, A.rotation, A.local_feat, A.global_feat, A.W1, A.b1, A.W2, A.b2) = (x.data_ptr() for x in leaves)
         A.cls_id, A.d_max, A.f_dc, A.f_rest = cls_id.data_ptr(), d_max.data_ptr(), f_dc.data_ptr(), f_rest.data_ptr()
         A.r6, A.t, A.exposure, A.gt, A.mono, A.rdk, A.Kmat = (r6.data_ptr(), t.data_ptr(), E.data_ptr(), gt.data_ptr(), mono.data_ptr(),
@@ -270,7 +327,7 @@ def train_on_keyframe(scene, keyframe, is_important):
             (A.exp_avg_dc, A.exp_avg_sq_dc, A.exp_avg_rest, A.exp_avg_sq_rest, A.lr_dc, A.lr_rest) = (
                 cs["m_dc"].data_ptr(), cs["v_dc"].data_ptr(), cs["m_rest"].data_ptr(), cs["v_rest"].data_ptr(), cs["lr_dc"].data_ptr(),
                 cs["lr_rest"].data_ptr())
-        plan.bound = bound
+        plan.bound, plan.bound_ptrs = bound, ptrs
     if cs:
         A.color_adam = 1
         A.adam_b1, A.adam_b2, A.adam_eps = float(cs["betas"][0]), float(cs["betas"][1]), float(cs["eps"])
@@ -283,7 +340,7 @@ def train_on_keyframe(scene, keyframe, is_important):
     A.eps2d, A.near_plane, A.far_plane, A.radius_clip = float(eps2d), 0.01, 1e10, 0.0
     A.lambda_dssim, A.depth_weight, A.ssim_grad_scale = lam, wd, -lam / float(3 * H * W)
     timer = rasterizer._TIMER
-    A.time_mask = 0 if timer is None else sum(1 << i for i, s in enumerate(STAGES) if timer.only is None or s in timer.only)
+    A.time_mask = 0 if timer is None else sum(1 << i for i, s in enumerate(_Lazy.stages) if timer.only is None or s in timer.only)
     with torch.no_grad(), _lib.on_device(dev):
         bg = torch.rand(3, device=dev)                                   # the reference's draw (h3dgsv3.py:421), same generator stream
         loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -312,7 +369,7 @@ def train_on_keyframe(scene, keyframe, is_important):
         return None, bg
     if rc != 0:
         plan.t["cam_grad"].zero_()
-        stage = STAGES[plan.out.stage] if 0 <= plan.out.stage < len(STAGES) else "?"
+        stage = _Lazy.stages[plan.out.stage] if 0 <= plan.out.stage < len(_Lazy.stages) else "?"
         _lib.check(rc, f"adk_mapper_step (stage {stage})")
     plan.route_miss = 0
     STATS["native"] += 1
@@ -349,8 +406,13 @@ def train_on_keyframe(scene, keyframe, is_important):
 
 def drain_timings(lib=None):
     """{stage: (sum_ms, min_ms, count)} of the event pairs the native steps recorded since the last call (waits for them)."""
+    if lib is None and not _lib.is_loaded():
+        return {}                      # nothing can have been recorded: do not load (or require) the library for this
+    if not _ensure_parsed():
+        return {}
     lib = lib or _lib.load()
-    n = len(STAGES)
+    stages = _Lazy.stages
+    n = len(stages)
     S, M, C = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
     lib.adk_mapper_step_timings(S, M, C)
-    return {STAGES[i]: (S[i], M[i], int(C[i])) for i in range(n) if C[i] > 0}
+    return {stages[i]: (S[i], M[i], int(C[i])) for i in range(n) if C[i] > 0}

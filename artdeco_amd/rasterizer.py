@@ -66,9 +66,10 @@ _NULL = contextlib.nullcontext()
 
 def set_stage_timer(t: StageTimer | None) -> None:
     global _TIMER
-    if t is not None:
-        from . import native_step
-        native_step.drain_timings()   # pairs recorded under a previous timer are not this one's
+    from . import native_step
+    # pairs recorded under a previous timer are not the next one's, and a timer that is removed without summary_ms() must not leave its
+    # events behind on the C side (drain_timings() is a no-op while the library has not been loaded)
+    native_step.drain_timings()
     _TIMER = t
 
 

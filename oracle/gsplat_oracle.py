@@ -308,14 +308,27 @@ def _tile_decisions(m2, cn, op, px, py):
     return keep, live, ov, T_incl, T_excl, sigma
 
 
-def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, knife_eps=None, decide=None):
+def knife_pairs(dec, keep, eps, eps_T=None):
+    """bool [n, P]: the (splat, pixel) pairs of `_tile_decisions` output `dec` that sit on one of the rasteriser's DISCONTINUITIES while the
+    pixel is still live -- alpha within a relative `eps` of 1/255 (skip) or of 0.999 (clamp), sigma at 0, or the transmittance after a kept
+    splat within a relative `eps_T` (default eps) of 1e-4 (terminate)."""
+    ov, Ti, Te, sg = dec[2], dec[3], dec[4], dec[5]
+    eps_T = eps if eps_T is None else eps_T
+    reached = Te > TRANSMITTANCE_EPS * (1.0 - eps_T)
+    near = ((ov * 255.0 - 1.0).abs() <= eps) | ((ov - MAX_ALPHA).abs() <= eps * MAX_ALPHA) \
+        | (sg.abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= eps_T * TRANSMITTANCE_EPS))
+    return near & reached
+
+
+def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, knife_eps=None, decide=None, knife_eps_T=None):
     """ONE tile of rasterize_to_pixels_fwd (App. A item 4), vectorised over [n splats in list order, P pixels], autograd-capable.
 
     m2 [n,2], cn [n,3], col [n,CDIM], op [n] of the tile's list (depth order); px, py [P] pixel centres; first_index = position of the
     list's first entry in the sorted intersection list.  Returns (colour [P,CDIM], T_final [P], last index int32 [P], extras or None);
-    extras = (knife bool [P], main list position int64 [P] (-1: none), main_w [P], second_w [P], touch bool [n,P]) -- `touch` marks the
-    (splat, pixel) pairs that either contribute (alpha T > 0) or sit on a decision within knife_eps while the pixel is still live: the
-    pairs whose gradients move if that pixel's decisions fall differently.
+    extras = (knife bool [P], main list position int64 [P] (-1: none), main_w [P], second_w [P], touch bool [n,P], skip_knife bool [P]) --
+    `touch` marks the (splat, pixel) pairs that either contribute (alpha T > 0) or sit on a SKIP / clamp decision within knife_eps while the
+    pixel is still live: the pairs whose gradients move if that pixel's decisions fall differently; `skip_knife` = `knife` without the
+    termination edge (a splat entering or leaving at T = 1e-4 moves nothing a gradient comparison sees).
     decide = (m2, cn, op) in float32: the per-pixel DECISIONS (skip below 1/255, terminate at T <= 1e-4) are taken by a single-precision
     evaluation of these -- the values an fp32 rasteriser decides on -- and the differentiable arithmetic of the call's own dtype runs ON
     them (the knife band of `extras` is then measured on the fp32 values too: where ANOTHER fp32 evaluation may still decide otherwise)."""
@@ -353,10 +366,9 @@ def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, kn
                 ov, Ti, Te, sg = dec[2], dec[3], dec[4], dec[5]
             else:
                 ov, Ti, Te, sg = (op[:, None] * torch.exp(-sigma)).detach(), T_incl.detach(), T_excl.detach(), sigma.detach()
-            reached = Te > TRANSMITTANCE_EPS * (1.0 - eps)
-            near = ((ov * 255.0 - 1.0).abs() <= eps) | ((ov - MAX_ALPHA).abs() <= eps * MAX_ALPHA) \
-                | (sg.abs() <= 1e-6) | (keep & ((Ti - TRANSMITTANCE_EPS).abs() <= eps * TRANSMITTANCE_EPS))
-            knife = (near & reached).any(0)
+            on_edge = knife_pairs((None, None, ov, Ti, Te, sg), keep, eps, knife_eps_T)
+            on_skip_edge = knife_pairs((None, None, ov, Ti, Te, sg), keep, eps, 0.0)     # without the termination edge
+            knife = on_edge.any(0)
             wd = w.detach()
             k = min(2, n)
             top = torch.topk(wd, k, dim=0)
@@ -364,7 +376,7 @@ def composite_tile(m2, cn, col, op, px, py, first_index=0, want_extras=False, kn
             w2 = top.values[1] if k > 1 else torch.zeros_like(w1)
             first = (wd == w1[None, :]).to(torch.int8).argmax(0)  # first list position holding the maximum
             main = torch.where(w1 > 0, first, torch.full_like(first, -1))
-            extras = (knife, main, w1, w2, (wd > 0) | (near & reached))
+            extras = (knife, main, w1, w2, (wd > 0) | on_skip_edge, on_skip_edge.any(0))
     return colour, T_final, lastk, extras
 
 

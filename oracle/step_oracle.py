@@ -51,6 +51,13 @@ KF_KEYS = ("kf.rW2C", "kf.tW2C", "kf.exposure")
 #: relative half-width of the band around a rasteriser decision inside which an fp32 evaluation may fall on the other side
 #: (fp32 alpha / transmittance carry ~1e-6 relative error after a few hundred blended splats)
 KNIFE_EPS = 2e-5
+#: the same for the termination test T (1 - alpha) <= 1e-4: T is a product of hundreds of factors, two fp32 evaluations drift apart further
+KNIFE_EPS_T = 1e-3
+#: pixels per call of composite_tile: [n, 64] float64 temporaries stay in a core's L2 (whole 16x16 tiles made the tile passes DRAM-bound
+#: with a node's worth of workers: 96 workers only 2x faster than 8)
+P_BLOCK = 64
+#: intra-op threads of the serial phases (projection graph, SSIM, final backward): the test process itself runs torch single-threaded
+SERIAL_THREADS = 16
 #: half-width of the band around an image-space decision of the loss (sign of an L1 term, clamp at 0 / 1, the 0.2 outlier threshold)
 IMAGE_KNIFE_TOL = 2e-5
 
@@ -142,6 +149,7 @@ _POOL_WORKERS = 0
 _WORKER_PREFIX = None
 _PASS1 = ("means2d", "conics", "feat", "opac", "flat", "offsets", "means2d32", "conics32", "opac32")
 _PASS2 = ("g_col", "g_T", "knife_px")
+_SCAN = ("flat", "offsets", "means2d32", "conics32", "opac32")
 
 
 def _publish(prefix, names):
@@ -149,7 +157,8 @@ def _publish(prefix, names):
         v = _SH[k]
         np.save(f"{prefix}.{k}.npy", v.numpy() if torch.is_tensor(v) else np.asarray(v))
     with open(f"{prefix}.scalars.json", "w") as f:
-        json.dump({"n_isects": int(_SH["n_isects"]), "tile_w": int(_SH["tile_w"]), "knife_eps": float(_SH["knife_eps"])}, f)
+        json.dump({"n_isects": int(_SH["n_isects"]), "tile_w": int(_SH["tile_w"]), "knife_eps": float(_SH["knife_eps"]),
+                   "knife_eps_T": float(_SH["knife_eps_T"])}, f)
 
 
 def _attach(prefix, names):
@@ -189,6 +198,7 @@ def _fwd_chunk(task):
     if prefix is not None:
         _attach(prefix, _PASS1)
     m2, cn, ft, op, flat = _SH["means2d"], _SH["conics"], _SH["feat"], _SH["opac"], _SH["flat"]
+    eps, eps_T = _SH["knife_eps"], _SH["knife_eps_T"]
     out = []
     with torch.no_grad():
         for tid in tids:
@@ -197,9 +207,14 @@ def _fwd_chunk(task):
                 continue
             g = flat[s:e]
             px, py, tx, ty = _tile_pixels(tid, m2.dtype)
-            col, T, last, ex = go.composite_tile(m2[g], cn[g], ft[g], op[g], px, py, first_index=s, want_extras=True,
-                                                 knife_eps=_SH["knife_eps"], decide=_decide(g))
-            out.append((tid, col.numpy(), T.numpy(), ex[0].numpy()))
+            a, b, c, d, dec = m2[g], cn[g], ft[g], op[g], _decide(g)
+            cols, Ts, kns = [], [], []
+            for p0 in range(0, px.shape[0], P_BLOCK):
+                sl = slice(p0, p0 + P_BLOCK)
+                col, T, last, ex = go.composite_tile(a, b, c, d, px[sl], py[sl], first_index=s, want_extras=True, knife_eps=eps,
+                                                     decide=dec, knife_eps_T=eps_T)
+                cols.append(col); Ts.append(T); kns.append(ex[0].to(torch.uint8) + 2 * ex[5].to(torch.uint8))   # bit 0: any edge, bit 1: skip edge
+            out.append((tid, torch.cat(cols).numpy(), torch.cat(Ts).numpy(), torch.cat(kns).numpy()))
     return out
 
 
@@ -209,6 +224,7 @@ def _bwd_chunk(task):
         _attach(prefix, _PASS1 + _PASS2)
     m2, cn, ft, op, flat = _SH["means2d"], _SH["conics"], _SH["feat"], _SH["opac"], _SH["flat"]
     g_col, g_T, knife = _SH["g_col"], _SH["g_T"], _SH["knife_px"]
+    eps, eps_T = _SH["knife_eps"], _SH["knife_eps_T"]
     ids_all, grads_all, touched = [], [], []
     for tid in tids:
         s, e = _span(tid)
@@ -216,17 +232,23 @@ def _bwd_chunk(task):
             continue
         g = flat[s:e]
         px, py, tx, ty = _tile_pixels(tid, m2.dtype)
-        sl = (slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE))
+        sl2 = (slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE))
         leaves = [t[g].clone().requires_grad_(True) for t in (m2, cn, ft, op)]
-        kn = knife[sl].reshape(-1)
-        col, T, last, ex = go.composite_tile(*leaves, px, py, first_index=s, want_extras=bool(kn.any()), knife_eps=_SH["knife_eps"],
-                                             decide=_decide(g))
-        scalar = (col * g_col[sl].reshape(-1, col.shape[1])).sum() + (T * g_T[sl].reshape(-1)).sum()
-        scalar.backward()
+        gc, gT, kn = g_col[sl2].reshape(-1, ft.shape[1]), g_T[sl2].reshape(-1), knife[sl2].reshape(-1)
+        dec = _decide(g)
+        hit = torch.zeros(g.shape[0], dtype=torch.bool)
+        for p0 in range(0, px.shape[0], P_BLOCK):
+            sl = slice(p0, p0 + P_BLOCK)
+            want = bool(kn[sl].any())
+            col, T, last, ex = go.composite_tile(*leaves, px[sl], py[sl], first_index=s, want_extras=want, knife_eps=eps, decide=dec,
+                                                 knife_eps_T=eps_T)
+            ((col * gc[sl]).sum() + (T * gT[sl]).sum()).backward()       # accumulates into the leaves' .grad
+            if want:
+                hit |= ex[4][:, kn[sl]].any(1)
         ids_all.append(g.numpy())
         grads_all.append(np.concatenate([l.grad.reshape(g.shape[0], -1).numpy() for l in leaves], axis=1))   # [n, 2+3+4+1]
-        if ex is not None:
-            touched.append(g[ex[4][:, kn].any(1)].numpy())
+        if bool(hit.any()):
+            touched.append(g[hit].numpy())
     if not ids_all:
         return None
     ids = np.concatenate(ids_all)
@@ -235,6 +257,34 @@ def _bwd_chunk(task):
     acc = np.zeros((uniq.shape[0], gr.shape[1]))
     np.add.at(acc, inv, gr)
     return uniq, acc, (np.unique(np.concatenate(touched)) if touched else np.zeros(0, np.int64))
+
+
+def _scan_chunk(task):
+    """fp32 decisions only: the Gaussians (rows of the selected set) that sit ON a decision at some live pixel, and how many such
+    (splat, pixel) pairs / pixels there are."""
+    prefix, tids = task
+    if prefix is not None:
+        _attach(prefix, _SCAN)
+    flat = _SH["flat"]
+    eps, eps_T = _SH["knife_eps"], _SH["knife_eps_T"]
+    rows, n_pairs, n_pix = [], 0, 0
+    with torch.no_grad():
+        for tid in tids:
+            s, e = _span(tid)
+            if e <= s:
+                continue
+            g = flat[s:e]
+            px, py, tx, ty = _tile_pixels(tid, torch.float32)
+            a, b, d = _decide(g)
+            for p0 in range(0, px.shape[0], P_BLOCK):
+                sl = slice(p0, p0 + P_BLOCK)
+                dec = go._tile_decisions(a, b, d, px[sl], py[sl])
+                on_edge = go.knife_pairs(dec, dec[0], eps, eps_T)
+                if bool(on_edge.any()):
+                    rows.append(g[on_edge.any(1)].numpy())
+                    n_pairs += int(on_edge.sum())
+                    n_pix += int(on_edge.any(0).sum())
+    return (np.unique(np.concatenate(rows)) if rows else np.zeros(0, np.int64)), n_pairs, n_pix
 
 
 def _chunks(workers):
@@ -298,7 +348,95 @@ def default_workers():
 
 
 # ----------------------------------------------------------------------------- the step
-def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_targets=None, knife_eps=KNIFE_EPS,
+class _threads:
+    """torch intra-op threads for the serial phases (the caller's setting is restored)."""
+
+    def __init__(self, n):
+        self.n = max(1, min(n, default_workers()))
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(self.n)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.old)
+
+
+def _fp32_decisions(state, kf, cfg):
+    """Phase A: every decision of the step's forward with the reference's own fp32 operations (harness/mapper.py:render is the same chain)."""
+    W, H = cfg["width"], cfg["height"]
+    f32 = torch.float32
+    st32 = {k: (v.to(f32) if v.is_floating_point() else v) for k, v in state.items()}
+    with torch.no_grad():
+        Rt32 = get_Rt(kf["rW2C"].to(f32), kf["tW2C"].to(f32))
+        par32, dec = _lod_and_params(st32, Rt32)
+        fl_x, fl_y = W / (2 * cfg["tanfovx"]), H / (2 * cfg["tanfovy"])
+        K32 = torch.tensor([[fl_x, 0, W / 2.0], [0, fl_y, H / 2.0], [0, 0, 1]], dtype=f32)
+        p32 = go.project(par32["xyz"], par32["rotation"], par32["scaling"], par32["opacity"], Rt32, K32, W, H, cfg["eps2d"])
+        isects = go.isect_tiles(p32["means2d"], p32["radii"], p32["depths"], W, H)
+    return st32, par32, dec, K32, p32, isects
+
+
+def knife_scan(state, kf, cfg, *, workers=None, knife_eps=KNIFE_EPS, knife_eps_T=KNIFE_EPS_T):
+    """Which Gaussians (bool [N]) sit ON a per-pixel decision of the rasteriser for this view -- fp32 evaluation, (splat, pixel) pairs within
+    `knife_eps` of alpha = 1/255 / 0.999 or within `knife_eps_T` of the termination threshold -- and the number of such pairs and pixels."""
+    workers = default_workers() if workers is None else workers
+    with _threads(SERIAL_THREADS):
+        st32, par32, dec, K32, p32, isects = _fp32_decisions(state, kf, cfg)
+    _SH.clear()
+    _SH.update(means2d32=p32["means2d"], conics32=p32["conics"], opac32=par32["opacity"],
+               flat=torch.from_numpy(isects["flatten_ids"].astype(np.int64)), offsets=isects["offsets"].reshape(-1), n_isects=isects["n_isects"],
+               tile_w=isects["tile_w"], grid=torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij"), knife_eps=knife_eps,
+               knife_eps_T=knife_eps_T)
+    chunks = _chunks(workers)
+    tmpdir = prefix = None
+    if workers > 1 and len(chunks) > 1:
+        tmpdir = tempfile.mkdtemp(prefix="adk_step_oracle_")
+        prefix = os.path.join(tmpdir, "frame")
+        _publish(prefix, _SCAN)
+    sel_rows = torch.zeros(par32["opacity"].shape[0], dtype=torch.bool)
+    pairs = pixels = 0
+    for rows, n_pairs, n_pix in _run(_scan_chunk, chunks, workers, prefix):
+        sel_rows[torch.from_numpy(rows)] = True
+        pairs += n_pairs
+        pixels += n_pix
+    _SH.clear()
+    if tmpdir:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    on_edge = torch.zeros(state["xyz"].shape[0], dtype=torch.bool)
+    on_edge[torch.nonzero(dec["selection_mask"]).squeeze(-1)[sel_rows]] = True
+    return on_edge, pairs, pixels
+
+
+def settle_scene(state, kf, cfg, *, workers=None, knife_eps=1e-4, knife_eps_T=0.0, nudge=2e-3, max_rounds=6, log=None):
+    """A TEST's way of keeping its own scene off the rasteriser's knife edges (as `adjust_targets` does for the loss's): the opacity of every
+    Gaussian that sits on a SKIP decision at some pixel of this view -- alpha within `knife_eps` of 1/255 (or of 0.999), far wider than two
+    fp32 evaluations differ -- is raised by a relative `nudge`, and the view is scanned again, until no (splat, pixel) pair is left on such
+    an edge (each round leaves ~1e-5 of the moved pairs on a new one).  The TERMINATION edge (T (1 - alpha) against 1e-4) is left alone by
+    default (knife_eps_T = 0): a transmittance is the product of hundreds of factors, ~1 % of the terminating pixels pass within 1e-3 of the
+    threshold whatever one splat's opacity is, and a splat that enters or leaves there carries a weight <= 1e-4 -- nothing a gradient
+    comparison at 1e-4 sees; pixel-level comparisons mask those pixels (`raster_knife` of optimisation_step, which keeps KNIFE_EPS_T).
+    Returns (state with the adjusted `opacity` logits, rounds, pairs left)."""
+    state = dict(state)
+    state["opacity"] = state["opacity"].clone()
+    pairs, last = -1, None
+    for r in range(max_rounds):
+        on_edge, pairs, pixels = knife_scan(state, kf, cfg, workers=workers, knife_eps=knife_eps, knife_eps_T=knife_eps_T)
+        if log is not None:
+            log.append((r, int(on_edge.sum()), pairs, pixels))
+        if pairs == 0 or (last is not None and pairs >= last):   # the few that opacity cannot move: a pixel centre ON a splat's centre (sigma = 0)
+            return state, r, pairs
+        last = pairs
+        x = state["opacity"][on_edge]
+        # d ln sigmoid(x) / dx = 1 - sigmoid(x): the step that multiplies the opacity by (1 + nudge)
+        state["opacity"][on_edge] = x + (nudge / (1.0 - torch.sigmoid(x)).clamp_min(1e-3)).clamp_max(0.5)
+    on_edge, pairs, pixels = knife_scan(state, kf, cfg, workers=workers, knife_eps=knife_eps, knife_eps_T=knife_eps_T)
+    if log is not None:
+        log.append((max_rounds, int(on_edge.sum()), pairs, pixels))
+    return state, max_rounds, pairs
+
+
+def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_targets=None, knife_eps=KNIFE_EPS, knife_eps_T=KNIFE_EPS_T,
                       image_knife_tol=IMAGE_KNIFE_TOL, want_grads=True, dtype=torch.float64, knife_rows_from="image", timings=None):
     """One `optimization_step` up to (not including) the optimisers.  state / kf / cfg: `snapshot()`.  bg: the step's random background
     [3].  adjust_targets(image [3,H,W] fp64, invdepth [1,H,W] fp64, gt, mono) -> (gt, mono): lets a TEST move its own targets off the
@@ -309,9 +447,10 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
     `knife_rows` marks).  timings: a dict that receives the seconds of each phase.
 
     Returns dict: loss (float), image [3,H,W] (exposed, clamped), invdepth [1,H,W], visibility bool [N], global_visibility bool [Nvox],
-    grads {15 leaves: GAUSS_KEYS, MLP_KEYS, KF_KEYS} fp64, raster_knife / image_knife bool [H,W], knife_rows bool [N] (Gaussians that
-    contribute to an IMAGE-knife pixel: their gradient moves if the loss decides that pixel the other way), gt / mono (the targets used),
-    n_isects, selected."""
+    grads {15 leaves: GAUSS_KEYS, MLP_KEYS, KF_KEYS} fp64, raster_knife (any rasteriser edge, the termination edge at KNIFE_EPS_T included:
+    what a pixel-level comparison masks) / skip_knife (the skip / clamp edges only) / image_knife bool [H,W], knife_rows bool [N] (Gaussians
+    that contribute to a pixel of the set `knife_rows_from` names: their gradient moves if that pixel is decided the other way), gt / mono
+    (the targets used), n_isects, selected."""
     W, H = cfg["width"], cfg["height"]
     workers = default_workers() if workers is None else workers
     f32, f64 = torch.float32, dtype
@@ -322,23 +461,16 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
             now = time.time()
             timings[name] = timings.get(name, 0.0) + now - _t[0]
             _t[0] = now
-    st32 = {k: (v.to(f32) if v.is_floating_point() else v) for k, v in state.items()}
+    serial = _threads(SERIAL_THREADS)
+    serial.__enter__()
+    st32, par32, dec, K32, p32, isects = _fp32_decisions(state, kf, cfg)
     N = st32["xyz"].shape[0]
-
-    # ---- A. the fp32 pass: every decision, with the reference's own operations (harness/mapper.py:render is the same chain)
     with torch.no_grad():
-        Rt32 = get_Rt(kf["rW2C"].to(f32), kf["tW2C"].to(f32))
-        par32, dec = _lod_and_params(st32, Rt32)
-        fl_x, fl_y = W / (2 * cfg["tanfovx"]), H / (2 * cfg["tanfovy"])
-        K32 = torch.tensor([[fl_x, 0, W / 2.0], [0, fl_y, H / 2.0], [0, 0, 1]], dtype=f32)
-        p32 = go.project(par32["xyz"], par32["rotation"], par32["scaling"], par32["opacity"], Rt32, K32, W, H, cfg["eps2d"])
-        isects = go.isect_tiles(p32["means2d"], p32["radii"], p32["depths"], W, H)
         sel = dec["selection_mask"]
         visibility = torch.zeros(N, dtype=torch.bool)
         visibility[sel] = p32["radii"].max(dim=1).values > 0
         global_visibility = torch.zeros(st32["global_feat"].shape[0], dtype=torch.bool)
         global_visibility[st32["cls_id"][visibility].squeeze(-1)] = True
-
     lap("A fp32 decisions")
     # ---- B. the differentiable chain in fp64 on those decisions
     leaves = {k: state[k].to(f64).clone().requires_grad_(want_grads) for k in GAUSS_KEYS + MLP_KEYS}
@@ -363,7 +495,8 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
     _SH.update(means2d32=p32["means2d"], conics32=p32["conics"], opac32=par32["opacity"])     # the per-pixel decisions are taken on these
     _SH.update(means2d=ras_in[0].detach(), conics=ras_in[1].detach(), feat=ras_in[2].detach(), opac=ras_in[3].detach(),
                flat=torch.from_numpy(isects["flatten_ids"].astype(np.int64)), offsets=isects["offsets"].reshape(-1), n_isects=isects["n_isects"],
-               tile_w=tile_w, grid=torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij"), knife_eps=knife_eps)
+               tile_w=tile_w, grid=torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij"), knife_eps=knife_eps,
+               knife_eps_T=knife_eps_T)
     chunks = _chunks(workers)
     tmpdir = prefix = None
     if workers > 1 and len(chunks) > 1:
@@ -372,15 +505,16 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
         _publish(prefix, _PASS1)
     render = torch.zeros(Hp, Wp, 4, dtype=f64)
     T_img = torch.ones(Hp, Wp, dtype=f64)
-    raster_knife = torch.zeros(Hp, Wp, dtype=torch.bool)
+    knife_bits = torch.zeros(Hp, Wp, dtype=torch.uint8)
     for res in _run(_fwd_chunk, chunks, workers, prefix):
         for tid, col, T, kn in res:
             ty, tx = divmod(tid, tile_w)
             sl = (slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE))
             render[sl] = torch.from_numpy(col).reshape(TILE, TILE, 4)
             T_img[sl] = torch.from_numpy(T).reshape(TILE, TILE)
-            raster_knife[sl] = torch.from_numpy(kn).reshape(TILE, TILE)
-    render, T_img, raster_knife = render[:H, :W].contiguous(), T_img[:H, :W].contiguous(), raster_knife[:H, :W]
+            knife_bits[sl] = torch.from_numpy(kn).reshape(TILE, TILE)
+    render, T_img, knife_bits = render[:H, :W].contiguous(), T_img[:H, :W].contiguous(), knife_bits[:H, :W]
+    raster_knife, skip_knife = (knife_bits & 1).bool(), (knife_bits & 2).bool()
 
     lap("C tile pass 1")
     # ---- D. the image-space chain (h3dgsv3.py:682-686, 611-614, 428-449)
@@ -425,10 +559,11 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
         if not is_important:
             image_knife |= ((img["outlier_error"][:2] - 0.2).abs() < tol).any(0)
     out = dict(loss=float(loss.detach()), image=img["image"].detach(), invdepth=img["invdepth"].detach(), visibility=visibility,
-               global_visibility=global_visibility, raster_knife=raster_knife, image_knife=image_knife, gt=gt, mono=mono,
+               global_visibility=global_visibility, raster_knife=raster_knife, skip_knife=skip_knife, image_knife=image_knife, gt=gt, mono=mono,
                n_isects=isects["n_isects"], selected=sel, isects=isects, radii=p32["radii"])
     if not want_grads:
         _SH.clear()
+        serial.__exit__()
         if tmpdir:
             shutil.rmtree(tmpdir, ignore_errors=True)
         return out
@@ -440,7 +575,7 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
         full = torch.zeros((Hp, Wp) + tuple(t.shape[2:]), dtype=t.dtype)
         full[:H, :W] = t
         return full
-    knife_px = {"image": image_knife, "raster": raster_knife, "both": image_knife | raster_knife}[knife_rows_from]
+    knife_px = {"image": image_knife, "raster": skip_knife, "both": image_knife | skip_knife}[knife_rows_from]
     _SH.update(g_col=pad(g_render), g_T=pad(g_T), knife_px=pad(knife_px))
     n_sel = ras_in[0].shape[0]
     acc = torch.zeros(n_sel, 10, dtype=f64)
@@ -467,6 +602,7 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
     knife_rows[torch.nonzero(sel).squeeze(-1)[knife_sel]] = True
     out.update(grads=grads, knife_rows=knife_rows)
     lap("F backward to the leaves")
+    serial.__exit__()
     return out
 
 

@@ -96,43 +96,6 @@ def test_fused_render_matches_unfused(lod, dev, monkeypatch):
         assert rel <= 1e-4, (k, rel)
 
 
-def _rows_under_image_knife_pixels(sc, kid, seed, is_important, seen, tol=5e-6):
-    """Pixels on which the LOSS (not the rasteriser) sits on a decision -- |exposed render - target| < tol (sign of an L1 term), exposed
-    render within tol of the clamp bounds 0 / 1, inverse depth within tol of its target, weighted error within tol of the 0.2 outlier
-    threshold -- evaluated on the unfused scene's own render with the background the step is about to draw (torch.manual_seed(seed),
-    first torch.rand(3)).  Returns a bool [N] mask of the Gaussians whose radius box (the rasteriser's own radii: it bounds every pixel
-    the Gaussian can reach) covers such a pixel, or None when there is no such pixel.  `seen`: the spy of _capture_rasteriser_inputs."""
-    with torch.no_grad():
-        kf = sc.keyframes[kid]
-        lvl = kf.pyr_lvl
-        torch.manual_seed(seed)
-        bg = torch.rand(3, device=sc.device)
-        w, h = sc.width // 2 ** lvl, sc.height // 2 ** lvl
-        Rt = kf.get_Rt().to(sc.device)
-        pkg = sc.render(w, h, Rt, bg)
-        raw = ((kf.exposure[:3, :3] @ pkg["render"].view(3, -1)) + kf.exposure[:3, 3, None]).view(3, h, w)
-        gt = kf.image_pyr[lvl]
-        kn = (((raw - gt).abs() < tol) | (raw.abs() < tol) | ((raw - 1).abs() < tol)).any(0)
-        kn |= ((pkg["invdepth"] - kf.get_mono_idepth(lvl)).abs() < tol)[0]
-        if not is_important:
-            err = sc._rdk_for(h, w) * (raw.clamp(0, 1) - gt).abs()
-            kn |= ((err - 0.2).abs() < tol).any(0)
-        if not bool(kn.any()):
-            return None
-        ys, xs = torch.nonzero(kn, as_tuple=True)
-        # the rasteriser saw the LoD-selected subset (harness/mapper.py:render, h3dgsv3.py:626-639): map its rows back
-        cam_centre = Rt.inverse()[:3, 3]
-        selected = torch.nonzero(((sc.xyz - cam_centre).norm(dim=1, keepdim=True) < 2 * sc.d_max).squeeze(-1)).squeeze(-1)
-        radii, m2d = seen[-1]["_radii"].to(sc.device).float(), seen[-1]["_means2d"].to(sc.device)
-        assert radii.shape[0] == selected.shape[0]
-        under = torch.zeros(radii.shape[0], dtype=torch.bool, device=sc.device)
-        for x, y in zip(xs.tolist()[:256], ys.tolist()[:256]):
-            under |= (radii[:, 0] > 0) & ((m2d[:, 0] - (x + 0.5)).abs() <= radii[:, 0] + 1) & ((m2d[:, 1] - (y + 0.5)).abs() <= radii[:, 1] + 1)
-        rows = torch.zeros(sc.xyz.shape[0], dtype=torch.bool, device=sc.device)
-        rows[selected[under]] = True
-        return rows
-
-
 def _sync_state(src, dst):
     """dst <- src: every Gaussian parameter, both Adam moments, the learning rates, the mlp and the keyframes' state."""
     with torch.no_grad():
@@ -154,84 +117,9 @@ def _sync_state(src, dst):
             kb.depth_loss_weight = ka.depth_loss_weight
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", [3, 4, 5, 6, 7])   # five scenes in one process: one green run of one seed was weak evidence (round 3 history)
-@pytest.mark.parametrize("reg", [0.0, 0.05])
-def test_fused_optimization_step_gradients_match_unfused(reg, seed, dev, monkeypatch):
-    """Full optimisation steps (render, loss, backward, pose Adam, sparse Adam) with and without the fused glue FROM THE SAME
-    STATE: the loss and every GRADIENT agree at fp32 tolerance.  Gradients are compared before the optimiser touches
-    them (Adam with eps = 1e-15 and no bias correction turns rounding noise into steps of ~5 lr, so parameters are the wrong
-    thing to compare); the SH colours, whose Adam step the fused path applies inside the projection backward without ever
-    materialising their gradient, are compared through their first moment (from a zero moment: exp_avg = (1 - b1) g on the
-    visible rows).  reg != 0 exercises the scaling regulariser, which must average over the LoD-selected rows only
-    (h3dgsv3.py:443)."""
-    from artdeco_amd import fused
-    a, b = _scene(dev, N=8000, seed=seed), _scene(dev, N=8000, seed=seed)
-    a.scaling_reg_factor = b.scaling_reg_factor = reg
-    assert fused.patch_scene_model(b)
-    seen = _capture_rasteriser_inputs(monkeypatch)      # of the unfused scene `a` (the fused one calls the rasteriser directly)
-    keys = ("xyz", "scaling", "rotation", "opacity", "local_feat", "global_feat")
-    for i in range(3):
-        _sync_state(a, b)
-        for sc in (a, b):   # zero the colour moments so that exp_avg after the step is (1 - b1) * gradient
-            for k in ("f_dc", "f_rest"):
-                sc.optimizer.params[k]["exp_avg"].zero_()
-        near_image_knife = _rows_under_image_knife_pixels(a, i % 2, i, is_important=(i != 1), seen=seen)
-        grads = {}
-        for name, sc in (("a", a), ("b", b)):
-            orig = sc.optimizer.step
-
-            def spy(*args, _o=orig, _sc=sc, _n=name, **kw):
-                grads[_n] = {k: _sc.gaussian_params[k]["val"].grad.clone() for k in keys}
-                grads[_n].update({"mlp." + n: p.grad.clone() for n, p in _sc.mlp_cov.named_parameters()})
-                return _o(*args, **kw)
-            sc.optimizer.step = spy
-            torch.manual_seed(i)
-            loss = float(sc.optimization_step(i % 2, is_important=(i != 1)))
-            sc.optimizer.step = orig
-            grads[name]["loss"] = loss
-        assert abs(grads["a"]["loss"] - grads["b"]["loss"]) <= 2e-5 * max(1.0, abs(grads["a"]["loss"]))
-        # Criterion: rel_l2 <= 2e-4 on every tensor (measured: 1-3e-6; two scenes through the SAME path repeat to 1e-7).  The two
-        # paths hand the rasteriser LoD parameters that differ by an ulp (torch's Linear / exp / sigmoid chain vs lod_params.hip), and
-        # hipBLASLt does not pick the same kernel for the unfused mlp_cov GEMM in every process: in roughly one process in ten a
-        # pixel sits on the alpha >= 1/255 (or T <= 1e-4) decision of one splat, the two paths blend a different splat set there,
-        # and every Gaussian behind it on that pixel sees a different transmittance (tools/lab/grad_noise.py: the difference then
-        # jumps to 2.9e-5 or 4.0e-4).  Whether THIS step is such a step is decided by the oracle, not by the size of the error:
-        # the pixels on which the two paths' rendered inverse depth disagrees must all be pixels the oracle places on a knife edge
-        # (extras["knife"], evaluated on the unfused path's own rasteriser inputs); only then -- a decision really fell
-        # differently, on a pixel where it may -- is the step held to 2e-3 instead of 2e-4.
-        def rel_of(x, y):
-            return float((x - y).norm() / (x.norm() + 1e-30))
-
-        inv_a, inv_b = a.keyframes[i % 2].latest_invdepth, b.keyframes[i % 2].latest_invdepth
-        da, db = torch.nan_to_num(1.0 / inv_a, posinf=0.0), torch.nan_to_num(1.0 / inv_b, posinf=0.0)
-        # a flipped splat moves the pixel's accumulated depth by alpha T z >= (1/255) T z; two evaluations of the SAME decisions agree
-        # to ~1e-6 here (depths <= 6), so 1e-5 separates the two down to T ~ 1e-3, below which the splat's gradient share is nil
-        flipped = ((da - db).abs() > 1e-5)[0]
-        knife = bool(flipped.any())
-        if knife:
-            on_edge = _knife_pixels(seen[-1]).to(dev)
-            assert bool((flipped & ~on_edge).sum() == 0), (i, "the two paths disagree on pixels that are not on a knife edge")
-        per_gauss = {k: (grads["a"][k].double(), grads["b"][k].double()) for k in keys}
-        per_gauss.update({k: (a.optimizer.params[k]["exp_avg"].double(), b.optimizer.params[k]["exp_avg"].double()) for k in ("f_dc", "f_rest")})
-        tol = 2e-3 if knife else 2e-4
-        # The loss has knife edges of its own, in IMAGE space: sign(image - target) of the L1 terms where a rendered value meets its
-        # target, the clamp of the exposed image at 0 and 1, the 0.2 outlier threshold (h3dgsv3.py:432-448).  The two paths' images differ
-        # by ~1e-6; a pixel within 5e-6 of one of these flips dL/dimage there and moves the gradient of the few Gaussians under it by
-        # tens of percent (seed 6, step 0: five rows carried 99.4 % of a 3.8e-3 difference; the CPU-oracle path agrees with BOTH paths to
-        # 1e-6 on another background, tools/lab/fused_grad_diag.py).  Such pixels are identified BEFORE the step from the unfused path's
-        # own render; the Gaussians whose radius box covers one leave the per-Gaussian comparison (they must be few), and
-        # the gradients that sum over all Gaussians (mlp, global_feat) are held to 1e-2 on such a step.
-        summed_tol = tol
-        if near_image_knife is not None:
-            assert float(near_image_knife.float().mean()) < 0.3
-            keep_rows = ~near_image_knife
-            per_gauss = {k: ((x[keep_rows], y[keep_rows]) if x.shape[0] == keep_rows.shape[0] else (x, y)) for k, (x, y) in per_gauss.items()}
-            summed_tol = 1e-2
-        for k, (x, y) in per_gauss.items():
-            assert rel_of(x, y) <= (summed_tol if k == "global_feat" else tol), (i, k, rel_of(x, y), knife, near_image_knife is not None)
-        for k in ["mlp." + n for n, _ in a.mlp_cov.named_parameters()]:
-            assert rel_of(grads["a"][k].double(), grads["b"][k].double()) <= summed_tol, (i, k, knife, near_image_knife is not None)
+# (round 5) test_fused_optimization_step_gradients_match_unfused -- the fused step against the fp32 GPU mirror over five seeds, with its
+# 2e-4 / 2e-3 / 1e-2 tolerance ladder -- is gone: tests/test_step_oracle.py holds the same five seeds, with and without the scaling
+# regulariser, to an fp64 oracle of the whole step at 1e-4 (and the default path at the BASELINE sizes).
 
 
 @pytest.mark.gpu

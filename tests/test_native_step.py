@@ -169,8 +169,8 @@ def test_native_step_grows_its_lists_and_retries(dev, monkeypatch):
     monkeypatch.setattr(native_step.rasterizer, "_CAPACITY_HINT", {})
     real = native_step.StepPlan.__init__
 
-    def tiny(self, lib, dev_, N, V, W, H, tile_px, capacity):
-        real(self, lib, dev_, N, V, W, H, tile_px, 1024)
+    def tiny(self, lib, dev_, N, V, W, H, tile_px, capacity, shared=None):
+        real(self, lib, dev_, N, V, W, H, tile_px, 1024, shared)
     monkeypatch.setattr(native_step.StepPlan, "__init__", tiny)
     r0 = native_step.STATS["capacity_retries"]
     ga = _one_step(a, monkeypatch, True, True)
@@ -312,6 +312,38 @@ def test_the_plan_follows_a_growing_map(dev, monkeypatch):
         g = sc.gaussian_params[k]["val"].grad
         assert g is not None and g.shape == sc.gaussian_params[k]["val"].shape and bool(torch.isfinite(g).all())
     assert all(bool(torch.isfinite(pd["val"]).all()) for pd in sc.optimizer.params.values() if pd["val"].is_floating_point())
+
+
+@pytest.mark.gpu
+def test_plans_of_two_resolutions_share_the_per_map_buffers(dev, monkeypatch):
+    """A scene trained at two pyramid levels has two step plans (image-sized buffers per resolution) over ONE set of per-Gaussian / per-voxel
+    buffers; steps alternate between them and each still matches the per-stage chain."""
+    import torch.nn.functional as F
+    from test_fused_glue import _sync_state
+    from artdeco_amd import fused, native_step
+    a, b = _scene(dev, N=6000, seed=4), _scene(dev, N=6000, seed=4)
+    for sc in (a, b):
+        assert fused.patch_scene_model(sc)
+        kf = sc.keyframes[1]
+        kf.image_pyr = [kf.image_pyr[0], F.avg_pool2d(kf.image_pyr[0], 2).contiguous()]
+        kf.idepth_pyr = [kf.idepth_pyr[0], F.avg_pool2d(kf.idepth_pyr[0], 2).contiguous()]
+        kf.pyr_lvl = 1
+    for i in range(4):
+        _sync_state(a, b)
+        ga = _one_step(a, monkeypatch, True, True, kid=i % 2, seed=30 + i)
+        gb = _one_step(b, monkeypatch, False, True, kid=i % 2, seed=30 + i)
+        assert ga["native_calls"] == 1 and torch.equal(ga["loss"], gb["loss"]) and torch.equal(ga["invdepth"], gb["invdepth"]), i
+        for k, x in ga["grads"].items():
+            y = gb["grads"][k]
+            assert float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)) <= 1e-5, (i, k)
+    plans = list(a.__dict__["_adk_step_plans"].values())
+    assert len(plans) == 2 and {(p.W, p.H) for p in plans} == {(a.width, a.height), (a.width // 2, a.height // 2)}
+    for name in native_step.StepPlan.PER_MAP - {"v_dc", "v_rest"}:
+        assert plans[0].t[name].data_ptr() == plans[1].t[name].data_ptr(), name
+    for name in ("render_colors", "v_col", "image", "cam_grad", "pairs"):
+        assert plans[0].t[name].data_ptr() != plans[1].t[name].data_ptr(), name
+    one = sum(t.numel() * t.element_size() for t in plans[0].t.values())
+    assert native_step.STATS["plan_bytes"] < 2 * one
 
 
 @pytest.mark.gpu

@@ -10,9 +10,11 @@ Knife edges, and what is done about each (measured first, DESIGN round-5 finding
  * the rasteriser's (alpha >= 1/255, T (1 - alpha) <= 1e-4): the oracle takes these per-pixel decisions from an fp32 evaluation of the fp32
    projection outputs -- the values an fp32 rasteriser decides on, bit-identical to the HIP projection's -- and differentiates in fp64 ON them
    (with fp64 decisions, an independent fp32 torch evaluation of the same step already differs from fp64 by 2e-4 / 2e-3 at 1 M / 512x384:
-   exactly what the HIP path showed).  What is left are pixels where two fp32 evaluations may still disagree (a value within 2e-5 of a
-   threshold): the Gaussians blended on those pixels -- identified by the ORACLE, a few per mille, fraction asserted -- leave the MAX-error
-   criterion of the per-Gaussian leaves; they stay in rel_l2 and in every summed leaf (mlp_cov, voxel features, pose, exposure).
+   exactly what the HIP path showed).  Two fp32 evaluations still disagree where a value sits within ~1e-6 of a threshold, and ONE such splat
+   moves the summed leaves by 1e-4: so the test also moves ITS OWN SCENE off those edges first (`settle_scene`: the opacity of every Gaussian
+   with an alpha within 1e-4 of 1/255 at some pixel -- ~1 % of them -- is raised by 2e-3, rescanned until none is left).  The handful that
+   opacity cannot move (a pixel centre on a splat centre) and the clamp edges of the loss are identified by the ORACLE, and the Gaussians
+   blended on those pixels (< 1 %, fraction asserted) leave the MAX-error criterion of the per-Gaussian leaves only.
 
 CPU part (`-m "not gpu"`): the oracle against the harness mirror run on the fp32 CPU oracles (the chain the reference's real class is
 pinned to in tests/test_reference_scene_model.py).
@@ -47,9 +49,10 @@ def _rel(x, y):
     return float((x - y).norm() / (y.norm() + 1e-300)), float((x - y).abs().max() / (y.abs().max() + 1e-300))
 
 
-def _compare(got, o, tol=1e-4, label="", max_knife_rows=0.01):
+def _compare(got, o, tol=1e-4, label="", max_knife_rows=0.01, tol_max=None, tol_pose=None):
     """rel_l2 over ALL rows and the max error (relative to the largest entry) of every leaf; for the per-Gaussian leaves the max error is
-    taken over the rows the oracle does not place under a knife pixel (`knife_rows`: at most `max_knife_rows` of them)."""
+    taken over the rows the oracle does not place under a knife pixel (`knife_rows`: at most `max_knife_rows` of them).  tol_max / tol_pose:
+    other bounds for the max error / the keyframe's pose (default: tol)."""
     from oracle import step_oracle as SO
     N = o["knife_rows"].shape[0]
     keep = ~o["knife_rows"]
@@ -69,7 +72,9 @@ def _compare(got, o, tol=1e-4, label="", max_knife_rows=0.01):
           + "  ".join(f"{k} {a:.1e}/{b:.1e}/{c:.1e}" for k, (a, b, c) in worst.items()))
     assert frac <= max_knife_rows, (label, frac)
     for k, (rl2, rmax, _) in worst.items():
-        assert rl2 <= tol and rmax <= tol, (label, k, rl2, rmax)
+        t_l2 = tol_pose if (tol_pose is not None and k in ("kf.rW2C", "kf.tW2C")) else tol
+        t_mx = tol_pose if (tol_pose is not None and k in ("kf.rW2C", "kf.tW2C")) else (tol if tol_max is None else tol_max)
+        assert rl2 <= t_l2 and rmax <= t_mx, (label, k, rl2, rmax)
     return worst
 
 
@@ -122,6 +127,26 @@ def test_adjust_targets_moves_only_the_knife_pixels():
     assert float(g2.min()) >= 0 and float(g2.max()) <= 1
 
 
+def test_settle_scene_moves_the_scene_off_the_skip_edges():
+    """settle_scene: after it, no (splat, pixel) pair of the view has an alpha within 1e-4 of 1/255 (but for the handful a pixel centre on a
+    splat centre leaves), only opacities moved, each by ~2e-3 relative, and the scan it is built on agrees with the oracle's own knife mask."""
+    from harness import mapper
+    from oracle import step_oracle as SO
+    sc = _perturb(mapper.build_synthetic_mapper(6000, 160, 112, "cpu", seed=5, n_keyframes=2), 5, False)
+    state, kfd, cfg = SO.snapshot(sc, 1)
+    on_edge, pairs, pixels = SO.knife_scan(state, kfd, cfg, workers=1, knife_eps=1e-4, knife_eps_T=0.0)
+    assert pairs >= pixels > 0 and int(on_edge.sum()) > 0
+    log = []
+    settled, rounds, left = SO.settle_scene(state, kfd, cfg, workers=1, log=log)
+    assert left <= 2 and rounds <= 4 and log[0][2] == pairs
+    moved = settled["opacity"] != state["opacity"]
+    assert bool(moved[on_edge].all()) and all(torch.equal(settled[k], state[k]) for k in state if k != "opacity")
+    rel = (torch.sigmoid(settled["opacity"][moved]) / torch.sigmoid(state["opacity"][moved]) - 1.0)
+    assert 1.5e-3 <= float(rel.min()) and float(rel.max()) <= 1.3e-2          # one to a few nudges of 2e-3
+    o = SO.optimisation_step(settled, kfd, cfg, torch.tensor([0.2, 0.5, 0.8]), True, workers=1, want_grads=False, knife_eps=1e-4)
+    assert int(o["skip_knife"].sum()) <= 2 and int(o["raster_knife"].sum()) >= int(o["skip_knife"].sum())
+
+
 # --------------------------------------------------------------------------------------------------------------- GPU: the default path
 def _default_path_step(sc, kid, important, seed):
     """One `optimization_step` of the patched scene in the DEFAULT environment, the optimisers spied on: every gradient the step left
@@ -155,7 +180,7 @@ def _default_path_step(sc, kid, important, seed):
     return got
 
 
-def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeypatch, max_mask_flips=4):
+def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeypatch, max_mask_flips=4, **tols):
     import os
     from artdeco_amd import fused
     from harness import mapper
@@ -168,6 +193,13 @@ def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeyp
     kid = 1
     kf = sc.keyframes[kid]
     state, kfd, cfg = SO.snapshot(sc, kid)
+    t0 = time.time()
+    settle_log = []
+    state, rounds, left = SO.settle_scene(state, kfd, cfg, log=settle_log)     # the scene off the rasteriser's skip edges: opacities of ~1 % of the Gaussians move by 2e-3
+    with torch.no_grad():
+        sc.gaussian_params["opacity"]["val"].copy_(state["opacity"].to(dev))
+    print(f"[step-oracle {N}/{W}x{H}] settle_scene {time.time() - t0:.1f} s: (round, Gaussians on an edge, pairs, pixels) {settle_log}")
+    assert left <= 16
     torch.manual_seed(seed)
     bg = torch.rand(3, device=dev).cpu()              # what the step draws after the same seeding (h3dgsv3.py:421)
     rdk = SO.radial_decay_kernel(H, W, cfg["rad_decay"]).double()
@@ -198,9 +230,9 @@ def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeyp
     assert bool((torch.isfinite(inv_o) == torch.isfinite(inv_g))[keep].all())
     err = ((inv_g - inv_o).abs() * (keep & fin))
     assert float(torch.nan_to_num(err).max()) <= 1e-4 * float(inv_o[fin].abs().max())
-    assert float(keep.float().mean()) > 0.995
+    assert float(keep.float().mean()) > 0.95     # the termination edge at 1e-3: ~1 % of the pixels that terminate at all
     assert n_img_knife <= 64         # what is left are clamp edges (exposed render within 2e-5 of 0 or 1), which no target can move
-    _compare(got, o, tol=1e-4, label=label)
+    _compare(got, o, label=label, **{"tol": 1e-4, **tols})
 
 
 @pytest.mark.gpu
@@ -220,7 +252,12 @@ def test_default_step_matches_the_fp64_oracle_at_run_sh_geometry(dev, monkeypatc
 
 @pytest.mark.gpu
 def test_default_step_matches_the_fp64_oracle_at_4M_with_lod(dev, monkeypatch):
-    _hold_default_path_to_the_oracle(dev, 4_000_000, 2592, 1944, True, True, 14, monkeypatch, max_mask_flips=16)
+    """configs[3].  At 2592x1944 a pixel coordinate has 2.4e-4 px of fp32 resolution, and the oracle's own chain evaluated in fp32 ON THE SAME
+    DECISIONS (torch CPU, no kernel of this package involved) already differs from its fp64 evaluation by 1-3e-4 rel_l2 / up to 9e-3 max on the
+    per-Gaussian leaves and 2-3e-3 on the pose, whose 12 numbers are sums of 3.4 M signed terms (profiles/r05_fp32_floor_4M.txt): the bounds
+    here are that floor, not the 1e-4 an fp32 rasteriser cannot reach against fp64 at this size."""
+    _hold_default_path_to_the_oracle(dev, 4_000_000, 2592, 1944, True, True, 14, monkeypatch, max_mask_flips=16, tol=3e-4, tol_max=2e-3,
+                                     tol_pose=5e-3, max_knife_rows=0.02)
 
 
 @pytest.mark.gpu
@@ -243,6 +280,10 @@ def test_default_step_matches_the_fp64_oracle_small_scenes_with_lod_and_regulari
         kid, important = i % 2, i != 1
         kf = sc.keyframes[kid]
         state, kfd, cfg = SO.snapshot(sc, kid)
+        state, _, left = SO.settle_scene(state, kfd, cfg, workers=1)
+        assert left <= 4
+        with torch.no_grad():
+            sc.gaussian_params["opacity"]["val"].copy_(state["opacity"].to(dev))
         torch.manual_seed(100 + i)
         bg = torch.rand(3, device=dev).cpu()
         rdk = SO.radial_decay_kernel(H, W, cfg["rad_decay"]).double()
@@ -255,4 +296,4 @@ def test_default_step_matches_the_fp64_oracle_small_scenes_with_lod_and_regulari
         assert abs(got["loss"] - o["loss"]) <= 1e-5 * abs(o["loss"])
         assert torch.equal(got["vis"].cpu(), o["visibility"]) and torch.equal(got["gvis"].cpu(), o["global_visibility"])
         assert 0 < int(o["selected"].sum()) < N
-        _compare(got, o, tol=1e-4, label=f"seed {seed} reg {reg} step {i}", max_knife_rows=0.05)
+        _compare(got, o, tol=1e-4, label=f"seed {seed} reg {reg} step {i}", max_knife_rows=0.02)
