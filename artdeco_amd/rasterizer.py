@@ -30,6 +30,14 @@ class StageTimer:
     def __init__(self, only=None):
         self.events: dict[str, list] = {}
         self.only = None if only is None else frozenset(only)
+        self._native: dict[str, list] = {}   # stage -> [sum, min, count] folded from the C side's pairs (adk_mapper_step)
+
+    def _absorb(self, drained: dict) -> None:
+        for k, (s, m, c) in drained.items():
+            if self.only is not None and k not in self.only:
+                continue
+            a = self._native.setdefault(k, [0.0, m, 0])
+            a[0] += s; a[1] = min(a[1], m); a[2] += c
 
     @contextlib.contextmanager
     def stage(self, name: str):
@@ -50,11 +58,12 @@ class StageTimer:
         for k, evs in self.events.items():
             ts = [a.elapsed_time(b) for a, b in evs]
             acc[k] = [sum(ts), min(ts), len(ts)]
-        # stages that ran inside adk_mapper_step recorded their event pairs on the C side (artdeco_amd/native_step.py)
+        # stages that ran inside adk_mapper_step recorded their event pairs on the C side (artdeco_amd/native_step.py): the pairs still
+        # pending there belong to the installed timer; a timer that has been removed absorbed its pairs when it was
         from . import native_step
-        for k, (s, m, c) in native_step.drain_timings().items():
-            if self.only is not None and k not in self.only:
-                continue
+        if _TIMER is self:
+            self._absorb(native_step.drain_timings())
+        for k, (s, m, c) in self._native.items():
             a = acc.setdefault(k, [0.0, m, 0])
             a[0] += s; a[1] = min(a[1], m); a[2] += c
         return {k: {"mean_ms": a[0] / a[2], "min_ms": a[1], "count": a[2]} for k, a in acc.items()}
@@ -67,9 +76,11 @@ _NULL = contextlib.nullcontext()
 def set_stage_timer(t: StageTimer | None) -> None:
     global _TIMER
     from . import native_step
-    # pairs recorded under a previous timer are not the next one's, and a timer that is removed without summary_ms() must not leave its
-    # events behind on the C side (drain_timings() is a no-op while the library has not been loaded)
-    native_step.drain_timings()
+    # the pairs pending on the C side were recorded under the OUTGOING timer: it absorbs them (a later summary_ms() still reports them),
+    # nothing stays behind for the next timer or for nobody (drain_timings() is a no-op while the library has not been loaded)
+    drained = native_step.drain_timings()
+    if _TIMER is not None:
+        _TIMER._absorb(drained)
     _TIMER = t
 
 

@@ -621,6 +621,30 @@ def extra_configs(args, dev):
              (f"headline config, UNCHANGED host code: ARTDECO's torch glue, natives swapped only ({args.gaussians} Gaussians {args.width}x{args.height})",
               args.gaussians, args.width, args.height, False, False, 1, True),
              ("north-star target 1M Gaussians 512x384, UNCHANGED host code", 1_000_000, 512, 384, False, False, 1, True)]
+    # A frame on the other side of what used to be the 8 192-entries-per-tile cliff (round 5): the north-star size with splats twice as wide
+    # (sigma ~ 4 px: I / N ~ 8, every tile list 10-20 k entries).  Until round 4 such a frame left the tile-local sort AND the one-call step.
+    try:
+        from artdeco_amd import native_step as _ns
+        scene = mapper.build_synthetic_mapper(1_000_000, 512, 384, dev, seed=0, targets="render", sigma_px=4.0)
+        fused.patch_scene_model(scene)
+        before = dict(_ns.STATS)
+        dt = _time_steps(scene)
+        d = {k: _ns.STATS[k] - before[k] for k in ("native", "fallback_route", "fallback_layout", "long_list_steps")}
+        from artdeco_amd import rasterizer as _r
+        res["north-star size, DENSE frame: 1M Gaussians 512x384 with sigma ~ 4 px (tile lists of 10-20 k entries: the long-list sort inside the one-call step)"] = {
+            "ms_per_step": dt * 1e3, "steps_only_frames_per_s": 1.0 / (dt * STEPS_PER_FRAME), "intersections_I": _r.LAST_STATS.get("I"),
+            "steps_native": d["native"], "steps_with_a_long_list": d["long_list_steps"], "fallback_route": d["fallback_route"],
+            "fallback_layout": d["fallback_layout"]}
+        # the way round 4 ran such a frame: the per-stage chain with the global radix route (adk_mapper_step returned ADK_STEP_EROUTE)
+        os.environ["ARTDECO_AMD_NATIVE_STEP"], os.environ["ADK_BIN_LONG"] = "0", "0"
+        try:
+            res[next(reversed(res))]["ms_per_step_round4_path (per-stage chain, global radix route)"] = _time_steps(scene) * 1e3
+        finally:
+            del os.environ["ARTDECO_AMD_NATIVE_STEP"], os.environ["ADK_BIN_LONG"]
+        del scene
+        torch.cuda.empty_cache()
+    except Exception as e:  # report, never hide
+        res["north-star size, DENSE frame"] = {"error": repr(e)[:300]}
     for name, n, w, h, use_fused, lod, pyr, do_stream in cases:
         try:
             tw, th = w >> (pyr - 1), h >> (pyr - 1)

@@ -561,7 +561,7 @@ def synthetic_cloud(N, width, height, seed=0, sh_k=16, z_range=(2.0, 6.0), sigma
     return dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, fx=fx)
 
 
-def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random", lod=False, order="random"):
+def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targets="random", lod=False, order="random", sigma_px=2.0):
     """MapperScene + keyframes on the synthetic cloud; the training resolution IS (width, height).
     targets: "random" = uniform-noise keyframe images (every parameter gets a large gradient: what the parity tests
     want); "render" = each keyframe observes the cloud itself (its own render and inverse depth), i.e. a converged map,
@@ -573,7 +573,7 @@ def build_synthetic_mapper(N, width, height, device, seed=0, n_keyframes=4, targ
     was built from keyframes nearer and farther than the one rendering it).  About 8 % of the cloud then fails
     `dist < 2 d_max` and is culled, another ~25 % is faded by the alpha ratio (h3dgsv3.py:628-639); with lod=False d_max is
     1e3 and the LoD logic never triggers (the SURVEY 8(d) statistics, used for the headline)."""
-    c = synthetic_cloud(N, width, height, seed)
+    c = synthetic_cloud(N, width, height, seed, sigma_px=sigma_px)   # sigma_px = 2: SURVEY 8(d)'s cloud; larger: a denser frame (longer tile lists)
     if order == "raster":
         # the order add_new_gaussians appends in: image raster order of the creating view (boolean-mask indexing of the pixel grid,
         # h3dgsv3.py:800).  SURVEY 8(d)'s cloud is in RANDOM order, the worst case for every kernel that scatters by screen position.

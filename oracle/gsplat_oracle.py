@@ -433,7 +433,7 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, isect
         out_T[sl] = T_final.reshape(TILE, TILE)
         last[sl] = lastk.reshape(TILE, TILE)
         if extras is not None:
-            knife, main, w1, w2, _ = ex
+            knife, main, w1, w2 = ex[:4]
             ex_knife[sl] = knife.reshape(TILE, TILE)
             mid = torch.where(main >= 0, g[main.clamp_min(0)].to(torch.int32), torch.full_like(main, -1, dtype=torch.int32))
             ex_main[sl] = mid.reshape(TILE, TILE)
