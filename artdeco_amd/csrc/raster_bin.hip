@@ -608,6 +608,7 @@ __global__ __launch_bounds__(512) void bin_tile_sort_merge_kernel(const unsigned
 // workgroup's own rewrite of a buffer it read a level earlier).  Pending segments hold > 1 024 keys each, so a list of n keys never has more
 // than n / 1 024 of them on the stack: 4 096 slots = lists of up to 4 194 304 entries (BIN_SORT_LONG_MAX; the host knows the fullest tile).
 #define BIN_LONG_NB 1024
+#define BIN_LONG_REG 32              // keys a thread holds in registers while its workgroup partitions a segment of up to 16 384 keys
 #define BIN_LONG_STACK 4096
 #define BIN_SORT_LONG_MAX (BIN_LONG_STACK * 1024)
 
@@ -666,9 +667,24 @@ __global__ __launch_bounds__(512) void bin_tile_sort_long_kernel(unsigned long l
         const unsigned long long* src = ((cw >> 31) ? scratch : pairs) + s + seg0;
         unsigned long long* const dst_base = (cw >> 31) ? pairs : scratch;
         unsigned long long* dst = dst_base + s + seg0;
-        // -- key range of the segment
+        // -- key range of the segment.  Segments of up to 512 x BIN_LONG_REG keys (every first level but a pathological one) are read ONCE, all
+        // loads in flight together, and the three sweeps below run on registers; longer ones sweep the source three times.
+        constexpr int REG = BIN_LONG_REG;
+        const bool in_regs = count <= 512 * REG;
+        unsigned long long kreg[REG];
         unsigned long long lo = ~0ull, hi = 0ull;
-        for (int i = tid; i < count; i += 512) { const unsigned long long k = src[i]; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < REG; ++r) { const int i = r * 512 + tid; kreg[r] = i < count ? src[i] : ~0ull; }
+#pragma unroll
+            for (int r = 0; r < REG; ++r) {
+                const unsigned long long k = kreg[r];
+                lo = k < lo ? k : lo;                               // the padding ~0 never wins a minimum against a real key
+                hi = (r * 512 + tid < count && k > hi) ? k : hi;
+            }
+        } else {
+            for (int i = tid; i < count; i += 512) { const unsigned long long k = src[i]; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+        }
         lo = wave_min_u64(lo); hi = wave_max_u64(hi);
         if (lane == 0) { red_min[wv] = lo; red_max[wv] = hi; }
         int nb_log = 2;
@@ -682,7 +698,13 @@ __global__ __launch_bounds__(512) void bin_tile_sort_long_kernel(unsigned long l
         const int bits = 64 - __clzll((long long)range);
         const int shift = bits > nb_log ? bits - nb_log : 0;
         // -- count, scan
-        for (int i = tid; i < count; i += 512) atomicAdd(&cnt[(uint32_t)((src[i] - lo) >> shift)], 1u);
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < REG; ++r)
+                if (r * 512 + tid < count) atomicAdd(&cnt[(uint32_t)((kreg[r] - lo) >> shift)], 1u);
+        } else {
+            for (int i = tid; i < count; i += 512) atomicAdd(&cnt[(uint32_t)((src[i] - lo) >> shift)], 1u);
+        }
         __syncthreads();
         {   // exclusive scan of cnt[0 .. NB): thread tid owns entries 2 tid, 2 tid + 1 (NB <= 1024 = 2 x 512)
             const uint32_t a = 2 * tid < NB ? cnt[2 * tid] : 0u, b = 2 * tid + 1 < NB ? cnt[2 * tid + 1] : 0u;
@@ -699,9 +721,15 @@ __global__ __launch_bounds__(512) void bin_tile_sort_long_kernel(unsigned long l
         }
         __syncthreads();
         // -- scatter to the other buffer (order inside a bucket is arbitrary: it is sorted or partitioned next)
-        for (int i = tid; i < count; i += 512) {
-            const unsigned long long k = src[i];
-            dst[atomicAdd(&cnt[(uint32_t)((k - lo) >> shift)], 1u)] = k;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < REG; ++r)
+                if (r * 512 + tid < count) dst[atomicAdd(&cnt[(uint32_t)((kreg[r] - lo) >> shift)], 1u)] = kreg[r];
+        } else {
+            for (int i = tid; i < count; i += 512) {
+                const unsigned long long k = src[i];
+                dst[atomicAdd(&cnt[(uint32_t)((k - lo) >> shift)], 1u)] = k;
+            }
         }
         __threadfence();
         __syncthreads();

@@ -51,6 +51,8 @@ KF_KEYS = ("kf.rW2C", "kf.tW2C", "kf.exposure")
 #: relative half-width of the band around a rasteriser decision inside which an fp32 evaluation may fall on the other side
 #: (fp32 alpha / transmittance carry ~1e-6 relative error after a few hundred blended splats)
 KNIFE_EPS = 2e-5
+#: half-width of the band around 0 of a hidden unit's pre-activation in mlp_cov (two fp32 evaluations of a 32-term sum of O(1) products)
+KNIFE_EPS_RELU = 2e-5
 #: the same for the termination test T (1 - alpha) <= 1e-4: T is a product of hundreds of factors, two fp32 evaluations drift apart further
 KNIFE_EPS_T = 1e-3
 #: pixels per call of composite_tile: [n, 64] float64 temporaries stay in a core's L2 (whole 16x16 tiles made the tile passes DRAM-bound
@@ -110,9 +112,13 @@ def radial_decay_kernel(H, W, sigma):
     return torch.exp(-(xx ** 2 + yy ** 2) / (2 * sigma ** 2))
 
 
-def _mlp_cov(x, st):
-    h = F.relu(F.linear(x, st["mlp.0.weight"], st["mlp.0.bias"]))
-    return F.linear(h, st["mlp.2.weight"], st["mlp.2.bias"])
+def _mlp_cov(x, st, relu_mask=None):
+    """mlp_cov = Linear(32, 32) -> ReLU -> Linear(32, 7) (h3dgsv3.py:118-123).  relu_mask given: the ReLU's on / off DECISIONS of another
+    (fp32) evaluation are applied instead of this one's sign test; returns (output, pre-activation, mask)."""
+    z = F.linear(x, st["mlp.0.weight"], st["mlp.0.bias"])
+    mask = (z > 0) if relu_mask is None else relu_mask
+    h = torch.where(mask, z, torch.zeros_like(z))
+    return F.linear(h, st["mlp.2.weight"], st["mlp.2.bias"]), z, mask
 
 
 def _lod_and_params(st, Rt, decisions=None):
@@ -132,7 +138,9 @@ def _lod_and_params(st, Rt, decisions=None):
     rotation = st["rotation"][sel]
     feats = torch.cat([st["f_dc"][sel], st["f_rest"][sel]], dim=1)
     ids = st["cls_id"][sel].squeeze(-1).long()
-    scale_rot = _mlp_cov(torch.cat([st["global_feat"][ids], st["local_feat"][sel]], dim=1), st)
+    scale_rot, z, relu_mask = _mlp_cov(torch.cat([st["global_feat"][ids], st["local_feat"][sel]], dim=1), st, decisions.get("relu_mask"))
+    if "relu_mask" not in decisions:       # the pass that MAKES the decisions: the ReLU's are among them (a hidden unit within an ulp of 0)
+        decisions["relu_mask"], decisions["relu_pre"] = relu_mask, z.detach()
     scaling = scaling * torch.sigmoid(scale_rot[:, :3])
     rotation = F.normalize(rotation * scale_rot[:, 3:])
     return dict(xyz=xyz[sel], opacity=opacity.squeeze(-1), scaling=scaling, rotation=rotation, feats=feats), decisions
@@ -377,9 +385,10 @@ def _fp32_decisions(state, kf, cfg):
     return st32, par32, dec, K32, p32, isects
 
 
-def knife_scan(state, kf, cfg, *, workers=None, knife_eps=KNIFE_EPS, knife_eps_T=KNIFE_EPS_T):
+def knife_scan(state, kf, cfg, *, workers=None, knife_eps=KNIFE_EPS, knife_eps_T=KNIFE_EPS_T, relu_eps=KNIFE_EPS_RELU):
     """Which Gaussians (bool [N]) sit ON a per-pixel decision of the rasteriser for this view -- fp32 evaluation, (splat, pixel) pairs within
-    `knife_eps` of alpha = 1/255 / 0.999 or within `knife_eps_T` of the termination threshold -- and the number of such pairs and pixels."""
+    `knife_eps` of alpha = 1/255 / 0.999 or within `knife_eps_T` of the termination threshold -- and the number of such pairs and pixels;
+    and (bool [N], unit index [N], sign [N]) of the visible Gaussians with a hidden unit of mlp_cov within `relu_eps` of its ReLU's switch."""
     workers = default_workers() if workers is None else workers
     with _threads(SERIAL_THREADS):
         st32, par32, dec, K32, p32, isects = _fp32_decisions(state, kf, cfg)
@@ -403,12 +412,24 @@ def knife_scan(state, kf, cfg, *, workers=None, knife_eps=KNIFE_EPS, knife_eps_T
     _SH.clear()
     if tmpdir:
         shutil.rmtree(tmpdir, ignore_errors=True)
+    sel_idx = torch.nonzero(dec["selection_mask"]).squeeze(-1)
     on_edge = torch.zeros(state["xyz"].shape[0], dtype=torch.bool)
-    on_edge[torch.nonzero(dec["selection_mask"]).squeeze(-1)[sel_rows]] = True
-    return on_edge, pairs, pixels
+    on_edge[sel_idx[sel_rows]] = True
+    # hidden units of mlp_cov within relu_eps of their ReLU's switch (visible Gaussians only: the others' mlp output reaches nothing)
+    vis = p32["radii"].max(dim=1).values > 0
+    zmin, unit = dec["relu_pre"].abs().min(dim=1)
+    relu_sel = (zmin <= relu_eps) & vis
+    relu_edge = torch.zeros(state["xyz"].shape[0], dtype=torch.bool)
+    relu_edge[sel_idx[relu_sel]] = True
+    relu_unit = torch.full((state["xyz"].shape[0],), -1, dtype=torch.long)
+    relu_unit[sel_idx[relu_sel]] = unit[relu_sel]
+    relu_sign = torch.zeros(state["xyz"].shape[0])
+    relu_sign[sel_idx[relu_sel]] = torch.sign(dec["relu_pre"][relu_sel, unit[relu_sel]])
+    return on_edge, pairs, pixels, (relu_edge, relu_unit, relu_sign)
 
 
-def settle_scene(state, kf, cfg, *, workers=None, knife_eps=1e-4, knife_eps_T=0.0, nudge=2e-3, max_rounds=6, log=None):
+def settle_scene(state, kf, cfg, *, workers=None, knife_eps=1e-4, knife_eps_T=0.0, nudge=2e-3, relu_band=1e-4, relu_nudge=2e-3, max_rounds=6,
+                 log=None):
     """A TEST's way of keeping its own scene off the rasteriser's knife edges (as `adjust_targets` does for the loss's): the opacity of every
     Gaussian that sits on a SKIP decision at some pixel of this view -- alpha within `knife_eps` of 1/255 (or of 0.999), far wider than two
     fp32 evaluations differ -- is raised by a relative `nudge`, and the view is scanned again, until no (splat, pixel) pair is left on such
@@ -416,23 +437,35 @@ def settle_scene(state, kf, cfg, *, workers=None, knife_eps=1e-4, knife_eps_T=0.
     default (knife_eps_T = 0): a transmittance is the product of hundreds of factors, ~1 % of the terminating pixels pass within 1e-3 of the
     threshold whatever one splat's opacity is, and a splat that enters or leaves there carries a weight <= 1e-4 -- nothing a gradient
     comparison at 1e-4 sees; pixel-level comparisons mask those pixels (`raster_knife` of optimisation_step, which keeps KNIFE_EPS_T).
-    Returns (state with the adjusted `opacity` logits, rounds, pairs left)."""
+    The ReLU of mlp_cov is a decision of the same kind -- a hidden unit whose pre-activation two fp32 evaluations place on different sides
+    of 0 switches that Gaussian's feature gradients on or off (seen at 1 M / 1080p: local_feat / global_feat / mlp.0.* at 1e-4 with every
+    other leaf at 1e-5) -- and is handled the same way: a visible Gaussian with a unit within `relu_band` of 0 gets its local_feat moved
+    along that unit's weights so that the pre-activation lands `relu_nudge` away.
+    Returns (state with the adjusted `opacity` logits and `local_feat`, rounds, edges left)."""
     state = dict(state)
     state["opacity"] = state["opacity"].clone()
+    state["local_feat"] = state["local_feat"].clone()
+    W1l = state["mlp.0.weight"][:, state["global_feat"].shape[1]:].float()       # the columns of Linear 1 that read local_feat
     pairs, last = -1, None
-    for r in range(max_rounds):
-        on_edge, pairs, pixels = knife_scan(state, kf, cfg, workers=workers, knife_eps=knife_eps, knife_eps_T=knife_eps_T)
+    for r in range(max_rounds + 1):
+        on_edge, pairs, pixels, (relu_edge, relu_unit, relu_sign) = knife_scan(state, kf, cfg, workers=workers, knife_eps=knife_eps,
+                                                                               knife_eps_T=knife_eps_T, relu_eps=relu_band)
+        n_relu = int(relu_edge.sum())
         if log is not None:
-            log.append((r, int(on_edge.sum()), pairs, pixels))
-        if pairs == 0 or (last is not None and pairs >= last):   # the few that opacity cannot move: a pixel centre ON a splat's centre (sigma = 0)
-            return state, r, pairs
+            log.append((r, int(on_edge.sum()), pairs, pixels, n_relu))
+        stuck = last is not None and pairs >= last      # the few that opacity cannot move: a pixel centre ON a splat's centre (sigma = 0)
+        if (pairs == 0 or stuck) and n_relu == 0 or r == max_rounds:
+            return state, r, pairs + n_relu
         last = pairs
-        x = state["opacity"][on_edge]
-        # d ln sigmoid(x) / dx = 1 - sigmoid(x): the step that multiplies the opacity by (1 + nudge)
-        state["opacity"][on_edge] = x + (nudge / (1.0 - torch.sigmoid(x)).clamp_min(1e-3)).clamp_max(0.5)
-    on_edge, pairs, pixels = knife_scan(state, kf, cfg, workers=workers, knife_eps=knife_eps, knife_eps_T=knife_eps_T)
-    if log is not None:
-        log.append((max_rounds, int(on_edge.sum()), pairs, pixels))
+        if pairs and not stuck:
+            x = state["opacity"][on_edge]
+            # d ln sigmoid(x) / dx = 1 - sigmoid(x): the step that multiplies the opacity by (1 + nudge)
+            state["opacity"][on_edge] = x + (nudge / (1.0 - torch.sigmoid(x)).clamp_min(1e-3)).clamp_max(0.5)
+        if n_relu:
+            # move the unit's pre-activation away from 0 by relu_nudge along the unit's own weights on local_feat (the smallest change that does)
+            w = W1l[relu_unit[relu_edge]]
+            s = torch.where(relu_sign[relu_edge] == 0, torch.ones(n_relu), relu_sign[relu_edge])
+            state["local_feat"][relu_edge] += (s * relu_nudge / w.pow(2).sum(1).clamp_min(1e-12))[:, None] * w
     return state, max_rounds, pairs
 
 
@@ -599,8 +632,12 @@ def optimisation_step(state, kf, cfg, bg, is_important, *, workers=None, adjust_
     grads = {k: (leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])) for k in GAUSS_KEYS + MLP_KEYS}
     grads["kf.rW2C"], grads["kf.tW2C"], grads["kf.exposure"] = kfl["rW2C"].grad, kfl["tW2C"].grad, g_exposure
     knife_rows = torch.zeros(N, dtype=torch.bool)
-    knife_rows[torch.nonzero(sel).squeeze(-1)[knife_sel]] = True
-    out.update(grads=grads, knife_rows=knife_rows)
+    sel_idx = torch.nonzero(sel).squeeze(-1)
+    knife_rows[sel_idx[knife_sel]] = True
+    # a hidden unit of mlp_cov on its ReLU's switch: that Gaussian's feature gradients are one decision away from another value
+    relu_sel = (dec["relu_pre"].abs().min(dim=1).values <= KNIFE_EPS_RELU) & (p32["radii"].max(dim=1).values > 0)
+    knife_rows[sel_idx[relu_sel]] = True
+    out.update(grads=grads, knife_rows=knife_rows, relu_knife_rows=int(relu_sel.sum()))
     lap("F backward to the leaves")
     serial.__exit__()
     return out
