@@ -232,6 +232,19 @@ __global__ void pose6d_fwd_kernel(const float* __restrict__ r6, const float* __r
     Rt[12] = 0.f; Rt[13] = 0.f; Rt[14] = 0.f; Rt[15] = 1.f;
 }
 
+// Keyframe.set_Rt (scene/keyframe.py:156-159): rW2C <- Rt[:3, :2], tW2C <- Rt[:3, 3], approx_centre = -Rt[:3, :3]^T Rt[:3, 3] as ONE launch
+// (the reference: two copy_ and a slice / transpose / matmul / negate chain, ~8 launches per keyframe inside run_system.py's SLAM-keyframe loop)
+__global__ void pose6d_set_kernel(const float* __restrict__ Rt, float* __restrict__ r6, float* __restrict__ t, float* __restrict__ centre) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float R[3][3], tt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { R[i][0] = Rt[4 * i]; R[i][1] = Rt[4 * i + 1]; R[i][2] = Rt[4 * i + 2]; tt[i] = Rt[4 * i + 3]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { r6[2 * i] = R[i][0]; r6[2 * i + 1] = R[i][1]; t[i] = tt[i]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) centre[j] = -((R[0][j] * tt[0] + R[1][j] * tt[1]) + R[2][j] * tt[2]);
+}
+
 __global__ void pose6d_bwd_kernel(const float* __restrict__ r6, const float* __restrict__ v_Rt, float* __restrict__ v_r6,
                                   float* __restrict__ v_t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -390,6 +403,13 @@ int adk::pose6d_fwd_clear(const float* r6, const float* t, float* Rt, void* a, i
     const int blocks = (int)(work <= 256 ? 1 : (adk::ceil_div(work, 256) > 2048 ? 2048 : adk::ceil_div(work, 256)));
     hipLaunchKernelGGL(adk::pose6d_fwd_clear_kernel, dim3(blocks), dim3(256), 0, stream, r6, t, Rt, static_cast<unsigned char*>(a), na,
                        static_cast<unsigned char*>(b), nb);
+    ADK_RETURN_LAST_ERROR();
+}
+
+extern "C" int adk_pose6d_set(const float* Rt, float* r6, float* t, float* centre, hipStream_t stream)
+{
+    if (!Rt || !r6 || !t || !centre) return ADK_EINVAL;
+    hipLaunchKernelGGL(adk::pose6d_set_kernel, dim3(1), dim3(64), 0, stream, Rt, r6, t, centre);
     ADK_RETURN_LAST_ERROR();
 }
 

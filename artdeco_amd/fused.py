@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import sys
 import types
 
 import torch
@@ -440,6 +441,51 @@ class PoseRt(torch.autograd.Function):
             rc = lib.adk_pose6d_bwd(r6c.data_ptr(), v_Rt.data_ptr(), v_r6.data_ptr(), v_t.data_ptr(), _lib.stream_of(r6c))
         _lib.check(rc, "adk_pose6d_bwd")
         return v_r6, v_t
+
+
+def _pose_params_ok(kf) -> bool:
+    r6, t = getattr(kf, "rW2C", None), getattr(kf, "tW2C", None)
+    return (torch.is_tensor(r6) and torch.is_tensor(t) and r6.is_cuda and t.is_cuda and r6.dtype == torch.float32 and t.dtype == torch.float32
+            and tuple(r6.shape) == (3, 2) and tuple(t.shape) == (3,) and r6.is_contiguous() and t.is_contiguous() and r6.device == t.device)
+
+
+def fused_get_Rt(self):
+    """Keyframe.get_Rt (scene/keyframe.py:150-154) as ONE launch (PoseRt: adk_pose6d_fwd, differentiable) instead of eye + sixD2mtx's
+    norm / div / sum / mul / sub / cross / stack + two slice assignments (~12 launches and their autograd nodes).  run_system.py's
+    SLAM-keyframe loop (:194-227) calls it twice per EXISTING keyframe on every SLAM keyframe: a third of a 1 000-frame sequence's wall time
+    is that loop (DESIGN finding 43).  Anything but contiguous fp32 parameters on a GPU goes to ARTDECO's own body."""
+    if not _pose_params_ok(self):
+        return type(self)._unfused_get_Rt(self)
+    return PoseRt.apply(self.rW2C, self.tW2C)
+
+
+def fused_set_Rt(self, Rt):
+    """Keyframe.set_Rt (scene/keyframe.py:156-159) as ONE launch (adk_pose6d_set): rW2C.data <- Rt[:3, :2], tW2C.data <- Rt[:3, 3],
+    approx_centre = -Rt[:3, :3]^T Rt[:3, 3]."""
+    if not (_pose_params_ok(self) and torch.is_tensor(Rt) and Rt.is_cuda and Rt.dtype == torch.float32 and tuple(Rt.shape) == (4, 4)
+            and Rt.device == self.rW2C.device):
+        return type(self)._unfused_set_Rt(self, Rt)
+    lib = _lib.load()
+    Rc = Rt.detach().contiguous()
+    with torch.no_grad(), _lib.on_device(Rc.device):
+        centre = torch.empty(3, dtype=torch.float32, device=Rc.device)
+        rc = lib.adk_pose6d_set(Rc.data_ptr(), self.rW2C.data.data_ptr(), self.tW2C.data.data_ptr(), centre.data_ptr(), _lib.stream_of(Rc))
+    _lib.check(rc, "adk_pose6d_set")
+    self.approx_centre = centre
+
+
+def patch_keyframe_class(cls) -> bool:
+    """Install fused_get_Rt / fused_set_Rt on a Keyframe CLASS (ARTDECO's scene.keyframe.Keyframe through the hook -- its sources pinned as the
+    "pose" group --, or the harness mirror's): idempotent; the originals stay reachable as `_unfused_get_Rt` / `_unfused_set_Rt`."""
+    if cls is None or not hasattr(cls, "get_Rt"):
+        return False
+    if "_unfused_get_Rt" not in cls.__dict__ and cls.get_Rt is not fused_get_Rt:
+        cls._unfused_get_Rt = cls.get_Rt
+        cls.get_Rt = fused_get_Rt
+    if hasattr(cls, "set_Rt") and "_unfused_set_Rt" not in cls.__dict__ and cls.set_Rt is not fused_set_Rt:
+        cls._unfused_set_Rt = cls.set_Rt
+        cls.set_Rt = fused_set_Rt
+    return True
 
 
 _SSIM_C1, _SSIM_C2 = 0.01 ** 2, 0.03 ** 2  # fused_ssim/__init__.py:36-37
@@ -1215,6 +1261,11 @@ def patch_scene_model(scene, verify: bool = False) -> bool:
     scene._artdeco_amd_skipped = dict(skip)
     freeze_gc(force=False)   # only with ARTDECO_AMD_GC_FREEZE=1: never a side effect of an import
     step_ok, densify_ok = "step" not in skip, "densify" not in skip
+    if "pose" not in skip and os.environ.get("ARTDECO_AMD_FUSE_POSE", "1") != "0":
+        # Keyframe.get_Rt / set_Rt as one launch each, on the CLASS the scene-model module binds (and its subclasses that override them)
+        mod = sys.modules.get(type(scene).__module__)
+        for name in ("Keyframe", "StreamKeyframe"):
+            patch_keyframe_class(getattr(mod, name, None))
     if step_ok:
         scene._unfused_render = scene.render
         scene.render = types.MethodType(fused_render, scene)

@@ -12,6 +12,7 @@ line on stderr names the methods that moved.
 Groups (a group is installed only when all of its methods match):
   step     the per-iteration path  h3dgsv3.py:401-469, 595-700; optimizers.py:77-161; keyframe.py:150-154, 186-191
   densify  the important-frame path  h3dgsv3.py:227-316, 766-953; optimizers.py:163-219; utils.py:93-108, 188-216
+  pose     Keyframe.get_Rt / set_Rt  keyframe.py:144-159; utils.py:223-229
 """
 from __future__ import annotations
 
@@ -37,6 +38,8 @@ GROUPS = {
                 # fused_add_new_gaussians uses artdeco_amd's PoseRt where the reference calls Keyframe.get_R / get_t / get_Rt -> sixD2mtx
                 # (keyframe.py:144-154, utils.py:223), and replicates make_torch_sampler's uv * 2 / (size - 1) - 1 (utils.py:203-212)
                 ("keyframe", "get_R"), ("keyframe", "get_t"), ("keyframe", "get_Rt"), ("kfutils", "sixD2mtx")],
+    # round 5: Keyframe.get_Rt / set_Rt themselves as one launch each (fused.patch_keyframe_class), for run_system.py's SLAM-keyframe loop
+    "pose": [("keyframe", "get_R"), ("keyframe", "get_t"), ("keyframe", "get_Rt"), ("keyframe", "set_Rt"), ("kfutils", "sixD2mtx")],
 }
 
 
@@ -69,7 +72,10 @@ def _resolve(scene_cls, optimizer_cls, where: str, attr: str):
         kf = getattr(mod, "Keyframe", None)
         if kf is None:
             return None
-        return getattr(kf, attr, None) if where == "keyframe" else getattr(sys.modules.get(kf.__module__), attr, None)
+        if where == "keyframe":
+            # a class this package has already patched (fused.patch_keyframe_class) is verified by the body it kept, not by the replacement
+            return getattr(kf, "_unfused_" + attr, None) or getattr(kf, attr, None)
+        return getattr(sys.modules.get(kf.__module__), attr, None)
     return getattr(mod, attr, None)
 
 

@@ -431,6 +431,9 @@ int adk_photometric_bwd(int W, int H, const float* colors4, const float* alphas,
  * (utils.py:223-229): r6 [3,2] row-major, t [3] -> Rt [4,4]; and its backward. */
 int adk_pose6d_fwd(const float* r6, const float* t, float* Rt, adk_stream_t stream);
 int adk_pose6d_bwd(const float* r6, const float* v_Rt, float* v_r6, float* v_t, adk_stream_t stream);
+/* Keyframe.set_Rt (scene/keyframe.py:156-159) as one launch: r6 [3,2] <- Rt[:3,:2], t [3] <- Rt[:3,3], centre [3] = -Rt[:3,:3]^T Rt[:3,3]
+ * (Rt [4,4] row-major, contiguous).  Round 5: run_system.py's SLAM-keyframe loop calls get_Rt twice and set_Rt once per keyframe. */
+int adk_pose6d_set(const float* Rt, float* r6, float* t, float* centre, adk_stream_t stream);
 
 /* Visibility masks of SceneModel.render (h3dgsv3.py:695-698): vis[g] = radii[g] > 0 (both axes);
  * gvis[cls_id[g]] = 1 for every visible g (gvis [V] bytes, cleared here; may be NULL). */

@@ -673,3 +673,47 @@ def test_fused_paths_on_an_empty_scene(dev):
     assert pkg["render"].shape == (3, 64, 96) and pkg["visibility_filter"].numel() == 0
     assert torch.allclose(pkg["render"], torch.tensor([0.2, 0.4, 0.6], device=dev)[:, None, None].expand(3, 64, 96))
     assert sc.optimization_step(0) is None
+
+
+@pytest.mark.gpu
+def test_fused_keyframe_pose_ops_match_the_torch_bodies(dev):
+    """Round 5: Keyframe.get_Rt / set_Rt (scene/keyframe.py:150-159) as one launch each on the Keyframe CLASS (fused.patch_keyframe_class,
+    installed with the scene's fused paths): what run_system.py's SLAM-keyframe loop (:194-227) calls per existing keyframe.  Same matrix
+    (1e-6: sixD2mtx's own roundings), same gradient through it, same parameters / approximate centre after set_Rt; CPU keyframes keep
+    ARTDECO's body."""
+    from artdeco_amd import fused
+    from harness import mapper, stream
+    sc = mapper.build_synthetic_mapper(3000, 160, 112, dev, seed=2, n_keyframes=0)
+    assert fused.patch_scene_model(sc)
+    assert mapper.StreamKeyframe.get_Rt is fused.fused_get_Rt and mapper.StreamKeyframe.set_Rt is fused.fused_set_Rt
+    assert mapper.Keyframe.get_Rt is fused.fused_get_Rt
+    frames = stream.synthetic_frames(sc, 2, seed=1, slam_hw=(56, 80))
+    g = torch.Generator().manual_seed(4)
+    for fr in frames:
+        kf = stream.make_keyframe(sc, fr, len(sc.keyframes))
+        with torch.no_grad():
+            kf.rW2C.add_(0.2 * torch.randn(3, 2, generator=g).to(dev))
+            kf.tW2C.add_(0.5 * torch.randn(3, generator=g).to(dev))
+        Rt_f = kf.get_Rt()
+        Rt_u = type(kf)._unfused_get_Rt(kf)
+        assert Rt_f.shape == (4, 4) and torch.allclose(Rt_f, Rt_u, atol=1e-6)
+        w = torch.randn(4, 4, generator=g).to(dev)
+        (Rt_f * w).sum().backward()
+        gf = (kf.rW2C.grad.clone(), kf.tW2C.grad.clone())
+        kf.rW2C.grad = kf.tW2C.grad = None
+        (Rt_u * w).sum().backward()
+        assert torch.allclose(gf[0], kf.rW2C.grad, rtol=1e-4, atol=1e-5) and torch.allclose(gf[1], kf.tW2C.grad, atol=1e-6)
+        kf.rW2C.grad = kf.tW2C.grad = None
+        new = Rt_u.detach().clone()
+        new[:3, 3] += torch.tensor([0.1, -0.2, 0.05], device=dev)
+        new[:3, :3] = mapper.sixD2mtx(new[:3, :2] + 0.05)
+        kf.set_Rt(new)
+        a = (kf.rW2C.detach().clone(), kf.tW2C.detach().clone(), kf.approx_centre.clone())
+        type(kf)._unfused_set_Rt(kf, new)
+        assert torch.equal(a[0], kf.rW2C.detach()) and torch.equal(a[1], kf.tW2C.detach())
+        assert torch.allclose(a[2], kf.approx_centre, atol=1e-6) and a[2].shape == (3,)
+        kf.set_Rt(new[None][0].t().t())      # a non-contiguous-looking view goes through .contiguous()
+        assert torch.equal(a[0], kf.rW2C.detach())
+        sc.add_keyframe(kf)
+    cpu_kf = mapper.Keyframe(torch.rand(3, 8, 8), torch.rand(1, 8, 8), torch.eye(4), "cpu")
+    assert torch.equal(cpu_kf.get_Rt(), torch.eye(4))      # CPU parameters: ARTDECO's own body

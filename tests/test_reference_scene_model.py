@@ -98,6 +98,10 @@ def test_module_binds_the_dropins_and_autofuse_wraps_the_class(ref_module, monke
     assert scene.render.__func__ is fused.fused_render and scene.optimization_step.__func__ is fused.fused_optimization_step
     assert scene.optimizer.step.__func__ is fused.fused_optimizer_step
     assert scene.weed_out_gaussians.__func__ is fused.fused_weed_out_gaussians
+    # round 5: the Keyframe CLASS the module binds carries the one-launch get_Rt / set_Rt (sources pinned as the "pose" group); on CPU
+    # parameters they run ARTDECO's own bodies
+    assert mod.Keyframe.get_Rt is fused.fused_get_Rt and mod.Keyframe.set_Rt is fused.fused_set_Rt
+    assert mod.Keyframe._unfused_get_Rt.__qualname__ == "Keyframe.get_Rt"
     scene.reset_optimizer()                     # h3dgsv3.py:317-330 replaces the optimiser; the wrapper follows it
     assert scene.optimizer.step.__func__ is fused.fused_optimizer_step
     monkeypatch.setenv("ARTDECO_AMD_AUTOFUSE", "0")
