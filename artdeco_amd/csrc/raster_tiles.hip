@@ -347,8 +347,12 @@ struct PixBwd {
 #ifndef ADK_BWD_MINWAVES
 #define ADK_BWD_MINWAVES 5   // 96 VGPRs, no scratch (99 -> 4 waves without it)
 #endif
-template <int QX, int QY, bool SUB = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 1 : ADK_BWD_MINWAVES, 8))) void raster_bwd_kernel(
+// WG2 (round 5, lab knob ADK_RASTER_BWD_WG2=1): the two 16x8 halves of a list tile as the two waves of ONE 128-thread workgroup instead of two
+// single-wave workgroups -- the 64 splats of a batch are staged once, both waves park their totals in ONE shared table (LDS float adds) and
+// the batch is flushed once: one 48 B atomic record per (splat, TILE) again instead of per (splat, half).  The price: three real workgroup
+// barriers per batch between two waves whose hit counts differ.  Measured: DESIGN finding 42.
+template <int QX, int QY, bool SUB = false, bool WG2 = false>
+__global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 1 : ADK_BWD_MINWAVES, 8))) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     const float* __restrict__ final_T, const int32_t* __restrict__ last_ids,
@@ -356,17 +360,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
     float* __restrict__ v_rec)
 {
     static_assert(!SUB || (QX <= 2 && QY == 1), "SUB: a wave serves one quadrant or one 16x8 half of a 16x16 list tile");
+    static_assert(!WG2 || (SUB && QX == 2 && QY == 1), "WG2: the two 16x8 halves of a tile as the two waves of one workgroup");
     constexpr int NQ = QX * QY, TPW = SUB ? 16 : 8 * QX, TPH = SUB ? 16 : 8 * QY;
     constexpr int PARTS = SUB ? 4 / NQ : 1, PCOLS = SUB ? 2 / QX : 1;
     __shared__ float4 srec[64][3];
     __shared__ int sid[64];
     __shared__ float sacc[64][12]; // [staged splat][dword of its gradient record]: totals parked until the batch is flushed
+    __shared__ unsigned long long wg2_mask[2];
+    __shared__ int wg2_final[2];
     const int n_tiles = tile_w * tile_h;
-    const int vtile = xcd_remap(blockIdx.x, PARTS * n_tiles);
+    const int wave = WG2 ? (int)(threadIdx.x >> 6) : 0;
+    const int vtile = WG2 ? xcd_remap(blockIdx.x, n_tiles) * PARTS + wave : xcd_remap(blockIdx.x, PARTS * n_tiles);
     const int tile = vtile / PARTS, part = vtile % PARTS;
     const int tx = tile % tile_w, ty = tile / tile_w;
     const int px0 = tx * TPW + (part % PCOLS) * 8 * QX, py0 = ty * TPH + (part / PCOLS) * 8 * QY;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 
     const int range_start = offsets[tile];
     const int range_end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -442,6 +450,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
     const float4* rec4 = reinterpret_cast<const float4*>(rec);
     const float fx0 = (float)(px0 + (lane & 7)) + 0.5f, fy0 = (float)(py0 + (lane >> 3)) + 0.5f;
     const float tox = (float)px0 + 0.5f, toy = (float)py0 + 0.5f;
+    if constexpr (WG2) { // both waves walk the SAME batches (they share the staging and the barriers): the later of the two halves' last contributors
+        if (lane == 0) wg2_final[wave] = tile_bin_final;
+        for (int i = threadIdx.x; i < 64 * 12; i += 128) (&sacc[0][0])[i] = 0.f; // parked totals are ADDED by both waves; the flush zeroes what it reads
+        __syncthreads();
+        tile_bin_final = max(wg2_final[0], wg2_final[1]);
+    }
 
     // walk the tile's list back to front in groups of 64; groups entirely behind every pixel's last
     // contributor are skipped without being loaded
@@ -454,9 +468,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         if (have) {
             g = flatten_ids[batch_end - lane];
-            r0 = rec4[3 * (int64_t)g]; r1 = rec4[3 * (int64_t)g + 1]; r2 = rec4[3 * (int64_t)g + 2];
-            sid[lane] = g;
-            stage_splat(srec[lane], r0, r1, r2);
+            r0 = rec4[3 * (int64_t)g]; r1 = rec4[3 * (int64_t)g + 1];
+            if (!WG2 || wave == 0) { // WG2: one wave stages for both (the other still needs r0 / r1 for its own cull test)
+                r2 = rec4[3 * (int64_t)g + 2];
+                sid[lane] = g;
+                stage_splat(srec[lane], r0, r1, r2);
+            }
         }
         __syncthreads();
         unsigned long long touched_mask = 0ull; // staged splats whose totals were parked in sacc
@@ -624,7 +641,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
                 if (pk_active) {
                     const float v = pk_use_z1 ? red.z1 : red.z0;
                     const float io = pk_is_b ? inv_opac2 : inv_opac;
-                    sacc[pk_is_b ? t2 : t][pk_dword] = v * (pk_is_opacity ? io : pk_scale);
+                    const float pv = v * (pk_is_opacity ? io : pk_scale);
+                    if constexpr (WG2) atomicAdd(&sacc[pk_is_b ? t2 : t][pk_dword], pv); // the other half's wave parks into the same table
+                    else sacc[pk_is_b ? t2 : t][pk_dword] = pv;
                 }
                 continue;
             }
@@ -634,22 +653,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
             touched_mask |= 1ull << t;
             // per-splat factors applied by the owner lane as it parks its total: -1 on the v_sigma-weighted dwords, -1/2 on the
             // symmetric conic entries, 1/opacity (staged in a.w) on the opacity gradient
-            if (red.is_owner) sacc[t][own_dword] = red.value * (own_is_opacity ? inv_opac : own_scale);
+            if (red.is_owner) {
+                const float pv = red.value * (own_is_opacity ? inv_opac : own_scale);
+                if constexpr (WG2) atomicAdd(&sacc[t][own_dword], pv);
+                else sacc[t][own_dword] = pv;
+            }
         }
         // Flush the batch: one instruction = 4 staged splats x the 12 dwords of their gradient records (10 live), so its
         // atomics fall into 4 records.  The per-splat factors were applied when the totals were parked, the lane's role
         // (dword live?) is a kernel-lifetime constant and the "was this splat touched" test is one bit test against a
         // scalar nibble: 2 VALU + 2 LDS reads + 1 atomic per instruction (a per-lane 64-bit shift, three compares on the
         // dword index, an LDS read of the opacity and a v_rcp per instruction before: 0.599 -> 0.580 ms).
-        if (touched_mask) {
+        if constexpr (WG2) { // both waves' marks, then ONE flush of the batch, its 16 instructions dealt out between the two waves
+            if (lane == 0) wg2_mask[wave] = touched_mask;
             __syncthreads();
+            touched_mask = wg2_mask[0] | wg2_mask[1];
+        }
+        if (WG2 || touched_mask) {
+            if constexpr (!WG2) __syncthreads();
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
+                if (WG2 && (j & 1) != wave) continue;
                 const unsigned nib = (unsigned)(touched_mask >> (4 * j)) & 0xFu; // scalar: the 4 splats this instruction covers
                 if (!nib) continue;
                 if (nib & flush_rowbit) { // this lane's dword is live and its splat was touched
                     const int sp = 4 * j + (lane >> 4);
                     const float total = sacc[sp][lane & 15];
+                    if constexpr (WG2) sacc[sp][lane & 15] = 0.f; // the table is ready for the next batch's adds
                     if (total != 0.f) unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[sp] + (lane & 15), total);
                 }
             }
@@ -679,6 +709,9 @@ static int split_parts(int n_tiles, bool bwd) {
     if (bwd) return n_tiles < 1600 ? 4 : (n_tiles < 20000 ? 2 : 1);   // round 4 (paired reduction): the halves win or tie up to 19 764 tiles, see the table above
     return n_tiles < 3072 ? 4 : 2;
 }
+
+// ADK_RASTER_BWD_WG2=1 (read per launch): the two-halves backward as one 128-thread workgroup per tile (lab form, DESIGN finding 42)
+static bool wg2_form() { const char* e = getenv("ADK_RASTER_BWD_WG2"); return e && e[0] == '1'; }
 
 // render_colors [H,W,4], render_alphas [H,W], final_T [H,W] (exact final transmittance, consumed by adk_raster_bwd),
 // last_ids [H,W]; backgrounds [4] or NULL; main_ids [H,W] (Gaussian id with the largest alpha*T per pixel, -1 if none) or NULL.
@@ -737,6 +770,9 @@ extern "C" int adk_raster_bwd_t(int width, int height, int tile_px_w, int tile_p
                            rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
     else if (const int parts = split_parts(tile_w * tile_h, true); parts == 4)
         hipLaunchKernelGGL((adk::raster_bwd_kernel<1, 1, true>), dim3(4 * tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
+                           rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
+    else if (parts == 2 && wg2_form())
+        hipLaunchKernelGGL((adk::raster_bwd_kernel<2, 1, true, true>), dim3(tile_w * tile_h), dim3(128), 0, stream, tile_w, tile_h, width, height,
                            rec, flatten_ids, offsets, (int)n_isects, backgrounds, final_T, last_ids, v_render_colors, v_render_alphas, v_rec);
     else if (parts == 2)
         hipLaunchKernelGGL((adk::raster_bwd_kernel<2, 1, true>), dim3(2 * tile_w * tile_h), dim3(64), 0, stream, tile_w, tile_h, width, height,
