@@ -252,7 +252,9 @@ def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeyp
 
 @pytest.mark.gpu
 def test_default_step_matches_the_fp64_oracle_at_1M_1080p(dev, monkeypatch):
-    _hold_default_path_to_the_oracle(dev, 1_000_000, 1920, 1080, True, False, 11, monkeypatch, tol_pose=1e-3)
+    # max error: the fp32 floor of THIS frame is 8.47e-5 on xyz (profiles/r05_fp32_floor_1M_1080p.txt; the HIP path: 8.5e-5) -- too close to 1e-4 to
+    # assert 1e-4 on a quantity that is a single worst element; rel_l2 stays at 1e-4 (measured <= 3.3e-5)
+    _hold_default_path_to_the_oracle(dev, 1_000_000, 1920, 1080, True, False, 11, monkeypatch, tol_pose=1e-3, tol_max=2e-4)
 
 
 @pytest.mark.gpu
