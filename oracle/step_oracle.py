@@ -29,7 +29,6 @@ from __future__ import annotations
 
 import atexit
 import json
-import math
 import multiprocessing as mp
 import os
 import shutil

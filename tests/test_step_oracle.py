@@ -19,7 +19,6 @@ Knife edges, and what is done about each (measured first, DESIGN round-5 finding
 CPU part (`-m "not gpu"`): the oracle against the harness mirror run on the fp32 CPU oracles (the chain the reference's real class is
 pinned to in tests/test_reference_scene_model.py).
 """
-import math
 import time
 
 import pytest
@@ -187,7 +186,6 @@ def _default_path_step(sc, kid, important, seed):
 
 
 def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeypatch, max_mask_flips=4, **tols):
-    import os
     from artdeco_amd import fused
     from harness import mapper
     from oracle import step_oracle as SO

@@ -14,7 +14,6 @@ and checks the split product's error against float64.
 
     python tools/lab/split_gemm_lab.py
 """
-import sys
 import torch
 
 dev = torch.device("cuda:0")
@@ -83,8 +82,6 @@ def main():
         print(f"  {name:12s} {K:5d} {N:5d} | {t16:7.1f} | {tg:11.1f} {ts:7.1f} | {t32:7.1f} | {e16:.1e} / {eb:.1e} / {e3:.1e} / {e32:.1e}")
         c = COUNTS[name]
         tot["fp16"] += c * t16; tot["bf16x3"] += c * (tg + ts); tot["fp32"] += c * t32
-    # per asymmetric pair match: two encodes + one decoder pass (both branches)
-    enc = lambda k: 0.0
     print(f"# GEMM time per tracked frame's trunk (1 encode + decoder, us): " + ", ".join(f"{k} {v / 1e3:.2f} ms" for k, v in tot.items()))
 
 
