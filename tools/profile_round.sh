@@ -17,6 +17,7 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then python "$ROOT/bench.py" > "$OUT/${TAG}_be
 rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o b -- $BENCH > /tmp/pk.log 2>&1
 cp /tmp/pk/b_kernel_stats.csv "$OUT/${TAG}_step_kernel_stats.csv"
 python "$ROOT/tools/step_timeline.py" /tmp/pk/b_kernel_trace.csv > "$OUT/${TAG}_step_timeline.txt"
+python "$ROOT/tools/step_timeline.py" /tmp/pk/b_kernel_trace.csv mid > "$OUT/${TAG}_step_timeline_timed_region.txt"   # a step without the breakdown pass's events
 rm -rf /tmp/pf /tmp/pw /tmp/ps
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o b -- $BENCH > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o b -- $BENCH > /tmp/pw.log 2>&1
