@@ -214,7 +214,8 @@ def main():
     cadence = dict(kf_every=args.kf_every, slam_every=args.slam_every, test_hold=args.test_hold)
     n_detail = 10 if world == 1 else 0
     n_frozen = args.steps if world == 1 else 0
-    frames = stream.synthetic_frames(scene, args.warmup + args.steps + n_frozen + n_detail, seed=rank, texture=args.texture)  # resident in HBM
+    n_torch_inv = args.steps if world == 1 and not args.unfused_glue else 0
+    frames = stream.synthetic_frames(scene, args.warmup + args.steps + n_frozen + n_torch_inv + n_detail, seed=rank, texture=args.texture)  # resident in HBM
 
     def sync_all():
         multigpu.barrier(dev)
@@ -244,9 +245,20 @@ def main():
         k0 = args.warmup + args.steps
         frozen = stream.run_stream(scene, frames[k0:k0 + n_frozen], start_index=k0, **cadence)
         fused.unfreeze_gc()   # everything reported after this runs with the interpreter's default again
+    torch_inv = None
+    if n_torch_inv:
+        # the next frames with torch's own 4x4 inverse back in place (ARTDECO_AMD_FAST_INV4=0): what the wrapped inverse is worth to run_system.py's
+        # SLAM-keyframe loop (a LATER window of the sequence: more keyframes in that loop than `value`'s window had)
+        from artdeco_amd import small_inverse
+        was = small_inverse.installed()
+        small_inverse.uninstall()
+        k0 = args.warmup + args.steps + n_frozen
+        torch_inv = stream.run_stream(scene, frames[k0:k0 + n_torch_inv], start_index=k0, **cadence)
+        if was:
+            small_inverse.install(force=True)
     if n_detail:
         # untimed: the loop's stages bracketed by device synchronisations, then the kernels of the optimisation step by HIP events
-        k0 = args.warmup + args.steps + n_frozen
+        k0 = args.warmup + args.steps + n_frozen + n_torch_inv
         frame_stages = stream.run_stream(scene, frames[k0:], start_index=k0, breakdown=True,
                                          **cadence)["stage_ms"]
         detail = rasterizer.StageTimer()
@@ -338,6 +350,13 @@ def main():
                                      "sequence_position": f"frames {args.warmup + args.steps}-{args.warmup + args.steps + n_frozen} of the same sequence",
                                      "note": "after fused.freeze_gc() (the host program's opt-in, ARTDECO_AMD_GC_FREEZE=1): no generation-2 "
                                              "collection walks the process's long-lived objects between optimisation steps"}
+        if torch_inv is not None:
+            k0 = args.warmup + args.steps + n_frozen
+            out["with_torch_inverse"] = {"frames_per_s": torch_inv["frames"] / torch_inv["seconds"], "frames": torch_inv["frames"],
+                                         "sequence_position": f"frames {k0}-{k0 + n_torch_inv} of the same sequence",
+                                         "note": "ARTDECO_AMD_FAST_INV4=0: torch.linalg.inv / Tensor.inverse as torch ships them (batched LU + a blocking "
+                                                 "read of `info` per call; run_system.py:221-223 calls three per mapper keyframe on a SLAM keyframe) "
+                                                 "instead of artdeco_amd.small_inverse (one launch, no read-back), default GC"}
         del scene, frames
         torch.cuda.empty_cache()
         if not args.no_extra_configs and world == 1:

@@ -31,6 +31,10 @@ def warm_libraries(dev):
     the rocSOLVER / hipBLAS handles (hundreds of milliseconds, once per process; run_system.py pays it on its first SLAM keyframe)."""
     e = torch.eye(4, device=dev)[None].repeat(3, 1, 1)
     torch.linalg.inv(e[0]); torch.inverse(e); torch.bmm(e, e)
+    from artdeco_amd import small_inverse
+    if small_inverse.installed():     # torch's own functions too: fused_rigid_transform_gs's inv_ex and an A/B against them share those handles
+        small_inverse._ORIG["linalg.inv"](e[0]); small_inverse._ORIG["inverse"](e)
+    torch.linalg.inv_ex(e)
     torch.cuda.synchronize()
 
 

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 17
+#define ADK_ABI_VERSION 18
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -434,6 +434,12 @@ int adk_pose6d_bwd(const float* r6, const float* v_Rt, float* v_r6, float* v_t, 
 /* Keyframe.set_Rt (scene/keyframe.py:156-159) as one launch: r6 [3,2] <- Rt[:3,:2], t [3] <- Rt[:3,3], centre [3] = -Rt[:3,:3]^T Rt[:3,3]
  * (Rt [4,4] row-major, contiguous).  Round 5: run_system.py's SLAM-keyframe loop calls get_Rt twice and set_Rt once per keyframe. */
 int adk_pose6d_set(const float* Rt, float* r6, float* t, float* centre, adk_stream_t stream);
+/* torch.linalg.inv / torch.inverse / Tensor.inverse of 4x4 fp32 matrices as run_system.py:221-224 calls them (three per mapper keyframe on a
+ * SLAM keyframe; h3dgsv3.py:1000 once per add_keyframe): n matrices, element (r, c) of matrix i at in[i * batch_stride + r * row_stride +
+ * c * col_stride] (element strides: the script inverts a transposed view), out [n,4,4] contiguous.  Gauss-Jordan, partial pivoting, fp64 inside.
+ * No read-back: a singular matrix gives a NaN-filled result and info[i] = 1 + the failing column (info [n] or NULL), not an exception. */
+int adk_inv4x4(const float* in, float* out, int64_t n, int64_t batch_stride, int64_t row_stride, int64_t col_stride, int32_t* info,
+               adk_stream_t stream);
 
 /* Visibility masks of SceneModel.render (h3dgsv3.py:695-698): vis[g] = radii[g] > 0 (both axes);
  * gvis[cls_id[g]] = 1 for every visible g (gvis [V] bytes, cleared here; may be NULL). */
