@@ -276,7 +276,6 @@ def test_exposure_clamp_matches_torch(dev):
 @pytest.mark.gpu
 def test_fused_optimizer_step_is_bit_identical(dev):
     """adk_adam_update_multi (one launch, in-kernel lr decay) == the per-tensor adamUpdate loop + torch lr ops."""
-    import copy
     from artdeco_amd import fused
     a = _scene(dev, N=6000, seed=5)
     a.optimization_step(0)                       # populates .grad on every parameter and non-trivial moments
