@@ -24,6 +24,7 @@
 //   * tiles are mapped to workgroups through an XCD-aware bijection so that neighbouring tiles
 //     (which share Gaussians) run on the same XCD and hit the same 4 MiB L2.
 #include "adk_common.hpp"
+#include <type_traits>
 
 namespace adk {
 
@@ -64,7 +65,31 @@ namespace adk {
 #ifndef ADK_BWD_ROWS_FIRST
 #define ADK_BWD_ROWS_FIRST 0
 #endif
+// Round 6 (tools/valu_cost_bench2.hip -> profiles/r06_valu_cost2.txt: v_mul / v_add / v_sub / v_fma / v_fmac / v_mov with VGPR operands issue at ~2.6
+// cycles per wave64 instruction per SIMD, v_min / v_max / every v_cmp / v_cndmask / DPP / anything with an SGPR operand at ~4.2, v_exp / v_rcp and
+// the permlane swaps at ~8.2): the per-evaluation bodies below are priced in those units and the dear class is what gets removed.
+//   ADK_FWD_LEAN    forward: ONE select per evaluated quadrant (alpha zeroed where the pixel does not blend the splat: T (1 - 0) = T and 0 T = 0
+//                   need no select of their own) instead of three, the terminating lanes fixed up in the branch that already handles them, and
+//                   last_ids written only there (it now holds the list index in front of the splat the pixel STOPPED at, or the tile's last
+//                   index if it never stopped -- all the backward needs: a splat between the last contributor and that index fails the same
+//                   alpha tests in the backward as it did here)
+//   ADK_CLAMP_HOIST min(0.999, alpha) -- and the backward's "clamped alpha passes no gradient" compare -- only for splats whose opacity can
+//                   reach 0.999 at all (alpha <= opacity wherever sigma >= 0): one ballot per staged batch, one scalar bit test per splat
+#ifndef ADK_FWD_LEAN
+#define ADK_FWD_LEAN 1
+#endif
+#ifndef ADK_CLAMP_HOIST
+#define ADK_CLAMP_HOIST 1
+#endif
+#ifndef ADK_CLAMP_HOIST_BWD
+#define ADK_CLAMP_HOIST_BWD 0   // measured (profiles/r06_ab_lean1.txt): forward -2 % alone / -9.1 % with FWD_LEAN; backward +0.7 % (two selects fewer, six scalar instructions more, at 6 waves)
+#endif
+// A wave-uniform flag tested where it is used: laundered through an empty asm at the use site so that the compare stays next to its branch
+// (s_cmp + s_cbranch_scc).  Hoisted into the defining block the i1 crossed basic blocks as a lane mask that hipcc rebuilt through a VGPR
+// (v_cndmask 0,1 + v_cmp_ne: two dear VALU instructions per use).
+__device__ __forceinline__ bool scalar_flag(unsigned f) { asm("" : "+s"(f)); return f != 0u; }
 #define MAX_ALPHA 0.999f
+#define CLAMP_OPAC 0.998f   // alpha = exp2(e) <= exp2(log2 opacity) (1 + 2^-21) < 0.999 for every opacity at or below this
 #define ALPHA_THR (1.0f / 255.0f)
 #define T_EPS 1e-4f
 
@@ -108,10 +133,10 @@ __device__ __forceinline__ bool splat_reaches_rect(float mx, float my, float a, 
 // disappear (2 of ~25 / ~45 VALU instructions per evaluated pixel quadrant in fwd / bwd).  Forward and backward use the
 // SAME explicit fma sequence (splat_exponent) so that they take identical skip / terminate decisions on every pixel.
 struct StagedSplat { float4 a, cn, col; }; // a = (mean2d.x, mean2d.y, log2 opacity, 1/opacity), cn = (A, B, C, unused)
-__device__ __forceinline__ void stage_splat(float4 (&dst)[3], const float4& r0, const float4& r1, const float4& r2) {
+__device__ __forceinline__ void stage_splat(float4 (&dst)[3], const float4& r0, const float4& r1, const float4& r2, float spare = 0.f) {
     const float L2E = 1.4426950408889634f;
     dst[0] = make_float4(r0.x, r0.y, __log2f(r0.z), __builtin_amdgcn_rcpf(r0.z)); // .w = 1/opacity (backward: scale of the opacity gradient)
-    dst[1] = make_float4(-0.5f * L2E * r1.x, -L2E * r1.y, -0.5f * L2E * r1.z, 0.f);
+    dst[1] = make_float4(-0.5f * L2E * r1.x, -L2E * r1.y, -0.5f * L2E * r1.z, spare); // .w: free for the caller (backward: the Gaussian's id)
     dst[2] = r2;
 }
 // log2(opacity * exp(-sigma)) at offset (dx, dy) from the splat centre
@@ -175,7 +200,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
         const int pxi = ox + (lane & 7), pyi = oy + (lane >> 3);
         PixFwd& P = px[q];
         P.o0 = P.o1 = P.o2 = P.o3 = 0.f;
-        P.T = 1.f; P.cur_idx = 0; P.best_vis = 0.f; P.best_idx = -1;
+        P.T = 1.f; P.best_vis = 0.f; P.best_idx = -1;
+        P.cur_idx = ADK_FWD_LEAN ? range_end - 1 : 0; // LEAN: the list index the backward starts at -- the tile's last unless the pixel stops earlier
         inside[q] = (pxi < W) && (pyi < H);
         done_m[q] = __builtin_amdgcn_ballot_w64(!inside[q]);
         if (__ballot(inside[q]) != 0ull) live |= 1u << q;
@@ -197,6 +223,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
             stage_splat(srec[lane], r0, r1, rec4[3 * g + 2]);
         }
         __syncthreads();
+#if ADK_CLAMP_HOIST
+        const unsigned long long clamp_m = __ballot(have && !(r0.z <= CLAMP_OPAC)); // staged splats whose alpha can reach the 0.999 clamp (NaN opacity: kept)
+#endif
         // splat-parallel culling: this lane's splat against each live quadrant -> the lane's own quadrant bit set
 #if ADK_CULL_BALLOT_FWD
         unsigned long long mq[NQ];
@@ -239,45 +268,92 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8
 #endif
             const float4 a = srec[t][0], cn = srec[t][1], col = srec[t][2];
             const int idx = batch_start + t;
+            // mc (wave-uniform): this splat's opacity can reach 0.999, so min(0.999, alpha) is taken; for every other splat it is the identity and a
+            // not-taken scalar branch skips it (asm volatile: as a select the compiler would if-convert it back into every evaluation)
+#if ADK_CLAMP_HOIST
+            const unsigned mc = (unsigned)(clamp_m >> t) & 1u;
+#else
+            const unsigned mc = 1u;
+#endif
+            {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (ADK_QHIT(q)) { // wave-uniform
-                    // Every predicate lives as a wave-uniform 64-bit lane mask (one v_cmp each, combined on the scalar unit) and is
-                    // applied as the mask operand of a v_cndmask: no 0/1 materialisation, no per-lane bit tests (a per-lane `done`
-                    // bit field + `bool && bool` + __ballot compiled to v_and / v_cmp / v_cndmask 0,1 / v_or / v_cmp_ne chains:
-                    // 24 VALU instructions per evaluated quadrant against 19 now; measured 0.270 -> 0.243 ms).  Measured and
-                    // rejected: the two state updates as plain v_movs under EXEC = contrib_m (0.254 ms: EXEC writes stall).
-                    PixFwd& P = px[q];
-                    const float dx = a.x - (fx0 + (float)((q % QX) * 8)), dy = a.y - (fy0 + (float)((q / QX) * 8));
-                    const float e = splat_exponent(a, cn, dx, dy);
-                    const float alpha = fminf(MAX_ALPHA, __builtin_amdgcn_exp2f(e));
-                    const unsigned long long m_sig = __builtin_amdgcn_ballot_w64(!(e > a.z)); // e > log2(opacity) <=> sigma < 0
-                    const unsigned long long m_thr = __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_THR));
-                    const unsigned long long valid_m = m_sig & m_thr & ~done_m[q];
-                    const float next_T = P.T * (1.0f - alpha);
-                    const unsigned long long m_le = __builtin_amdgcn_ballot_w64(next_T <= T_EPS);
-                    const unsigned long long term_m = valid_m & m_le;       // terminate BEFORE adding this splat
-                    const unsigned long long contrib_m = valid_m & ~m_le;
-                    float vis;
-                    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(vis) : "v"(alpha * P.T), "s"(contrib_m));
-                    P.o0 += col.x * vis; P.o1 += col.y * vis; P.o2 += col.z * vis; P.o3 += col.w * vis;
-                    if (MAIN_ID && vis > P.best_vis) { P.best_vis = vis; P.best_idx = idx; }
-                    // cur_idx = idx, T = next_T in the contributing lanes (the wave is always full here: 64-thread block, only
-                    // wave-uniform branches)
-                    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.cur_idx) : "v"(idx), "s"(contrib_m));
-                    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.T) : "v"(next_T), "s"(contrib_m));
-                    if (term_m != 0ull) { // rare: some pixel just finished
-                        done_m[q] |= term_m;
-                        if (~done_m[q] == 0ull) { // ... and it was the quadrant's last: later splats skip it
-                            live &= ~(1u << q);
-#if ADK_CULL_BALLOT_FWD
-                            mq[q] = 0ull;
-                            any = 0ull;
-#pragma unroll
-                            for (int qq = 0; qq < NQ; ++qq) any |= mq[qq];
-                            any &= ~((bit << 1) - 1ull);
+                for (int q = 0; q < NQ; ++q) {
+                    if (ADK_QHIT(q)) { // wave-uniform
+                        // Every predicate lives as a wave-uniform 64-bit lane mask (one v_cmp each, combined on the scalar unit) and is
+                        // applied as the mask operand of a v_cndmask: no 0/1 materialisation, no per-lane bit tests (a per-lane `done`
+                        // bit field + `bool && bool` + __ballot compiled to v_and / v_cmp / v_cndmask 0,1 / v_or / v_cmp_ne chains:
+                        // 24 VALU instructions per evaluated quadrant against 19; measured 0.270 -> 0.243 ms, round 2).  Measured and
+                        // rejected: the two state updates as plain v_movs under EXEC = contrib_m (0.254 ms: EXEC writes stall).
+                        PixFwd& P = px[q];
+                        const float dx = a.x - (fx0 + (float)((q % QX) * 8)), dy = a.y - (fy0 + (float)((q / QX) * 8));
+                        const float e = splat_exponent(a, cn, dx, dy);
+                        float alpha = __builtin_amdgcn_exp2f(e);
+                        if (__builtin_expect(scalar_flag(mc), !ADK_CLAMP_HOIST)) {
+#if ADK_CLAMP_HOIST
+                            asm volatile("s_nop 0\n\tv_min_f32_e32 %0, 0x3f7fbe77, %0" : "+v"(alpha)); // s_nop: v_exp result -> VALU use needs a wait state hipcc cannot see inside asm
+#else
+                            alpha = fminf(MAX_ALPHA, alpha);
 #endif
                         }
+                        const unsigned long long m_sig = __builtin_amdgcn_ballot_w64(!(e > a.z)); // e > log2(opacity) <=> sigma < 0
+                        const unsigned long long m_thr = __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_THR));
+                        const unsigned long long valid_m = m_sig & m_thr & ~done_m[q];
+#if ADK_FWD_LEAN
+                        // ONE select: alpha zeroed in the lanes that do not blend this splat.  Such a lane keeps T (T * 1) and adds nothing (0 * T),
+                        // and it cannot trip the terminate test: a pixel that is not finished has T > T_EPS, a finished one kept the T it had
+                        // in front of the splat it stopped at.  A lane that DOES stop here is fixed up in the branch below (as often as a pixel
+                        // finishes, i.e. once per pixel).  Same products in the same order as the three-select form: bit-identical output.
+                        float alpha_v;
+                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(alpha_v) : "v"(alpha), "s"(valid_m));
+                        float next_T = P.T * (1.0f - alpha_v);
+                        float vis = alpha_v * P.T;
+                        const unsigned long long term_m = __builtin_amdgcn_ballot_w64(next_T <= T_EPS); // terminate BEFORE adding this splat
+                        if (term_m != 0ull) {
+                            asm("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(vis) : "s"(term_m));
+                            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(next_T) : "v"(P.T), "s"(term_m));
+                            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.cur_idx) : "v"(idx - 1), "s"(term_m)); // the backward starts in front of this splat
+                            done_m[q] |= term_m;
+                            if (~done_m[q] == 0ull) { // ... and it was the quadrant's last: later splats skip it
+                                live &= ~(1u << q);
+#if ADK_CULL_BALLOT_FWD
+                                mq[q] = 0ull;
+                                any = 0ull;
+#pragma unroll
+                                for (int qq = 0; qq < NQ; ++qq) any |= mq[qq];
+                                any &= ~((bit << 1) - 1ull);
+#endif
+                            }
+                        }
+                        P.T = next_T;
+                        P.o0 += col.x * vis; P.o1 += col.y * vis; P.o2 += col.z * vis; P.o3 += col.w * vis;
+                        if (MAIN_ID && vis > P.best_vis) { P.best_vis = vis; P.best_idx = idx; }
+#else
+                        const float next_T = P.T * (1.0f - alpha);
+                        const unsigned long long m_le = __builtin_amdgcn_ballot_w64(next_T <= T_EPS);
+                        const unsigned long long term_m = valid_m & m_le;       // terminate BEFORE adding this splat
+                        const unsigned long long contrib_m = valid_m & ~m_le;
+                        float vis;
+                        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(vis) : "v"(alpha * P.T), "s"(contrib_m));
+                        P.o0 += col.x * vis; P.o1 += col.y * vis; P.o2 += col.z * vis; P.o3 += col.w * vis;
+                        if (MAIN_ID && vis > P.best_vis) { P.best_vis = vis; P.best_idx = idx; }
+                        // cur_idx = idx, T = next_T in the contributing lanes (the wave is always full here: 64-thread block, only
+                        // wave-uniform branches)
+                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.cur_idx) : "v"(idx), "s"(contrib_m));
+                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(P.T) : "v"(next_T), "s"(contrib_m));
+                        if (term_m != 0ull) { // rare: some pixel just finished
+                            done_m[q] |= term_m;
+                            if (~done_m[q] == 0ull) { // ... and it was the quadrant's last: later splats skip it
+                                live &= ~(1u << q);
+#if ADK_CULL_BALLOT_FWD
+                                mq[q] = 0ull;
+                                any = 0ull;
+#pragma unroll
+                                for (int qq = 0; qq < NQ; ++qq) any |= mq[qq];
+                                any &= ~((bit << 1) - 1ull);
+#endif
+                            }
+                        }
+#endif
                     }
                 }
             }
@@ -347,12 +423,19 @@ struct PixBwd {
 #ifndef ADK_BWD_MINWAVES
 #define ADK_BWD_MINWAVES 5   // 96 VGPRs, no scratch (99 -> 4 waves without it)
 #endif
+// Round 6: the halves form at 7 waves per SIMD (72 VGPRs, no scratch, once the parked totals share the staged records' LDS: 3 KB per wave instead of
+// 6.4) -- 0.5177 -> 0.5078 ms at 1 M / 1080p; forced to 8 (64 VGPRs, 10 dwords of scratch) it LOSES 9 % there.  The kernel sits on the knee between
+// issue-bound and latency-bound: an LDS-budget probe that left it 4 / 3 resident waves cost +13.6 % / +42 %, four padding VALU instructions per
+// evaluated quadrant (+6.3 % instructions) +4.8 % whether of the 2.6-cycle or of the 4.2-cycle class (profiles/r06_bwd_probes.txt).
+#ifndef ADK_BWD_MINWAVES_SUB
+#define ADK_BWD_MINWAVES_SUB 7   // the halves / quadrants forms (SUB)
+#endif
 // WG2 (round 5, lab knob ADK_RASTER_BWD_WG2=1): the two 16x8 halves of a list tile as the two waves of ONE 128-thread workgroup instead of two
 // single-wave workgroups -- the 64 splats of a batch are staged once, both waves park their totals in ONE shared table (LDS float adds) and
 // the batch is flushed once: one 48 B atomic record per (splat, TILE) again instead of per (splat, half).  The price: three real workgroup
 // barriers per batch between two waves whose hit counts differ.  Measured: DESIGN finding 42.
 template <int QX, int QY, bool SUB = false, bool WG2 = false>
-__global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 1 : ADK_BWD_MINWAVES, 8))) void raster_bwd_kernel(
+__global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(QX * QY == 8 ? 1 : (SUB ? ADK_BWD_MINWAVES_SUB : ADK_BWD_MINWAVES), 8))) void raster_bwd_kernel(
     int tile_w, int tile_h, int W, int H, const float* __restrict__ rec, const int32_t* __restrict__ flatten_ids,
     const int32_t* __restrict__ offsets, int n_isects, const float* __restrict__ backgrounds,
     const float* __restrict__ final_T, const int32_t* __restrict__ last_ids,
@@ -363,9 +446,13 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     static_assert(!WG2 || (SUB && QX == 2 && QY == 1), "WG2: the two 16x8 halves of a tile as the two waves of one workgroup");
     constexpr int NQ = QX * QY, TPW = SUB ? 16 : 8 * QX, TPH = SUB ? 16 : 8 * QY;
     constexpr int PARTS = SUB ? 4 / NQ : 1, PCOLS = SUB ? 2 / QX : 1;
+    // Round 6: ONE 3 KB table per wave.  A staged record's 12 dwords are dead once its splat has been evaluated (the wave holds them in registers), so
+    // the splat's 10 totals are parked OVER its own record -- gradient-record dwords 0-2, 4-6, 8-11; dword 3 (1/opacity) is never written and dword 7
+    // carries the Gaussian's id for the flush -- instead of in a second table + an id array (6.4 KB per wave capped the CU at 25 waves).
+    // WG2 (lab form: two waves share the staging) keeps its own table.
     __shared__ float4 srec[64][3];
-    __shared__ int sid[64];
-    __shared__ float sacc[64][12]; // [staged splat][dword of its gradient record]: totals parked until the batch is flushed
+    __shared__ float sacc_wg2[WG2 ? 64 * 12 : 4];
+    float (*sacc)[12] = WG2 ? reinterpret_cast<float (*)[12]>(&sacc_wg2[0]) : reinterpret_cast<float (*)[12]>(&srec[0][0]);
     __shared__ unsigned long long wg2_mask[2];
     __shared__ int wg2_final[2];
     const int n_tiles = tile_w * tile_h;
@@ -452,7 +539,7 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     const float tox = (float)px0 + 0.5f, toy = (float)py0 + 0.5f;
     if constexpr (WG2) { // both waves walk the SAME batches (they share the staging and the barriers): the later of the two halves' last contributors
         if (lane == 0) wg2_final[wave] = tile_bin_final;
-        for (int i = threadIdx.x; i < 64 * 12; i += 128) (&sacc[0][0])[i] = 0.f; // parked totals are ADDED by both waves; the flush zeroes what it reads
+        for (int i = threadIdx.x; i < 64 * 12; i += 128) sacc_wg2[i] = 0.f; // parked totals are ADDED by both waves; the flush zeroes what it reads
         __syncthreads();
         tile_bin_final = max(wg2_final[0], wg2_final[1]);
     }
@@ -471,12 +558,14 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
             r0 = rec4[3 * (int64_t)g]; r1 = rec4[3 * (int64_t)g + 1];
             if (!WG2 || wave == 0) { // WG2: one wave stages for both (the other still needs r0 / r1 for its own cull test)
                 r2 = rec4[3 * (int64_t)g + 2];
-                sid[lane] = g;
-                stage_splat(srec[lane], r0, r1, r2);
+                stage_splat(srec[lane], r0, r1, r2, __int_as_float(g));
             }
         }
         __syncthreads();
         unsigned long long touched_mask = 0ull; // staged splats whose totals were parked in sacc
+#if ADK_CLAMP_HOIST_BWD
+        const unsigned long long clamp_m = __ballot(have && !(r0.z <= CLAMP_OPAC)); // staged splats whose alpha can reach the 0.999 clamp
+#endif
         // splat-parallel culling: this lane's splat against each quadrant -> the lane's own quadrant bit set
 #if ADK_CULL_BALLOT_BWD
         unsigned long long mq[NQ];
@@ -510,6 +599,11 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
         auto eval_splat = [&](const int t, float (&acc)[NACC], float& inv_opac) -> bool {
+#if ADK_CLAMP_HOIST_BWD
+            const unsigned mc = (unsigned)(clamp_m >> t) & 1u; // wave-uniform: the splat's opacity can reach the 0.999 clamp (almost never)
+#else
+            const unsigned mc = 1u;
+#endif
 #if ADK_CULL_BALLOT_BWD
             const unsigned long long bit = 1ull << t;
 #define ADK_QHITB(q) (mq[q] & bit)
@@ -547,9 +641,20 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                     // LEAN form (round 4): validity folded into ov ONCE (an invalid lane then has alpha = 0, ra = 1, fac = 0, gq = 0 on its own),
                     // the <buffer, v_render> recurrence kept as E = C0 - bdot (one register and one v_sub less per evaluation), and the
                     // alpha > 0.999 clamp -- which passes no gradient -- handled in a wave-uniform branch that is almost never taken.
-                    const float ov_v = valid ? ov : 0.f;
+                    float ov_v = valid ? ov : 0.f;
+#if ADK_CLAMP_HOIST_BWD
+                    // min(0.999, .) IN PLACE and only for a splat that can reach it (not-taken scalar branch): where alpha is not clamped it IS ov_v, where
+                    // it is clamped the gradient is zeroed below, so one register serves as both (a separate alpha cost a v_mov per evaluation)
+                    unsigned long long clamped_m = 0ull;
+                    if (__builtin_expect(scalar_flag(mc), 0)) {
+                        clamped_m = __ballot(ov_v > MAX_ALPHA);
+                        asm volatile("v_min_f32_e32 %0, 0x3f7fbe77, %0" : "+v"(ov_v));
+                    }
+                    const float alpha = ov_v;
+#else
                     float alpha;
                     asm("v_min_f32_e32 %0, 0x3f7fbe77, %1" : "=v"(alpha) : "v"(ov_v));
+#endif
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha); // 1 ulp v_rcp_f32; alpha <= 0.999
                     P.T *= ra;
                     const float fac = alpha * P.T;
@@ -557,10 +662,16 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                     const float v_alpha = P.T * S1 + ra * P.E;
                     P.E -= fac * S1;
                     float gq = ov_v * v_alpha;   // opacity * vis * v_alpha = -v_sigma
+#if ADK_CLAMP_HOIST_BWD
+                    if (__builtin_expect(scalar_flag(mc), 0) && clamped_m != 0ull) { // clamped alpha passes no gradient (opacity > 0.999 at the splat centre: almost never)
+                        asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(gq) : "s"(clamped_m));
+                    }
+#else
                     if (__ballot(ov_v > MAX_ALPHA) != 0ull) { // clamped alpha passes no gradient (opacity > 0.999 at the splat centre: almost never)
                         asm volatile("; clamped alpha"); // keeps this a real, not-taken branch (if-converted it costs two compares and a select on every evaluation)
                         gq = (ov_v > MAX_ALPHA) ? 0.f : gq;
                     }
+#endif
 #else
                     float alpha_raw; // min(0.999, ov) on the v_exp result itself (fminf() puts a canonicalising v_max in front)
                     asm("s_nop 0\n\tv_min_f32_e32 %0, 0x3f7fbe77, %1" : "=v"(alpha_raw) : "v"(ov)); // s_nop: v_exp result -> VALU use needs 1 wait state, invisible to hipcc inside asm
@@ -582,7 +693,7 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
 #define ADK_FMAC(d, x, y) asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(d) : "v"(x), "v"(y))
                     if (!touched) {
                         ADK_MUL(c0, gq, dx); ADK_MUL(c1, gq, dy);
-                        asm("v_mov_b32_e32 %0, %1" : "=v"(c2) : "v"(gq));
+                        c2 = gq; // plain assignment: coalesced into gq's register (as asm it was a v_mov onto itself)
                         ADK_MUL(c3, c0, dx); ADK_MUL(c4, c0, dy); ADK_MUL(c5, c1, dy);
                         ADK_MUL(c6, fac, P.vr0); ADK_MUL(c7, fac, P.vr1); ADK_MUL(c8, fac, P.vr2); ADK_MUL(c9, fac, P.vr3);
                     } else {
@@ -615,6 +726,7 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
             return touched != 0;
         };
 #pragma clang diagnostic pop
+
         while (any) {
             const int t = __builtin_ctzll(any); // staged slot t holds list index batch_end - t (0 = furthest back)
             any &= any - 1;
@@ -680,7 +792,7 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                     const int sp = 4 * j + (lane >> 4);
                     const float total = sacc[sp][lane & 15];
                     if constexpr (WG2) sacc[sp][lane & 15] = 0.f; // the table is ready for the next batch's adds
-                    if (total != 0.f) unsafeAtomicAdd(v_rec + 12 * (int64_t)sid[sp] + (lane & 15), total);
+                    if (total != 0.f) unsafeAtomicAdd(v_rec + 12 * (int64_t)__float_as_int(srec[sp][1].w) + (lane & 15), total);
                 }
             }
         }

@@ -36,7 +36,7 @@ typedef struct ihipStream_t* adk_stream_t; /* == hipStream_t */
 #define ADK_EUNSUPPORTED (-3)
 
 /* ABI version of this header; bumped on any signature change. */
-#define ADK_ABI_VERSION 18
+#define ADK_ABI_VERSION 19
 int adk_abi_version(void);
 
 /* Streaming float4 copy of nbytes (multiple of 16, 16 B aligned pointers); used
@@ -229,6 +229,10 @@ int adk_bin_make_isect_ids(int64_t n_isects, const uint32_t* tile_ids, const int
 /* Replaces rasterize_to_pixels fwd: render_colors [H,W,4], render_alphas [H,W], last_ids [H,W];
  * final_T [H,W] = the exact final transmittance of each pixel, saved for the backward (upstream
  * recovers it as 1 - render_alphas, which loses up to 1e-4 relative where alpha ~ 1);
+ * last_ids [H,W] is the forward -> backward hand-off only (no caller reads it): the list index the backward starts this pixel at -- the
+ * entry in front of the splat the pixel STOPPED at (T (1 - alpha) <= 1e-4), or the tile's last entry if it never stopped (upstream stores
+ * the last CONTRIBUTING entry; every entry between the two fails the same alpha >= 1/255 / sigma >= 0 tests in the backward as it did in the
+ * forward, so the gradients are the same -- ABI v19);
  * backgrounds [4] or NULL; main_ids [H,W] or NULL = id of the Gaussian with the largest alpha*T per
  * pixel, -1 if none (mainGaussID of the on-the-fly-nvs GaussianRasterizer). */
 int adk_raster_fwd(int width, int height, const float* rec, const int32_t* flatten_ids,
