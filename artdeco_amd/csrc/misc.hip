@@ -43,7 +43,7 @@ extern "C" int adk_stream_copy(void* dst, const void* src, int64_t nbytes, hipSt
 // result and info = 1 + the column it failed at instead of an exception: there is no read-back.
 namespace adk {
 __global__ __launch_bounds__(64) void inv4x4_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int64_t sb, int64_t sr,
-                                                    int64_t sc, int32_t* __restrict__ info)
+                                                    int64_t sc, int32_t* __restrict__ info, int32_t* __restrict__ singular_count)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
@@ -81,18 +81,21 @@ __global__ __launch_bounds__(64) void inv4x4_kernel(const float* __restrict__ in
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[16 * i + 4 * r + c] = bad ? nan : (float)a[r][4 + c];
     if (info) info[i] = bad;
+    // the caller's sticky counter may be host-mapped pinned memory (system scope): written only in the singular case, read by the host at its
+    // next wait -- the error surfaces there instead of costing every inversion a read-back
+    if (bad && singular_count) __hip_atomic_fetch_add(singular_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 } // namespace adk
 
 // in: n matrices, element (r, c) of matrix i at in[i * batch_stride + r * row_stride + c * col_stride] (strides in elements); out [n,4,4] contiguous;
-// info [n] or NULL.
+// info [n] or NULL; singular_count (device or host-mapped pinned int32, or NULL) += 1 per singular matrix.
 extern "C" int adk_inv4x4(const float* in, float* out, int64_t n, int64_t batch_stride, int64_t row_stride, int64_t col_stride, int32_t* info,
-                          hipStream_t stream)
+                          int32_t* singular_count, hipStream_t stream)
 {
     if (n < 0) return ADK_EINVAL;
     if (n == 0) return 0;
     if (!in || !out) return ADK_EINVAL;
     hipLaunchKernelGGL(adk::inv4x4_kernel, dim3((unsigned)adk::ceil_div(n, (int64_t)64)), dim3(64), 0, stream, in, out, n, batch_stride, row_stride,
-                       col_stride, info);
+                       col_stride, info, singular_count);
     ADK_RETURN_LAST_ERROR();
 }

@@ -637,6 +637,9 @@ __device__ __forceinline__ void wave_sort_any(const unsigned long long* buf, int
     else wave_sort_tile<16>(buf, abs, n, lane, t, flatten_ids, tile_ids);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx950__) && defined(__AMDGCN_CUMODE__))
+#error "bin_tile_sort_long_kernel hands keys between the waves of a workgroup through global memory under workgroup-scope fences: built and measured for gfx950 in CU mode"
+#endif
 __global__ __launch_bounds__(512) void bin_tile_sort_long_kernel(unsigned long long* pairs, unsigned long long* scratch, const int32_t* __restrict__ offsets,
                                                                  int n_tiles, int64_t n_isects, int32_t* __restrict__ flatten_ids,
                                                                  uint32_t* __restrict__ tile_ids)
@@ -734,6 +737,10 @@ __global__ __launch_bounds__(512) void bin_tile_sort_long_kernel(unsigned long l
         // __syncthreads() carries (the waves of a workgroup share their CU's vector L1, so a line this workgroup rewrote is never stale
         // there).  An agent-scope fence here (`__threadfence()`) writes back and invalidates the XCD's whole L2 on every level of every
         // tile: measured 0.68 ms for the 768 lists of a dense north-star frame against 0.21 without it.
+        // (this does not rest on the CU-mode L1 by accident -- HIP's __syncthreads() IS fence(release, "workgroup") + s_barrier +
+        // fence(acquire, "workgroup"), and the backend legalises workgroup scope per target mode: under -mtgsplit, where a workgroup's waves
+        // may sit on different CUs, it emits the L1 invalidate / write-through that scope then needs.  This library is built for gfx950 in
+        // CU mode only, see the #error below.)
         __syncthreads();
         // -- children: small ones are sorted now (bucket b by wave b mod 8), large ones are pushed (thread 0, in bucket order)
         if (tid == 0) {

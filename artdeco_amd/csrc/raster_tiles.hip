@@ -593,16 +593,13 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
 #endif
         // One staged splat against the quadrants it can reach: the 10 per-lane sums in acc, the splat's 1/opacity in inv_opac; false if
         // no pixel blended it (acc is then undefined and nothing is reduced or parked).
-        // (ADK_BWD_FIRST reads c0..c9 only after the first blending quadrant has written them -- `touched` --, which the compiler cannot see: the
-        // diagnostic is silenced for this lambda alone, not for the file)
+        // -Wsometimes-uninitialized is silenced for this lambda alone (not for the file): see c0..c9 below
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
         auto eval_splat = [&](const int t, float (&acc)[NACC], float& inv_opac) -> bool {
 #if ADK_CLAMP_HOIST_BWD
             const unsigned mc = (unsigned)(clamp_m >> t) & 1u; // wave-uniform: the splat's opacity can reach the 0.999 clamp (almost never)
-#else
-            const unsigned mc = 1u;
 #endif
 #if ADK_CULL_BALLOT_BWD
             const unsigned long long bit = 1ull << t;
@@ -617,9 +614,19 @@ __global__ __launch_bounds__(WG2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
 #if ADK_BWD_FIRST
             // FIRST-TOUCH form (round 4): the first quadrant that blends the splat WRITES its products (acc0..2 are t1, t2, gq themselves,
             // the other seven are plain v_mul), later ones accumulate: no 10 v_mov zero-fill per splat and no v_fmac onto a zero.
-            // scalars, not an array (SROA turns a float[10] into one 10-register tuple and copies it whole), and deliberately left
-            // uninitialised: never read before the first quadrant that blends the splat has written them (`touched`), and an undefined
-            // incoming value is what lets the compiler keep ONE register per sum through the first-touch / accumulate branch
+            // scalars, not an array (SROA turns a float[10] into one 10-register tuple and copies it whole), declared WITHOUT an initialiser.
+            // The accumulate branch reads them only after a first-touch branch has written them (`touched`); the one place an indeterminate
+            // value is ever touched is the copy-out at the end when NO quadrant blended the splat -- a copy whose result the caller discards
+            // (`if (!eval_splat(...)) continue`).  Round 6 tried every defined spelling of "no value yet" and measured the code each gives for
+            // the halves kernel (hipcc 7.2; the default build: 42 v_mov, 72 VGPRs, no scratch):
+            //     = 0.f / any constant                      zero fills + copies at every merge (the form round 4 replaced)
+            //     asm("" : "=v"(c)) empty definition        +40 v_mov
+            //     __builtin_nondeterministic_value(c)       +40 v_mov (a frozen undef is a VALUE: the phi at each merge must copy it)
+            //     copy-out under `if (touched)` / early return   +19 v_mov and 44 B of scratch
+            // The register allocator keeps ONE register per sum through the first-touch / accumulate branch only when the incoming value is
+            // absent, not when it is arbitrary.  So the declaration stays as it was, the diagnostic stays silenced FOR THIS LAMBDA ONLY, and
+            // tests/test_codegen_guard.py pins what the optimiser makes of it (scratch 0, VGPR budget, v_mov count) so that a compiler
+            // update that changes its mind fails a test instead of silently costing a wave per SIMD.
             float c0, c1, c2, c3, c4, c5, c6, c7, c8, c9;
 #else
 #pragma unroll

@@ -1261,10 +1261,13 @@ def patch_scene_model(scene, verify: bool = False) -> bool:
     scene._artdeco_amd_skipped = dict(skip)
     freeze_gc(force=False)   # only with ARTDECO_AMD_GC_FREEZE=1: never a side effect of an import
     step_ok, densify_ok = "step" not in skip, "densify" not in skip
-    # torch.linalg.inv / torch.inverse / Tensor.inverse of 4x4 fp32 CUDA matrices as one launch without the info read-back (run_system.py's
-    # SLAM-keyframe loop inverts three per keyframe): every other argument goes to torch's own functions.  ARTDECO_AMD_FAST_INV4=0 leaves them alone.
-    from . import small_inverse
-    small_inverse.install()
+    # torch.linalg.inv / torch.inverse / Tensor.inverse of 4x4 fp32 CUDA matrices as one launch without the info read-back -- ONLY for calls made
+    # from run_system.py / h3dgsv3.py (the SLAM-keyframe loop inverts three per keyframe); every other caller and argument gets torch's own
+    # functions, and a singular matrix raises at the next step's host wait (small_inverse.check).  Tied to the `pose` pin group like the other
+    # pose hooks; ARTDECO_AMD_FAST_INV4=0 leaves torch alone.
+    if "pose" not in skip:
+        from . import small_inverse
+        small_inverse.install()
     if "pose" not in skip and os.environ.get("ARTDECO_AMD_FUSE_POSE", "1") != "0":
         # Keyframe.get_Rt / set_Rt as one launch each, on the CLASS the scene-model module binds (and its subclasses that override them)
         mod = sys.modules.get(type(scene).__module__)

@@ -27,10 +27,13 @@ def topology_from_env() -> Topology:
                     int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str, device: torch.device | None = None) -> Topology:
-    """Join the job launched by torch.distributed.run (env:// rendezvous on 127.0.0.1)."""
+def init(backend: str, device: torch.device | None = None, force: bool = False) -> Topology:
+    """Join the job launched by torch.distributed.run (env:// rendezvous on 127.0.0.1).  A lone rank needs no process group and gets none,
+    unless `force` (or ARTDECO_AMD_DIST_FORCE=1) asks for one -- which is how the RCCL branch is exercised on a one-GPU box
+    (tests/test_multigpu.py::test_rccl_barrier_and_metric_allreduce_one_rank: backend "nccl" IS RCCL on ROCm)."""
     topo = topology_from_env()
-    if topo.world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("ARTDECO_AMD_DIST_FORCE", "0") == "1"
+    if (topo.world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
@@ -44,7 +47,10 @@ def scene_for_rank(scenes: list, topo: Topology) -> list:
 
 def barrier(device: torch.device | None = None) -> None:
     if dist.is_initialized():
-        dist.barrier()
+        if device is not None and device.type == "cuda" and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device.index if device.index is not None else torch.cuda.current_device()])   # RCCL: name the device, no guess
+        else:
+            dist.barrier()
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
 

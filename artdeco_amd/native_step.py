@@ -22,6 +22,7 @@ import re
 import torch
 
 from . import _lib
+from . import small_inverse as _small_inverse
 from . import rasterizer
 
 _GRAIN = 1 << 20
@@ -374,6 +375,7 @@ def train_on_keyframe(scene, keyframe, is_important):
     plan.route_miss = 0
     STATS["native"] += 1
     STATS["wait_ns"] += int(plan.out.wait_ns)
+    _small_inverse.check()   # behind the call's own host wait: a singular 4x4 met by the wrapped inverse since the last step raises HERE (one pinned read)
     if plan.out.max_tile > 8192:
         STATS["long_list_steps"] += 1      # a tile list above 8 192 entries: sorted by the long-list kernel inside the call (round 5)
     n_isects = int(plan.out.n_isects)

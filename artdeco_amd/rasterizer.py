@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import sys
 import threading
 from dataclasses import dataclass
 
@@ -75,12 +76,12 @@ _NULL = contextlib.nullcontext()
 
 def set_stage_timer(t: StageTimer | None) -> None:
     global _TIMER
-    from . import native_step
-    # the pairs pending on the C side were recorded under the OUTGOING timer: it absorbs them (a later summary_ms() still reports them),
-    # nothing stays behind for the next timer or for nobody (drain_timings() is a no-op while the library has not been loaded)
-    drained = native_step.drain_timings()
     if _TIMER is not None:
-        _TIMER._absorb(drained)
+        # the pairs pending on the C side were recorded under the OUTGOING timer: it absorbs them (a later summary_ms() still reports them),
+        # nothing stays behind for the next timer.  Without an outgoing timer nothing can be pending (pairs are only recorded under one),
+        # and the call must stay free: no import, no header parse, no hipEventSynchronize.
+        from . import native_step
+        _TIMER._absorb(native_step.drain_timings())
     _TIMER = t
 
 
@@ -165,6 +166,13 @@ def _color_adam_for(colors: torch.Tensor, rest: torch.Tensor):
     return st if ok else None
 
 
+def _small_inverse_check():
+    """A singular 4x4 met by artdeco_amd.small_inverse's wrapped torch inverse surfaces at this (already existing) host wait."""
+    si = sys.modules.get("artdeco_amd.small_inverse")
+    if si is not None:
+        si.check()
+
+
 def _count_slot(device: torch.device):
     """Per-thread, per-device pinned int64 + event for the asynchronous read of n_isects."""
     slots = getattr(_TLS, "slots", None)
@@ -220,6 +228,7 @@ def _bin_global(lib, cfg, N, W, H, tile_w, tile_h, rec, depth_keys, gauss_ids, t
                                      ws.data_ptr(), ws.numel(), stream)
     _lib.check(rc, "adk_bin_depth_order")
     count_ready.synchronize()  # the one host wait of the pipeline (sizes the list)
+    _small_inverse_check()
     n_isects = int(host_count[0])
     LAST_STATS.update(N=N, I=n_isects, width=W, height=H, tile_px=(16, 16))   # plain numbers only: no tensor is kept alive from here
 
@@ -269,6 +278,7 @@ def _bin_lists(lib, cfg, tile_px, want_tile_ids, N, W, H, rec, depth_keys, gauss
                                                  W, H, tpw, tph, offsets.data_ptr(), tbase, tbytes, pairs.data_ptr(), stream)
             _lib.check(rc, "adk_bin_local_scatter")
         count_ready.synchronize()  # the one host wait of the pipeline
+        _small_inverse_check()
         n_isects, max_tile = int(host_count[0]), int(host_count[1])
         _CAPACITY_HINT[(dev.index, W, H, tpw)] = n_isects   # keyed on the image only: one entry per resolution however the map grows
         if max_tile > int(lib.adk_bin_local_sort_long_max()) or (max_tile > 8192 and os.environ.get("ADK_BIN_LONG", "1") == "0"):

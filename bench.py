@@ -655,11 +655,16 @@ def extra_configs(args, dev):
             "steps_native": d["native"], "steps_with_a_long_list": d["long_list_steps"], "fallback_route": d["fallback_route"],
             "fallback_layout": d["fallback_layout"]}
         # the way round 4 ran such a frame: the per-stage chain with the global radix route (adk_mapper_step returned ADK_STEP_EROUTE)
+        saved = {k: os.environ.get(k) for k in ("ARTDECO_AMD_NATIVE_STEP", "ADK_BIN_LONG")}   # a user's own setting survives this block
         os.environ["ARTDECO_AMD_NATIVE_STEP"], os.environ["ADK_BIN_LONG"] = "0", "0"
         try:
             res[next(reversed(res))]["ms_per_step_round4_path (per-stage chain, global radix route)"] = _time_steps(scene) * 1e3
         finally:
-            del os.environ["ARTDECO_AMD_NATIVE_STEP"], os.environ["ADK_BIN_LONG"]
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         del scene
         torch.cuda.empty_cache()
     except Exception as e:  # report, never hide

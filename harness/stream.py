@@ -25,6 +25,10 @@ import torch.nn.functional as F
 
 from harness import mapper
 
+# this file's slam_pose_update IS run_system.py:194-227 for the bench: its inversions take the path the script's own would
+from artdeco_amd import small_inverse as _si
+_si.allow_caller(__file__)
+
 
 def warm_libraries(dev):
     """One-off initialisations that are not part of any frame: the first torch.linalg.inv / torch.inverse on a device creates
@@ -117,11 +121,13 @@ def slam_pose_update_batched(scene, delta=1e-4, seed=0):
     scene.rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)
 
 
-@torch.no_grad()
 def slam_pose_update(scene, delta=1e-4, seed=0):
     """run_system.py:194-227: on a SLAM keyframe every mapper keyframe's pose is re-read from the (just optimised) SLAM graph and set,
     and the old / new camera-to-world matrices are collected keyframe by keyframe for rigid_transform_gs.  The new poses here are
-    the old ones moved by a small translation (what one global Gauss-Newton pass typically does to a converged trajectory)."""
+    the old ones moved by a small translation (what one global Gauss-Newton pass typically does to a converged trajectory).
+    Grad mode and detaches AS IN THE SCRIPT (round 6): the loop runs with grad enabled, `old_Rt = frame.get_Rt()` hangs off the
+    pose parameters and is inverted as such (:222), only the view matrix is detached (:221), and the new pose -- which the script takes from
+    the pypose SLAM graph -- carries no graph."""
     dev = scene.device
     K = len(scene.keyframes)
     old_c2ws = torch.zeros(K, 4, 4).to(dev)
@@ -129,16 +135,16 @@ def slam_pose_update(scene, delta=1e-4, seed=0):
     cam_centres = torch.zeros(K, 3).to(dev)
     g = torch.Generator().manual_seed(seed)
     for k, kf in enumerate(scene.keyframes):
-        old_Rt = kf.get_Rt().detach()
-        new_Rt = old_Rt.clone()
+        old_Rt = kf.get_Rt()                                            # :217 (requires grad, like the script's)
+        new_Rt = old_Rt.detach().clone()                                # :216 stands in for T_WCf.Inv().matrix()[0] (no graph)
         new_Rt[:3, 3] += (delta * torch.randn(3, generator=g)).to(dev)
-        kf.set_Rt(new_Rt)
-        view_matrix = kf.get_Rt().detach().transpose(0, 1)
-        centre = view_matrix.inverse()[3, :3]
-        old_c2ws[k] = torch.linalg.inv(old_Rt)
-        new_c2ws[k] = torch.linalg.inv(new_Rt)
-        cam_centres[k] = centre
-    scene.rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)
+        kf.set_Rt(new_Rt.to(old_Rt.device))                             # :219
+        view_matrix = kf.get_Rt().transpose(0, 1).to(dev)               # :220
+        centre = view_matrix.detach().inverse()[3, :3].to(dev)          # :221
+        old_c2ws[k] = torch.linalg.inv(old_Rt).to(dev)                  # :222
+        new_c2ws[k] = torch.linalg.inv(new_Rt).to(dev)                  # :223
+        cam_centres[k] = centre                                         # :224
+    scene.rigid_transform_gs(old_c2ws, new_c2ws, cam_centres)            # :230 (@torch.no_grad() itself, h3dgsv3.py:955)
     # the reference leaves xyz / rotation as plain tensors here (h3dgsv3.py:964-965); they become leaves again at the next
     # add_and_prune.  The fused step reads .requires_grad of its leaves, so nothing else is needed.
 

@@ -441,9 +441,11 @@ int adk_pose6d_set(const float* Rt, float* r6, float* t, float* centre, adk_stre
 /* torch.linalg.inv / torch.inverse / Tensor.inverse of 4x4 fp32 matrices as run_system.py:221-224 calls them (three per mapper keyframe on a
  * SLAM keyframe; h3dgsv3.py:1000 once per add_keyframe): n matrices, element (r, c) of matrix i at in[i * batch_stride + r * row_stride +
  * c * col_stride] (element strides: the script inverts a transposed view), out [n,4,4] contiguous.  Gauss-Jordan, partial pivoting, fp64 inside.
- * No read-back: a singular matrix gives a NaN-filled result and info[i] = 1 + the failing column (info [n] or NULL), not an exception. */
+ * No read-back: a singular matrix gives a NaN-filled result, info[i] = 1 + the failing column (info [n] or NULL) and -- ABI v19 --
+ * *singular_count += 1 (system-scope atomic: the counter may be host-mapped pinned memory, so that the host learns of it at its next wait
+ * without this call ever synchronising; NULL = not counted), not an exception. */
 int adk_inv4x4(const float* in, float* out, int64_t n, int64_t batch_stride, int64_t row_stride, int64_t col_stride, int32_t* info,
-               adk_stream_t stream);
+               int32_t* singular_count, adk_stream_t stream);
 
 /* Visibility masks of SceneModel.render (h3dgsv3.py:695-698): vis[g] = radii[g] > 0 (both axes);
  * gvis[cls_id[g]] = 1 for every visible g (gvis [V] bytes, cleared here; may be NULL). */

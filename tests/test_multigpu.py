@@ -97,3 +97,25 @@ def test_bench_entry_runs_two_ranks_on_one_gpu():
     assert abs(out["value"] - 2.0 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
     assert out["config"]["optimisation_steps"] >= 2 * 3 * 10          # SUM over ranks of >= 10 optimisation steps per frame
     assert out["roofline"]["avg_launch_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_barrier_and_metric_allreduce_one_rank():
+    """The RCCL branch itself (round 6): `multigpu.init("nccl", device, force=True)` under torch.distributed.run with ONE rank on the one GPU
+    (RCCL refuses two ranks on one device, so this is as far as a one-GPU box goes): process group bound to the device, barrier, the MAX / SUM
+    all-reduce of the metrics on device tensors, shutdown."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "tests", "host", "rccl_one_rank.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["backend"] == "nccl" and out["world"] == 1 and out["allreduce_ok"]
+    assert out["elapsed"] == 2.5 and out["sums"] == {"frames": 20.0, "steps": 270.0}

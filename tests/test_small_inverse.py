@@ -4,7 +4,9 @@
 The checker is the inverse itself in float64 (numpy.linalg.inv, LAPACK dgesv): an fp32 inverse computed by ANY backward-stable method
 differs from it by about cond(A) * 2^-24 relative to |A^-1|, so the bar is  |X - inv64(A)| <= 8 * cond(A) * eps32 * max|inv64(A)|
 per matrix -- and, measured beside it, torch's own fp32 LU on the same device must not be closer by more than that bound either.
-Everything that is not a plain CUDA fp32 [..., 4, 4] outside autograd must still reach torch's own functions."""
+Everything that is not a plain CUDA fp32 [..., 4, 4] must still reach torch's own functions -- and (round 6) so must every CALLER that is not
+one of ARTDECO's own two pose-inverting files; an argument inside autograd takes the same launch with the analytic backward; a singular matrix
+raises at the next host wait (`check()`), late but not never."""
 import os
 import sys
 
@@ -40,9 +42,10 @@ def _bound(A64):
 @pytest.fixture
 def patched():
     from artdeco_amd import small_inverse
-    was = small_inverse.installed()
-    small_inverse.install(force=True)
+    was, any_was = small_inverse.installed(), small_inverse._ANY_CALLER
+    small_inverse.install(force=True, any_caller=True)      # these tests call from THIS file: lift the caller restriction for them
     yield small_inverse
+    small_inverse.install(any_caller=any_was)
     if not was:
         small_inverse.uninstall()
 
@@ -65,6 +68,29 @@ def test_everything_but_cuda_fp32_4x4_reaches_torch(patched):
     with pytest.raises(torch.linalg.LinAlgError):
         torch.linalg.inv(torch.zeros(4, 4))                 # a CPU singular matrix still raises: torch's function
     assert patched.STATS["fast"] == before["fast"] and patched.STATS["torch"] > before["torch"]
+
+
+def test_only_artdecos_own_files_take_the_fast_path():
+    """The wrapped entry points look at the CALLING frame's file: run_system.py / h3dgsv3.py (and what allow_caller registered), nobody else."""
+    from artdeco_amd import small_inverse as si
+    src = "def call(si):\n    def wrapper():\n        return si._caller_ok()\n    return wrapper()\n"
+    any_was = si._ANY_CALLER
+    si._ANY_CALLER = False
+    try:
+        verdicts = {}
+        for fn in ("/somewhere/ARTDECO/run_system.py", "/x/Reconstruct/scene/scene_models/h3dgsv3.py", "/site-packages/pypose/lietensor/operation.py",
+                   "/x/webviewer/scene_models.py", __file__):
+            ns = {}
+            exec(compile(src, fn, "exec"), ns)
+            verdicts[os.path.basename(fn)] = ns["call"](si)
+        assert verdicts == {"run_system.py": True, "h3dgsv3.py": True, "operation.py": False, "scene_models.py": False,
+                            os.path.basename(__file__): False}
+        si._ANY_CALLER = True
+        ns = {}
+        exec(compile(src, "/anything.py", "exec"), ns)
+        assert ns["call"](si) is True
+    finally:
+        si._ANY_CALLER = any_was
 
 
 def test_install_is_idempotent_and_reversible():
@@ -134,22 +160,54 @@ def test_singular_matrices_give_nan_not_an_exception_and_no_synchronisation(patc
     got = patched.inv4x4(A, info)
     assert info.tolist() == [0, 0, 1, 0, 2, 0]
     assert torch.isnan(got[2]).all() and torch.isnan(got[4]).all() and torch.isfinite(got[[0, 1, 3, 5]]).all()
-    assert torch.isnan(torch.linalg.inv(A)[2]).all()                       # the wrapped entry point: NaN, where torch raises
+    torch.cuda.synchronize()
+    assert patched.singular_seen() >= 2
+    with pytest.raises(torch.linalg.LinAlgError, match="singular 4x4"):    # ... and the host hears of it at its next wait
+        patched.check()
+    patched.check()                                                        # reported once
+    assert torch.isnan(torch.linalg.inv(A)[2]).all()                       # the wrapped entry point: NaN at the call, where torch raises
+    torch.cuda.synchronize()
+    with pytest.raises(torch.linalg.LinAlgError):
+        patched.check()
     with pytest.raises(torch.linalg.LinAlgError):
         patched._ORIG["linalg.inv"](A)
 
 
 @pytest.mark.gpu
-def test_autograd_and_subclasses_stay_with_torch_on_the_device(patched):
+def test_autograd_takes_the_same_launch_and_other_dtypes_stay_with_torch(patched):
+    """run_system.py:222 inverts `frame.get_Rt()` with grad enabled: one launch + the analytic backward -A^-T G A^-T, equal to torch's."""
     dev = torch.device("cuda:0")
     A = _rigid(3, 2).to(dev).requires_grad_(True)
+    w = torch.randn(3, 4, 4, generator=torch.Generator().manual_seed(5)).to(dev)
     before = dict(patched.STATS)
-    torch.linalg.inv(A).sum().backward()
-    assert A.grad is not None and patched.STATS["fast"] == before["fast"]
+    (torch.linalg.inv(A) * w).sum().backward()
+    assert patched.STATS["fast_grad"] == before["fast_grad"] + 1 and patched.STATS["torch"] == before["torch"]
+    B = A.detach().clone().requires_grad_(True)
+    (patched._ORIG["linalg.inv"](B) * w).sum().backward()
+    assert torch.allclose(A.grad, B.grad, rtol=1e-4, atol=1e-5 * float(B.grad.abs().max()))
     with torch.no_grad():
-        torch.linalg.inv(A)                                                  # outside autograd the same tensor takes the kernel
+        torch.linalg.inv(A)                                                  # outside autograd the same tensor takes the plain launch
     assert patched.STATS["fast"] == before["fast"] + 1
     assert torch.linalg.inv(A.detach().double()).dtype == torch.float64 and patched.STATS["fast"] == before["fast"] + 1
+
+
+@pytest.mark.gpu
+def test_a_foreign_caller_keeps_torchs_inverse_on_the_device():
+    from artdeco_amd import small_inverse as si
+    dev = torch.device("cuda:0")
+    was, any_was = si.installed(), si._ANY_CALLER
+    si.install(force=True, any_caller=False)
+    try:
+        before = dict(si.STATS)
+        A = _rigid(2, 8).to(dev)
+        torch.linalg.inv(A); A.inverse(); torch.inverse(A)                   # this file is not run_system.py
+        assert si.STATS["foreign_caller"] == before["foreign_caller"] + 3 and si.STATS["fast"] == before["fast"]
+        with pytest.raises(torch.linalg.LinAlgError):
+            torch.linalg.inv(torch.zeros(4, 4, device=dev))                  # ... error behaviour included
+    finally:
+        si.install(any_caller=any_was)
+        if not was:
+            si.uninstall()
 
 
 @pytest.mark.gpu
