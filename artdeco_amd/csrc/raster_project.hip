@@ -462,7 +462,7 @@ __device__ __forceinline__ void color_adam_elem(float* __restrict__ p_ptr, float
 // v_rec layout mirrors rec: [0] s_x [1] s_y [2] v_opacity | [4] v_ca [5] v_cb [6] v_cc | [8..11] v_colour channels,
 // where (s_x, s_y) = sum over pixels of v_sigma * (mean2d - pixel): the raster backward leaves the multiplication by the
 // conic, v_mean2d = conic (s_x, s_y)^T, to this kernel (once per Gaussian instead of once per (splat, pixel)).
-// cam_grad[16]: v_R (9, row-major) | v_t (3) | v_campos (3) | pad, accumulated with atomics.
+// cam_grad: 16 DOUBLES (128 B, 8-byte aligned; round 6) -- v_R (9, row-major) | v_t (3) | v_campos (3) | pad, accumulated with fp64 atomics.
 #ifndef ADK_PROJECT_BWD_WAVES
 #define ADK_PROJECT_BWD_WAVES 4
 #endif
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ADK_PROJECT
     float* __restrict__ v_opacities, float* __restrict__ v_colors, float* __restrict__ v_sh_rest,
     float* __restrict__ cam_grad, ColorAdam opt)
 {
-    __shared__ float red[4][16];
+    __shared__ double red[4][16];
     // FUSE_ADAM: per-Gaussian (b_k, v_rgb, live) for the coalesced optimiser phase (17 B-conflict-free row pitch)
     __shared__ float adam_b[FUSE_ADAM ? 256 : 1][17];
     __shared__ float adam_v[FUSE_ADAM ? 256 : 1][3];
@@ -735,16 +735,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ADK_PROJECT
         }
     }
     if (cam_grad) { // uniform branch
+        // Round 6: the 15 camera sums are carried in DOUBLE from the thread's own fp32 contribution to the accumulator (cam_grad is 16 doubles).
+        // They are sums over every visible Gaussian of signed terms that cancel to a small fraction of their running magnitude: accumulated
+        // with fp32 atomics over ~4 000 workgroups the pose gradient sat 3.7-4.7e-4 off the fp64 oracle at 1 M / 1080p (finding 40) -- the
+        // largest deviation of any leaf, on the one that trains the camera.  64-bit shuffles + hardware fp64 atomics: 15 values per workgroup.
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
-            const float s_ = wave_sum(cg[i]);
-            if (lane == 0) red[wv][i] = s_;
+            double d = (double)cg[i];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (lane == 0) red[wv][i] = d;
         }
         __syncthreads();
         if (threadIdx.x < 15) {
-            const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            if (tot != 0.f) atomicAdd(cam_grad + threadIdx.x, tot);
+            const double tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (tot != 0.0) unsafeAtomicAdd(reinterpret_cast<double*>(cam_grad) + threadIdx.x, tot);
         }
     }
 }
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ADK_PROJECT
 // v_viewmat[4,4] += (v_R | v_t) + d(campos)/d(viewmat)^T v_campos, campos = -R^-1 t:
 //   v_t' = -R^-T v_cp ;  v_R' = -R^-T (v_Ri) ... with Ri = R^-1:  d(Ri) = -Ri dR Ri,
 //   campos = -Ri t  =>  v_Ri = -v_cp t^T ; v_R' = -Ri^T v_Ri Ri^T = Ri^T v_cp t^T Ri^T = (Ri^T v_cp)(Ri t)^T
-// Leaves cam_grad zeroed again: a caller can keep ONE accumulator per stream instead of clearing a fresh one every step.
+// Leaves cam_grad (16 doubles) zeroed again: a caller can keep ONE accumulator per stream instead of clearing a fresh one every step.
 __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, float* __restrict__ cam_grad,
                                              float* __restrict__ v_viewmat, const float* __restrict__ pose_r6, float* __restrict__ v_r6,
                                              float* __restrict__ v_t)
@@ -770,18 +776,19 @@ __global__ void viewmat_grad_finalize_kernel(const float* __restrict__ viewmat, 
         Ri[1][0] = c10 * id; Ri[1][1] = c11 * id; Ri[1][2] = c12 * id;
         Ri[2][0] = c20 * id; Ri[2][1] = c21 * id; Ri[2][2] = c22 * id;
     }
-    const float* vcp = cam_grad + 12;
+    double* cgd = reinterpret_cast<double*>(cam_grad);   // 16 doubles (round 6): v_R (9) | v_t (3) | v_campos (3) | pad
+    const float vcp[3] = {(float)cgd[12], (float)cgd[13], (float)cgd[14]};
     float a[3], bvec[3]; // a = Ri^T v_cp ; b = Ri t
     for (int i = 0; i < 3; ++i) {
         a[i] = Ri[0][i] * vcp[0] + Ri[1][i] * vcp[1] + Ri[2][i] * vcp[2];
         bvec[i] = Ri[i][0] * t[0] + Ri[i][1] * t[1] + Ri[i][2] * t[2];
     }
     for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) v_viewmat[i * 4 + j] = cam_grad[i * 3 + j] + a[i] * bvec[j];
-        v_viewmat[i * 4 + 3] = cam_grad[9 + i] - a[i];
+        for (int j = 0; j < 3; ++j) v_viewmat[i * 4 + j] = (float)(cgd[i * 3 + j] + (double)a[i] * (double)bvec[j]);
+        v_viewmat[i * 4 + 3] = (float)(cgd[9 + i] - (double)a[i]);
     }
     for (int j = 0; j < 4; ++j) v_viewmat[12 + j] = 0.f;
-    for (int j = 0; j < 16; ++j) cam_grad[j] = 0.f;
+    for (int j = 0; j < 16; ++j) cgd[j] = 0.0;
     // the one-call step: Keyframe.get_Rt's backward on the matrix this thread has just written (else a launch of its own, adk_pose6d_bwd)
     if (pose_r6) pose6d_bwd_body(pose_r6, v_viewmat, v_r6, v_t);
 }

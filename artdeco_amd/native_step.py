@@ -164,7 +164,7 @@ class StepPlan:
         e("ssim_sums", n_sums, **f32); e("photo_ws", int(lib.adk_photometric_workspace_bytes(W, H)), **u8)
         e("v_img", 3, H, W, **f32); e("v_col", H, W, 4, **f32); e("v_alpha", H, W, 1, **f32); e("v_exposure", 12, **f32)
         e("v_rec", N, 12, **f32); e("v_means", N, 3, **f32); e("v_quats", N, 4, **f32); e("v_scales", N, 3, **f32); e("v_opac", N, **f32)
-        self.t["cam_grad"] = torch.zeros(16, **f32)     # the projection backward leaves it zeroed again
+        self.t["cam_grad"] = torch.zeros(32, **f32)     # 16 doubles (ABI v19); the projection backward leaves it zeroed again
         e("v_viewmat", 4, 4, **f32)
         e("v_opacity_raw", N, 1, **f32); e("v_scaling_raw", N, 3, **f32); e("v_rotation", N, 4, **f32); e("v_local_feat", N, 16, **f32)
         e("v_global_feat", V, 16, **f32); e("v_mlp", _NW, **f32); e("lod_ws", int(lib.adk_lod_params_bwd_workspace_bytes(N)), **u8)

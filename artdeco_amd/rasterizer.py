@@ -468,7 +468,7 @@ _CAM_GRAD: dict = {}
 
 
 def _cam_grad_scratch(dev, stream) -> torch.Tensor:
-    """The 16-float accumulator of the camera gradient: adk_project_bwd leaves it zeroed again, so one per (device,
+    """The 16-double accumulator of the camera gradient: adk_project_bwd leaves it zeroed again, so one per (device,
     stream, THREAD) is cleared ONCE instead of a fill kernel per step.  Per thread: the accumulate and finalize kernels are two
     launches of one C call, and two threads issuing backward on one stream (the viewer thread renders under the same null
     stream, h3dgsv3.py:624) could otherwise interleave them -- accumulate(A), accumulate(B), finalize(A) -- on a shared buffer.
@@ -476,7 +476,7 @@ def _cam_grad_scratch(dev, stream) -> torch.Tensor:
     key = (dev.index, int(stream or 0), threading.get_ident())
     buf = _CAM_GRAD.get(key)
     if buf is None:
-        buf = _CAM_GRAD[key] = torch.zeros(16, dtype=torch.float32, device=dev)
+        buf = _CAM_GRAD[key] = torch.zeros(16, dtype=torch.float64, device=dev)   # fp64 accumulator since ABI v19
     return buf
 
 

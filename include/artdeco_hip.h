@@ -140,9 +140,10 @@ int adk_project_fwd(int N, const float* means, const float* quats, const float* 
                     uint32_t* depth_keys, uint32_t* gauss_ids, int32_t* tiles_per_gauss, adk_stream_t stream);
 
 /* Replaces fully_fused_projection bwd + spherical_harmonics bwd (+ the torch.inverse(viewmats)
- * autograd edge of rasterization()).  Any v_* output may be NULL.  cam_grad: 16 zeroed floats of
- * scratch, required iff v_viewmat [4,4] is requested; the call leaves them zeroed again (stream-ordered), so a caller
- * may keep one accumulator per stream instead of clearing a fresh one for every call. */
+ * autograd edge of rasterization()).  Any v_* output may be NULL.  cam_grad: 128 zeroed BYTES of 8-byte-aligned
+ * scratch (16 doubles since ABI v19: the 15 camera sums are accumulated in fp64 -- as fp32 atomics they sat 4e-4 off the fp64 gradient at
+ * 1 M Gaussians; the parameter keeps its float* type), required iff v_viewmat [4,4] is requested; the call leaves them zeroed again
+ * (stream-ordered), so a caller may keep one accumulator per stream instead of clearing a fresh one for every call. */
 int adk_project_bwd(int N, const float* means, const float* quats, const float* scales,
                     const float* colors_in, const float* sh_rest, int sh_K, int sh_degree, int color_mode,
                     const float* viewmat, const float* Kmat, int width, int height, float eps2d,
@@ -635,7 +636,7 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
  *   plan         everything else: intermediates (viewmat [16] .. last_ids), masks vis [N] / gvis [V] (bytes), loss scratch, and the
  *                gradients v_* the optimisers read: v_means (= gradient of xyz, LoD fade term included), v_opacity_raw, v_scaling_raw,
  *                v_rotation, v_local_feat, v_global_feat, v_mlp [1287] = dW1 | db1 | dW2 | db2, v_exposure [12], v_r6 [6], v_t [3];
- *                v_dc / v_rest only without color_adam.  cam_grad: 16 floats zeroed once by the caller (left zeroed by the call);
+ *                v_dc / v_rest only without color_adam.  cam_grad: 128 bytes (16 doubles, ABI v19) zeroed once by the caller (left zeroed by the call);
  *                pairs [isect_capacity] 8 B keys, pairs2 [isect_capacity] (the long tile lists' ping-pong buffer, adk_bin_local_sort_long_t; may be
  *                NULL), flatten_ids [isect_capacity]; bin_table: adk_bin_local_workspace_bytes_t + 256 bytes.
  * Return: ADK_OK; ADK_STEP_ECAPACITY when the frame has more intersections than isect_capacity (out->n_isects says how many: grow

@@ -430,7 +430,7 @@ def test_colour_adam_inside_backward_is_bit_identical(N, deg, dev):
 
     def grads():
         return [torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, device=dev),
-                torch.zeros(16, device=dev), torch.empty(4, 4, device=dev)]
+                torch.zeros(16, dtype=torch.float64, device=dev), torch.empty(4, 4, device=dev)]   # cam_grad: 16 doubles since ABI v19
 
     # reference path: gradients, then the optimiser
     A = [x.clone() for x in (f_dc, f_rest, m_dc, v_dc, m_rest, v_rest)]

@@ -5,8 +5,9 @@ tile offsets.  fp32 tolerance (north star: 1e-4 relative): rendered RGB+D / alph
 per-attribute gradient, with the gradient reference obtained by fp64 autograd over the oracle.
 The rasteriser has four discontinuities per (splat, pixel): alpha vs 1/255 (skip), alpha vs 0.999 (clamp),
 sigma vs 0, T(1-alpha) vs 1e-4 (terminate).  An fp32 and an fp64 evaluation may decide a pixel sitting on one of them
-differently, so the gradient tests IDENTIFY those pixels (oracle `extras["knife"]`, relative margin 5e-4, a few percent of the
-pixels) and take them out of the loss on both sides; on everything else the north-star criterion is asserted as is:
+differently, so the gradient tests IDENTIFY those pixels (oracle `extras["knife"]`, relative margin 5e-4: MEASURED 0.7 - 3.0 % of the
+pixels over every scene and window used here, and each test asserts its own measured fraction + 2 points, not a blanket allowance) and
+take them out of the loss on both sides; on everything else the north-star criterion is asserted as is:
 rel_l2 <= 1e-4 per attribute and max |error| <= 1e-4 max |gradient|, no outlier allowance.
 """
 import numpy as np
@@ -130,7 +131,7 @@ def test_forward_render_matches_oracle(N, W, H, seed, sh_degree, mode, dev):
     r, a = r[0].cpu(), a[0].cpu()
     assert r.shape == ro.shape and a.shape == ao.shape
     keep = (~ex["knife"])[..., None]   # every pixel that is not ON a skip / clamp / terminate threshold: 1e-4, no allowance
-    assert float(keep.float().mean()) > 0.9
+    assert float(keep.float().mean()) > 0.96   # measured knife fraction of these five scenes: 0.8 - 1.9 % (round 6) + 2 points
     assert float(((r - ro).abs() * keep).max()) <= 1e-4 * float(ro.abs().max())
     assert float(((a - ao).abs() * keep).max()) <= 1e-4
     # knife-edge pixels: a flipped decision moves the pixel by at most one splat's contribution
@@ -173,7 +174,7 @@ def test_backward_matches_fp64_autograd_oracle(N, W, H, seed, dev):
     ro, ao, _ = go.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["colors"],
                                  leaves["viewmat"], sc["K"], W, H, eps2d=0.01, grad_dtype=torch.float64, extras=ex)
     keep = (~ex["knife"])[..., None]
-    assert float(keep.double().mean()) > 0.8
+    assert float(keep.double().mean()) > 0.96    # measured knife fraction: 0.7 / 0.8 / 1.9 % (round 6) + 2 points
     v_r, v_a = v_r * keep, v_a * keep          # knife-edge pixels leave the loss on both sides
     ((ro * v_r.double()).sum() + (ao * v_a.double()).sum()).backward()
     # HIP
@@ -189,7 +190,7 @@ def test_backward_matches_fp64_autograd_oracle(N, W, H, seed, dev):
 
 @pytest.mark.gpu
 def test_camera_gradient_accumulator_is_left_zeroed(dev):
-    """adk_project_bwd hands its 16-float cam_grad scratch back zeroed (include/artdeco_hip.h), which is what lets the
+    """adk_project_bwd hands its 16-double cam_grad scratch back zeroed (include/artdeco_hip.h), which is what lets the
     binding keep one per stream: two backward passes in a row give the same view-matrix gradient (up to the order of the
     atomics), not the sum of both, and the cached accumulators read zero afterwards."""
     from artdeco_amd import rasterizer
@@ -403,7 +404,7 @@ def test_render_and_backward_at_baseline_sizes(N, W, H, window, tilt, dev):
     g = torch.Generator().manual_seed(5)
     keep = torch.zeros(H, W, 1, dtype=torch.bool)
     keep[ys, xs] = ~o["extras"]["knife"][ys, xs, None]
-    assert float(keep[ys, xs].double().mean()) > 0.7
+    assert float(keep[ys, xs].double().mean()) > 0.95   # measured knife fraction of the five windows: 1.7 - 2.7 % (round 6) + 2 points
     v_r = torch.randn(H, W, 4, generator=g) * keep
     v_a = torch.randn(H, W, 1, generator=g) * keep
     ((o["render"] * v_r.double()).sum() + (o["alphas"] * v_a.double()).sum()).backward()
@@ -458,7 +459,7 @@ def test_render_and_backward_at_northstar_sizes_in_every_wave_form(N, W, H, wind
     each other: forward on every non-knife pixel of the window and every per-attribute gradient at the north-star 1e-4.
     Reference: gsplat rasterize_to_pixels fwd/bwd reached from h3dgsv3.py:664-680; run.sh:15 (--downsampling 2.0)."""
     sc, o, v_r, v_a, keep, keep_frac = _window_oracle(N, W, H, window, tilt)
-    assert len(o["ids"]) > 500 and keep_frac > 0.7
+    assert len(o["ids"]) > 500 and keep_frac > 0.95    # measured knife fraction of the four windows: 2.1 - 3.0 % (round 6) + 2 points
     monkeypatch.setenv("ADK_RASTER_SPLIT_FWD", form)
     monkeypatch.setenv("ADK_RASTER_SPLIT_BWD", form)
     r, a, meta, hl = _run_hip(sc, dev, requires_grad=True)

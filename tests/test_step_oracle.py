@@ -185,7 +185,7 @@ def _default_path_step(sc, kid, important, seed):
     return got
 
 
-def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeypatch, max_mask_flips=4, **tols):
+def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeypatch, max_mask_flips=4, settle=True, **tols):
     from artdeco_amd import fused
     from harness import mapper
     from oracle import step_oracle as SO
@@ -199,14 +199,17 @@ def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeyp
     state, kfd, cfg = SO.snapshot(sc, kid)
     t0 = time.time()
     settle_log = []
-    state, rounds, left = SO.settle_scene(state, kfd, cfg, log=settle_log)     # the scene off the rasteriser's skip edges: opacities of ~1 % of the Gaussians move by 2e-3
-    with torch.no_grad():
-        sc.gaussian_params["opacity"]["val"].copy_(state["opacity"].to(dev))
-        sc.gaussian_params["local_feat"]["val"].copy_(state["local_feat"].to(dev))
-    print(f"[step-oracle {N}/{W}x{H}] settle_scene {time.time() - t0:.1f} s: (round, Gaussians on a skip edge, pairs, pixels, Gaussians on a ReLU edge) {settle_log}")
-    # what opacity cannot move: a pixel centre within ~3e-3 px of a splat's centre (|sigma| <= 1e-6, the band of the `sigma < 0` skip): ~2.5e-5 of
-    # the visible Gaussians have one; the Gaussians blended on those pixels leave the max-error criterion (knife_rows), nothing else
-    assert left <= 16 + 5e-5 * N, (left, settle_log)
+    if settle:
+        state, rounds, left = SO.settle_scene(state, kfd, cfg, log=settle_log)     # the scene off the rasteriser's skip edges: opacities of ~1 % of the Gaussians move by 2e-3
+        with torch.no_grad():
+            sc.gaussian_params["opacity"]["val"].copy_(state["opacity"].to(dev))
+            sc.gaussian_params["local_feat"]["val"].copy_(state["local_feat"].to(dev))
+        print(f"[step-oracle {N}/{W}x{H}] settle_scene {time.time() - t0:.1f} s: (round, Gaussians on a skip edge, pairs, pixels, Gaussians on a ReLU edge) {settle_log}")
+        # what opacity cannot move: a pixel centre within ~3e-3 px of a splat's centre (|sigma| <= 1e-6, the band of the `sigma < 0` skip): ~2.5e-5 of
+        # the visible Gaussians have one; the Gaussians blended on those pixels leave the max-error criterion (knife_rows), nothing else
+        assert left <= 16 + 5e-5 * N, (left, settle_log)
+    else:
+        print(f"[step-oracle {N}/{W}x{H}] scene AS BUILT (no settle_scene): threshold-adjacent (splat, pixel) pairs stay in")
     torch.manual_seed(seed)
     bg = torch.rand(3, device=dev).cpu()              # what the step draws after the same seeding (h3dgsv3.py:421)
     rdk = SO.radial_decay_kernel(H, W, cfg["rad_decay"]).double()
@@ -251,13 +254,31 @@ def _hold_default_path_to_the_oracle(dev, N, W, H, important, lod, seed, monkeyp
 @pytest.mark.gpu
 def test_default_step_matches_the_fp64_oracle_at_1M_1080p(dev, monkeypatch):
     # max error: the fp32 floor of THIS frame is 8.47e-5 on xyz (profiles/r05_fp32_floor_1M_1080p.txt; the HIP path: 8.5e-5) -- too close to 1e-4 to
-    # assert 1e-4 on a quantity that is a single worst element; rel_l2 stays at 1e-4 (measured <= 3.3e-5)
-    _hold_default_path_to_the_oracle(dev, 1_000_000, 1920, 1080, True, False, 11, monkeypatch, tol_pose=1e-3, tol_max=2e-4)
+    # assert 1e-4 on a quantity that is a single worst element; rel_l2 stays at 1e-4 (measured <= 3.3e-5).
+    # Pose (round 6): the camera sums are now carried in fp64 from each Gaussian's fp32 term to the accumulator (project_bwd: 64-bit shuffles +
+    # fp64 atomics) -- and the deviation did NOT move: 3.7e-4 / 4.7e-4 before and after (profiles/r06_step_oracle_pose_fp64_accumulator.log).
+    # It is not the reduction: each of the 925 k terms carries the rasteriser backward's own ~5e-6 fp32 error, and their sum cancels to ~12
+    # terms' worth on this centred view -- the same figure the oracle's own chain gives in torch fp32.  Held to the measured floor + 25 %,
+    # not to the 1e-3 of round 5.
+    _hold_default_path_to_the_oracle(dev, 1_000_000, 1920, 1080, True, False, 11, monkeypatch, tol_pose=6e-4, tol_max=2e-4)
 
 
 @pytest.mark.gpu
 def test_default_step_matches_the_fp64_oracle_at_the_northstar_size(dev, monkeypatch):
     _hold_default_path_to_the_oracle(dev, 1_000_000, 512, 384, True, False, 12, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_default_step_on_the_unsettled_scene_at_the_northstar_size(dev, monkeypatch):
+    """The same step on the scene AS BUILT (round 6): no opacity is nudged off the alpha = 1/255 edge and no feature off a ReLU
+    switch, so ~670 (splat, pixel) pairs within 1e-4 of a skip threshold -- and ~3 600 Gaussians with a hidden unit within 1e-3 of its switch --
+    stay in.  The oracle decides every pixel on the SAME fp32 values the kernels decide on, so all but the few pairs within ~1e-6 of an edge
+    agree; the Gaussians blended on a pixel that holds such a pair are the ORACLE's `knife_rows` (a few percent here: each near-threshold pixel
+    has ~50 contributors) and leave the max-error criterion of the per-Gaussian leaves only.  Everything else is held as in the settled test:
+    rel_l2 over ALL rows of every leaf, the summed leaves (mlp_cov, exposure, pose) included, and the max error on the non-knife rows."""
+    _hold_default_path_to_the_oracle(dev, 1_000_000, 512, 384, True, False, 12, monkeypatch, settle=False, max_knife_rows=0.03)   # measured 1.05 % + 2 points
+    # measured (profiles/r06_step_oracle_unsettled.log): rel_l2 <= 2.2e-5 on every leaf, max error on the non-knife rows <= 7.4e-5, over ALL
+    # rows 1.2e-4 (xyz: one row under a flipped pair) -- the settled scene's figures (8e-6 / 1.7e-5) were not an artefact of settling
 
 
 @pytest.mark.gpu
