@@ -176,8 +176,8 @@ struct KBest {
 };
 
 template <int K>
-__device__ __forceinline__ void scan_box(const float4* __restrict__ spts, int M, int box, float x, float y, float z,
-                                         uint32_t self_id, KBest<K>& kb)
+__device__ __forceinline__ int scan_box(const float4* __restrict__ spts, int M, int box, float x, float y, float z,
+                                        uint32_t self_id, KBest<K>& kb)
 {
     const int i0 = box * KNN_BOX;
     const int i1 = min(M, i0 + KNN_BOX);
@@ -188,20 +188,24 @@ __device__ __forceinline__ void scan_box(const float4* __restrict__ spts, int M,
         const float dx = c.x - x, dy = c.y - y, dz = c.z - z;
         kb.offer(dx * dx + dy * dy + dz * dz, (int)cid);
     }
+    return i1 - i0; // points visited (the measurement variant counts them)
 }
 
 // MODE 0: queries are the structure's own points, query q = Morton position q (home box known).
 // MODE 1: queries are arbitrary points (q_sel indices into pts); home box by binary search of the code.
 // OUT 0: write K (dist, index) pairs at out row; OUT 1: write mean of the K(=3) distances.
-template <int K, int MODE, int OUT>
+// COUNT (measurement only, adk_knn_index2_stats): stats[0] += boxes scanned, [1] += points visited, [2] += super-box tests, [3] += box tests --
+// "runtime is search-bound, so also report points-visited/query".  The product entry points instantiate COUNT = false.
+template <int K, int MODE, int OUT, bool COUNT = false>
 __global__ __launch_bounds__(256) void knn_query_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ q_sel, int Q, const float4* __restrict__ spts, int M,
     const uint32_t* __restrict__ sorted_codes, const Aabb* __restrict__ boxes, int n_boxes,
     const Aabb* __restrict__ supers, int n_supers, const float* __restrict__ bbox, float* __restrict__ out_d,
-    int32_t* __restrict__ out_i)
+    int32_t* __restrict__ out_i, unsigned long long* __restrict__ stats = nullptr)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
+    unsigned n_scanned = 0, n_points = 0, n_super_tests = 0, n_box_tests = 0;
     float x, y, z;
     uint32_t self_id;
     int home, out_row;
@@ -221,18 +225,21 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     }
     KBest<K> kb;
     kb.init();
-    scan_box<K>(spts, M, home, x, y, z, self_id, kb);
+    { const int v = scan_box<K>(spts, M, home, x, y, z, self_id, kb); if (COUNT) { n_scanned += 1; n_points += v; } }
     const int home_super = home / KNN_SUPER;
     // own super-box first (tight reject early), then the rest
     for (int pass = 0; pass < 2; ++pass) {
         for (int s = 0; s < n_supers; ++s) {
             if ((pass == 0) != (s == home_super)) continue;
+            if (COUNT) n_super_tests += 1;
             if (!(dist_box_point(supers[s], x, y, z) < kb.reject())) continue;
             const int b0 = s * KNN_SUPER, b1 = min(n_boxes, b0 + KNN_SUPER);
             for (int b = b0; b < b1; ++b) {
                 if (b == home) continue;
+                if (COUNT) n_box_tests += 1;
                 if (!(dist_box_point(boxes[b], x, y, z) < kb.reject())) continue;
-                scan_box<K>(spts, M, b, x, y, z, self_id, kb);
+                const int v = scan_box<K>(spts, M, b, x, y, z, self_id, kb);
+                if (COUNT) { n_scanned += 1; n_points += v; }
             }
         }
     }
@@ -244,6 +251,10 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
 #pragma unroll
         for (int j = 0; j < K; ++j) s += kb.d[j];
         out_d[out_row] = s / 3.0f; // boxMeanDist, simple_knn.cu:185
+    }
+    if (COUNT && stats) {
+        atomicAdd(stats + 0, (unsigned long long)n_scanned); atomicAdd(stats + 1, (unsigned long long)n_points);
+        atomicAdd(stats + 2, (unsigned long long)n_super_tests); atomicAdd(stats + 3, (unsigned long long)n_box_tests);
     }
 }
 
@@ -333,6 +344,22 @@ extern "C" int adk_knn_index2(const float* points, int P, int K, float* dists, i
     int rc = adk::knn_build(points, nullptr, P, w, &codes, stream);
     if (rc) return rc;
     return adk::knn_query_dispatch<0, 0>(K, points, nullptr, P, w, P, codes, dists, indices, stream);
+}
+
+// MEASUREMENT ONLY (bench_backend.py --knn): adk_knn_index2 for K = 3 with the search's work counted into stats[4] (zeroed by the caller):
+// boxes scanned, points visited, super-box tests, box tests, summed over the P queries.  Same results as adk_knn_index2.
+extern "C" int adk_knn_index2_stats(const float* points, int P, float* dists, int32_t* indices, void* workspace, int64_t workspace_bytes,
+                                    unsigned long long* stats, hipStream_t stream)
+{
+    if (P <= 0 || !points || !dists || !indices || !workspace || !stats) return ADK_EINVAL;
+    if (workspace_bytes < adk::knn_ws_bytes(P) || ((uintptr_t)workspace & 255)) return ADK_EWORKSPACE;
+    adk::KnnWs w = adk::knn_carve(workspace, P);
+    const uint32_t* codes;
+    int rc = adk::knn_build(points, nullptr, P, w, &codes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL((adk::knn_query_kernel<3, 0, 0, true>), dim3((unsigned)adk::ceil_div(P, 256)), dim3(256), 0, stream, points, nullptr, P, w.spts, P,
+                       codes, w.boxes, w.n_boxes, w.supers, w.n_supers, w.bbox, dists, indices, stats);
+    ADK_RETURN_LAST_ERROR();
 }
 
 // distCUDA2: mean of the 3 smallest squared distances per point (simple_knn.cu:150-186).

@@ -322,6 +322,10 @@ int64_t adk_knn_workspace_bytes(int64_t n_struct_points);
  * a row unspecified (ascending here); fewer than K neighbours leaves (FLT_MAX, -1).  K in 1..8, 12, 16. */
 int adk_knn_index2(const float* points, int P, int K, float* dists, int32_t* indices, void* workspace,
                    int64_t workspace_bytes, adk_stream_t stream);
+/* MEASUREMENT ONLY ("runtime is search-bound, so also report points-visited/query"): adk_knn_index2 with K = 3 and the search's
+ * work summed over the P queries into stats[4] (uint64, zeroed by the caller): boxes scanned, points visited, super-box tests, box tests. */
+int adk_knn_index2_stats(const float* points, int P, float* dists, int32_t* indices, void* workspace, int64_t workspace_bytes,
+                         unsigned long long* stats, adk_stream_t stream);
 
 /* Replaces distCUDA2(points) = SimpleKNN::knn -- spatial.cu:14-25, simple_knn.cu:188-227:
  * mean_dists[P] = mean of the 3 smallest squared distances. */
