@@ -64,6 +64,9 @@ def parse():
                     help="time ARTDECO's render() glue as stock torch ops instead of artdeco_amd.fused (SURVEY 8 f-1)")
     ap.add_argument("--no-frontend", action="store_true",
                     help="skip the bounded frontend / whole-system measurements reported next to `value` (N = 1 only)")
+    ap.add_argument("--psnr-large", action="store_true",
+                    help="also run the LARGE PSNR proxy in the untimed tail (harness/psnr_proxy.run_large: an 80 k-Gaussian scene reconstructed from streamed "
+                         "frames with add_new_gaussians + add_and_prune in the loop, HIP vs CPU oracle, 5 checkpoints; ~10 minutes, most of it the CPU oracle)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU work: a constant CPU step through the same launch / barrier / all-reduce / report code "
@@ -385,6 +388,21 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, timed["steps"] / args.steps)
             out["psnr_proxy"] = psnr_proxy(dev)
+            if args.psnr_large:
+                try:
+                    from harness import psnr_proxy as PP
+                    out["psnr_proxy_large"] = PP.run_large(dev, cpu_threads=32)
+                except Exception as e:  # report, never hide
+                    out["psnr_proxy_large"] = {"error": repr(e)[:300]}
+            else:   # the last measured large proxy travels with the line (it takes ten minutes: not in the default run)
+                lp = os.path.join(ROOT, "profiles", "r06_psnr_proxy_large.json")
+                if os.path.exists(lp):
+                    with open(lp) as f:
+                        d = json.load(f)
+                    out["psnr_proxy_large_last_measured"] = {"file": "profiles/r06_psnr_proxy_large.json", "max_abs_delta_db": d.get("max_abs_delta_db"),
+                                                             "checkpoints": [{k: cp[k] for k in ("step", "cpu_db", "hip_db", "delta_db")} for cp in d.get("checkpoints", [])],
+                                                             "gaussians_true": d.get("gaussians_true"), "steps": d.get("steps"),
+                                                             "how": "python bench.py --psnr-large (or python harness/psnr_proxy.py --large)"}
         if not args.no_frontend and world == 1:
             out["frontend"] = frontend_summary(args, dev, cpu=not args.no_cpu_baseline)
             out["system"] = system_summary()

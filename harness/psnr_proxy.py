@@ -183,7 +183,7 @@ def run(dev, steps=120, every=20, noise_floor=False, cpu_threads=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------
-# The LARGE proxy (round 6): a problem that can FAIL.  A 60 k-Gaussian true scene at 256x192 is reconstructed the way
+# The LARGE proxy (round 6): a problem that can FAIL.  An 80 k-Gaussian true scene at 256x192 (a 52 k-Gaussian start map) is reconstructed the way
 # run_system.py reconstructs a sequence -- frames arrive one at a time; each becomes a Keyframe, `add_new_gaussians` densifies from it (the
 # start map is missing a third of the scene, so the densified Gaussians are what the held-out views of that region see), `add_and_prune`
 # re-allocates the map and both Adam moments inside it, and a burst of optimisation steps follows -- once on the HIP path and once on the
@@ -191,7 +191,7 @@ def run(dev, steps=120, every=20, noise_floor=False, cpu_threads=None):
 # Held-out PSNR (the reference's, Reconstruct/utils.py:86-87; test views rendered as h3dgsv3.py:523-558 renders them) at five checkpoints.
 # ~4 s per CPU-oracle step at this size: twenty-odd minutes, so this is NOT in bench.py's default tail (python harness/psnr_proxy.py --large,
 # or bench.py --psnr-large); the small proxy above stays there.
-def run_large(dev, n_true=60_000, width=256, height=192, n_frames=10, steps_per_frame=32, n_test=6, checkpoints=5, lr_scale=LR_SCALE,
+def run_large(dev, n_true=80_000, width=256, height=192, n_frames=10, steps_per_frame=32, n_test=6, checkpoints=5, lr_scale=LR_SCALE,
               cpu_threads=None, sides=("cpu", "hip"), log=None):
     from harness import mapper as gmap
     import torch.nn.functional as F
@@ -340,7 +340,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--cpu-only", action="store_true", help="the CPU-oracle side alone (no GPU needed): a dry run of the harness")
-    ap.add_argument("--gaussians", type=int, default=60_000)
+    ap.add_argument("--gaussians", type=int, default=80_000)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--frames", type=int, default=10)
