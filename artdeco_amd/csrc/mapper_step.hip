@@ -82,6 +82,42 @@ static void publish_call_events() {
     }
 }
 
+// ---- the scaling regulariser of the step (h3dgsv3.py:443-449: loss += scaling_reg_factor * scale.prod(dim=1).mean(), `scale` = the
+// post-mlp_cov scales of the LoD-SELECTED Gaussians, :660,699).  run.sh trains with 0; with a non-zero factor the one-call step used to
+// hand the step back to the per-stage chain (VERDICT r05 missing-4).  Three small launches, only when the factor is not 0:
+//   sum     ws[0] += sum over selected rows of s0 s1 s2 (fp32 product as torch forms it, summed in double), ws[1] += their count
+//   finish  loss += factor * ws[0] / max(ws[1], 1);  ws[2] = factor / max(ws[1], 1);  ws[0] = ws[1] = 0 for the next step
+//   bwd     v_scales[g] += unit_grad * ws[2] * (s1 s2, s0 s2, s0 s1)   -- after the projection backward WROTE v_scales, before lod_params_bwd reads it
+__global__ __launch_bounds__(256) void scale_reg_sum_kernel(int N, const float* __restrict__ scale, const uint8_t* __restrict__ sel, double* __restrict__ ws) {
+    __shared__ double red[2][4];
+    double p = 0.0, c = 0.0;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < N; g += (int64_t)gridDim.x * 256)
+        if (sel[g]) { p += (double)((scale[3 * g] * scale[3 * g + 1]) * scale[3 * g + 2]); c += 1.0; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { p += __shfl_xor(p, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = p; red[1][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double P = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), C = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        if (C != 0.0) { unsafeAtomicAdd(ws, P); unsafeAtomicAdd(ws + 1, C); }
+    }
+}
+__global__ void scale_reg_finish_kernel(double* __restrict__ ws, float factor, float* __restrict__ loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double cnt = ws[1] > 1.0 ? ws[1] : 1.0;
+    loss[0] = (float)((double)loss[0] + (double)factor * ws[0] / cnt);
+    ws[2] = (double)factor / cnt;
+    ws[0] = 0.0; ws[1] = 0.0;
+}
+__global__ __launch_bounds__(256) void scale_reg_bwd_kernel(int N, const float* __restrict__ scale, const uint8_t* __restrict__ sel, const double* __restrict__ ws,
+                                                            const float* __restrict__ unit_grad, float* __restrict__ v_scales) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N || !sel[g]) return;
+    const float c = (float)ws[2] * unit_grad[0];
+    const float s0 = scale[3 * g], s1 = scale[3 * g + 1], s2 = scale[3 * g + 2];
+    v_scales[3 * g] += c * (s1 * s2); v_scales[3 * g + 1] += c * (s0 * s2); v_scales[3 * g + 2] += c * (s0 * s1);
+}
+
 struct StageScope {
     hipStream_t stream;
     hipEvent_t a = nullptr, b = nullptr;
@@ -279,6 +315,15 @@ static int mapper_step_impl(const AdkMapperStepArgs* A, AdkMapperStepOut* out, a
                                                                        A->photo_ws, A->photo_ws_bytes, f(A->parts), f(A->loss), stream));
     }
 
+    const bool scale_reg = A->scaling_reg_factor != 0.f;
+    if (scale_reg) { // h3dgsv3.py:443-449
+        if (!A->reg_ws) { out->stage = STAGE_photometric_loss; return ADK_EINVAL; }
+        hipLaunchKernelGGL(adk::scale_reg_sum_kernel, dim3(adk::stream_grid(N, 256)), dim3(256), 0, stream, N, cf(A->scale),
+                           static_cast<const uint8_t*>(A->sel), static_cast<double*>(A->reg_ws));
+        hipLaunchKernelGGL(adk::scale_reg_finish_kernel, dim3(1), dim3(64), 0, stream, static_cast<double*>(A->reg_ws), A->scaling_reg_factor, f(A->loss));
+        ADK_STEP_TRY(STAGE_photometric_loss, (int)hipGetLastError());
+    }
+
     // ---- backward, in the order the autograd engine runs the nodes
     {
         adk::StageScope ts(A, STAGE_ssim_bwd, stream);
@@ -322,6 +367,11 @@ static int mapper_step_impl(const AdkMapperStepArgs* A, AdkMapperStepOut* out, a
                                                  f(A->v_opac), f(A->v_dc), f(A->v_rest), cam_grad, v_viewmat, nullptr, pose_r6, f(A->v_r6), f(A->v_t),
                                                  stream));
         }
+    }
+    if (scale_reg) {
+        hipLaunchKernelGGL(adk::scale_reg_bwd_kernel, dim3((unsigned)adk::ceil_div((int64_t)N, (int64_t)256)), dim3(256), 0, stream, N, cf(A->scale),
+                           static_cast<const uint8_t*>(A->sel), static_cast<const double*>(A->reg_ws), cf(A->unit_grad), f(A->v_scales));
+        ADK_STEP_TRY(STAGE_lod_params_bwd, (int)hipGetLastError());
     }
     {
         adk::StageScope ts(A, STAGE_lod_params_bwd, stream);

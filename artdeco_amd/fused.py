@@ -665,10 +665,11 @@ def _accumulate(leaf: torch.Tensor, grad: torch.Tensor | None) -> None:
         leaf.grad += grad
 
 
-def _hand_chain_ok(self, keyframe) -> bool:
+def _hand_chain_ok(self, keyframe, allow_regulariser: bool = False) -> bool:
     """The hand-driven chain covers run.sh's configuration: pose parameters on the device in float32, no scaling
-    regulariser (a torch expression on `scaling` needs the autograd graph), ARTDECO_AMD_HAND_CHAIN != 0."""
-    return (self.scaling_reg_factor == 0 and keyframe.rW2C.is_cuda and keyframe.rW2C.dtype == torch.float32
+    regulariser (a torch expression on `scaling` needs the autograd graph), ARTDECO_AMD_HAND_CHAIN != 0.
+    allow_regulariser: the one-call step carries the regulariser itself (adk_mapper_step, ABI v19)."""
+    return ((allow_regulariser or self.scaling_reg_factor == 0) and keyframe.rW2C.is_cuda and keyframe.rW2C.dtype == torch.float32
             and keyframe.tW2C.is_cuda and os.environ.get("ARTDECO_AMD_HAND_CHAIN", "1") != "0" and torch.is_grad_enabled())
 
 
@@ -744,16 +745,19 @@ def fused_train_on_keyframe(self, keyframe_id, is_important=True):
     lvl = keyframe.pyr_lvl
     keyframe.zero_grad()
     self.optimizer.zero_grad()
-    if _hand_chain_ok(self, keyframe):
-        if native_step.enabled():
-            # the whole forward / loss / backward as one native call; None = this step needs the per-stage chain (nothing modified)
-            loss, bg = native_step.train_on_keyframe(self, keyframe, is_important)
-            if loss is not None:
-                return loss
-            return _train_on_keyframe_by_hand(self, keyframe, is_important, bg=bg)
+    bg_drawn = None
+    if native_step.enabled() and _hand_chain_ok(self, keyframe, allow_regulariser=True):
+        # the whole forward / loss / backward as one native call (the scaling regulariser included); None = this step needs the per-stage
+        # chain (nothing modified; `bg` is the background if it has been drawn already: one draw per step, as in the reference)
+        loss, bg_drawn = native_step.train_on_keyframe(self, keyframe, is_important)
+        if loss is not None:
+            return loss
+        if _hand_chain_ok(self, keyframe):
+            return _train_on_keyframe_by_hand(self, keyframe, is_important, bg=bg_drawn)
+    elif _hand_chain_ok(self, keyframe):
         return _train_on_keyframe_by_hand(self, keyframe, is_important)
     dev = self.device
-    bg = torch.rand(3, device=dev)
+    bg = bg_drawn if bg_drawn is not None else torch.rand(3, device=dev)
     scale = 2 ** lvl
     width, height = self.width // scale, self.height // scale
     if keyframe.rW2C.is_cuda and keyframe.rW2C.dtype == torch.float32:

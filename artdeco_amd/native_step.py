@@ -170,6 +170,7 @@ class StepPlan:
         e("v_global_feat", V, 16, **f32); e("v_mlp", _NW, **f32); e("lod_ws", int(lib.adk_lod_params_bwd_workspace_bytes(N)), **u8)
         e("v_r6", 3, 2, **f32); e("v_t", 3, **f32)
         self.t["unit_grad"] = torch.ones(1, **f32)
+        self.t["reg_ws"] = torch.zeros(4, dtype=torch.float64, device=dev)     # the scaling regulariser's sums (left zeroed by the call)
         A = self.args
         for name, ten in self.t.items():
             setattr(A, name, ten.data_ptr())
@@ -340,6 +341,7 @@ def train_on_keyframe(scene, keyframe, is_important):
     A.sh_K, A.sh_degree, A.mask_outliers, A.pose_grad = sh_K, deg, 0 if is_important else 1, int(pose_grad)
     A.eps2d, A.near_plane, A.far_plane, A.radius_clip = float(eps2d), 0.01, 1e10, 0.0
     A.lambda_dssim, A.depth_weight, A.ssim_grad_scale = lam, wd, -lam / float(3 * H * W)
+    A.scaling_reg_factor = float(getattr(scene, "scaling_reg_factor", 0.0) or 0.0)     # h3dgsv3.py:443-449, inside the call since ABI v19
     timer = rasterizer._TIMER
     A.time_mask = 0 if timer is None else sum(1 << i for i, s in enumerate(_Lazy.stages) if timer.only is None or s in timer.only)
     with torch.no_grad(), _lib.on_device(dev):

@@ -648,6 +648,9 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
  * adk_bin_local_sort_long_max(), or above 8 192 with pairs2 == NULL: use the per-stage calls with the global route).  Both are decided
  * BEFORE anything the caller owns has been modified.  Any other
  * negative value: the failing stage's own code, out->stage = its index in ADK_MAPPER_STAGES.
+ * scaling_reg_factor (ABI v19): h3dgsv3.py:443-449's regulariser, loss += factor * mean over the LoD-selected Gaussians of the product of their
+ * post-mlp_cov scales -- three small launches inside the call when it is not 0 (run.sh: 0); reg_ws: 32 bytes (4 doubles) zeroed once by the
+ * caller (left zeroed), may be NULL while the factor is 0.
  * ssim_grad_scale = -lambda_dssim / (3 W H), formed by the caller in double precision as the per-stage binding does (adk_fused_ssim_bwd's
  * dL_scalar).  time_mask: bit s set = bracket stage s with a pair of events (adk_mapper_step_timings folds and frees them). */
 #define ADK_STEP_ECAPACITY (-16)
@@ -662,10 +665,10 @@ int adk_rigid_transform(int64_t N, const int64_t* ids, int64_t n_keyframes, cons
     P(render_colors) P(render_alphas) P(final_T) P(last_ids) P(vis) P(gvis) \
     P(image) P(gt_used) P(dm) P(parts) P(ssim_sums) P(photo_ws) P(v_img) P(v_col) P(v_alpha) P(v_exposure) \
     P(v_rec) P(v_means) P(v_quats) P(v_scales) P(v_opac) P(v_dc) P(v_rest) P(cam_grad) P(v_viewmat) \
-    P(v_opacity_raw) P(v_scaling_raw) P(v_rotation) P(v_local_feat) P(v_global_feat) P(v_mlp) P(lod_ws) P(v_r6) P(v_t) \
+    P(v_opacity_raw) P(v_scaling_raw) P(v_rotation) P(v_local_feat) P(v_global_feat) P(v_mlp) P(lod_ws) P(v_r6) P(v_t) P(reg_ws) \
     L(isect_capacity) L(bin_table_bytes) L(lod_ws_bytes) L(photo_ws_bytes) L(n_ssim_sums) \
-    I(N) I(V) I(width) I(height) I(tile_px_w) I(tile_px_h) I(sh_K) I(sh_degree) I(mask_outliers) I(color_adam) I(pose_grad) I(time_mask) \
-    F(eps2d) F(near_plane) F(far_plane) F(radius_clip) F(lambda_dssim) F(depth_weight) F(adam_b1) F(adam_b2) F(adam_eps) F(ssim_grad_scale)
+    I(N) I(V) I(width) I(height) I(tile_px_w) I(tile_px_h) I(sh_K) I(sh_degree) I(mask_outliers) I(color_adam) I(pose_grad) I(time_mask) I(reserved) \
+    F(eps2d) F(near_plane) F(far_plane) F(radius_clip) F(lambda_dssim) F(depth_weight) F(adam_b1) F(adam_b2) F(adam_eps) F(ssim_grad_scale) F(scaling_reg_factor)
 #define ADK_MAPPER_STAGES(S) \
     S(lod_params_fwd) S(project_fwd) S(bin_count) S(bin_scatter) S(bin_sort) S(raster_fwd) S(photometric_fwd) S(ssim_fwd) \
     S(photometric_loss) S(ssim_bwd) S(photometric_bwd) S(raster_bwd) S(project_bwd) S(lod_params_bwd)

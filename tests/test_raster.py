@@ -275,6 +275,39 @@ def test_binning_is_bit_exact_at_northstar_sizes_on_every_route(N, W, H, route, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["local", "global"])
+@pytest.mark.parametrize("N,W,H,n_big,grow", [(30_000, 512, 384, 40, 40.0), (200_000, 1920, 1080, 12, 400.0)])
+def test_binning_is_bit_exact_with_screen_filling_gaussians(N, W, H, n_big, grow, route, dev, monkeypatch):
+    """Round 6 (finding 62): over a long sequence the optimiser grows a handful of Gaussians until they cover most of the frame.  Their tile
+    rectangles (hundreds to thousands of tiles; ALL 8 160 at 1080p) are counted / scattered / emitted by a whole workgroup or wave instead of
+    by the one thread that owns the Gaussian -- same lists: radii, tiles per Gaussian, sorted keys, sorted ids and offsets against the ORACLE,
+    bit for bit, on the tile-local and on the global route."""
+    sc = dict(_scene(N, W, H, 21), viewmat=_tilted_viewmat(4))
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:n_big]
+    sc["scales"] = sc["scales"].clone()
+    sc["scales"][idx] *= grow
+    sc["opacities"] = sc["opacities"].clone()
+    sc["opacities"][idx] = 0.9
+    for k in ("ADK_BIN_BUCKET_SORT", "ADK_BIN_LOCAL", "ADK_BIN_LONG"):
+        monkeypatch.delenv(k, raising=False)
+    if route == "global":
+        monkeypatch.setenv("ADK_BIN_LOCAL", "0")
+    p = go.project(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["viewmat"], sc["K"], W, H, 0.01)
+    oi = go.isect_tiles(p["means2d"], p["radii"], p["depths"], W, H)
+    n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    big = oi["tiles_per_gauss"][idx.numpy()]
+    assert (big > 48).sum() >= n_big // 2 and big.max() >= 0.5 * n_tiles, (big.max(), n_tiles)     # some rectangles cover most of the frame
+    r, a, meta, _ = _run_hip(sc, dev)
+    assert torch.equal(meta["radii"][0].cpu(), p["radii"])
+    assert np.array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), oi["tiles_per_gauss"])
+    assert meta["isect_ids"].numel() == oi["n_isects"]
+    assert np.array_equal(meta["isect_ids"].cpu().numpy(), oi["isect_ids"])
+    assert np.array_equal(meta["flatten_ids"].cpu().numpy(), oi["flatten_ids"])
+    assert np.array_equal(meta["isect_offsets"][0].cpu().numpy(), oi["offsets"])
+    assert bool(torch.isfinite(r).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["dense-northstar", "pile", "equal-depths"])
 def test_binning_is_bit_exact_beyond_8192_entries_per_tile(case, dev, monkeypatch):
     """Tile lists ABOVE 8 192 entries stay on the tile-local route (round 5: bin_tile_sort_long_kernel, recursive partition on the key range
