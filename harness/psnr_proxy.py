@@ -248,10 +248,10 @@ def run_large(dev, n_true=80_000, width=256, height=192, n_frames=10, steps_per_
     logit0 = torch.log(op[keep] / (1 - op[keep])) + 0.5 * torch.randn(n0, generator=gq)
     lsc0 = torch.log(2.0 * c["scales"][keep]) + 0.15 * torch.randn(n0, 3, generator=gq)
 
-    def build_side(mapper, device):
+    def build_side(mapper, device, position_scale=1.0):
         sc = mapper.MapperScene(W, H, c["fx"], device)
         neutral_mlp(sc)
-        sc.set_gaussians(means0, c["quats"][keep], lsc0, logit0, sh0, seed=0)
+        sc.set_gaussians(means0 * position_scale, c["quats"][keep], lsc0, logit0, sh0, seed=0)
         for k, pd in sc.optimizer.params.items():
             if "lr" in pd and k not in ("cls_id", "d_max", "id"):
                 pd["lr"] = pd["lr"] * lr_scale
@@ -261,6 +261,8 @@ def run_large(dev, n_true=80_000, width=256, height=192, n_frames=10, steps_per_
     runs = {}
     if "cpu" in sides:
         runs["cpu"] = (cmap, build_side(cmap, "cpu"))
+    if "cpu_perturbed" in sides:     # the proxy's own noise floor: the CPU oracle against ITSELF from positions scaled by 1 + 1e-7
+        runs["cpu_perturbed"] = (cmap, build_side(cmap, "cpu", position_scale=1.0 + 1e-7))
     if "hip" in sides:
         from artdeco_amd import fused
         sc = build_side(gmap, dev)
@@ -323,10 +325,12 @@ def run_large(dev, n_true=80_000, width=256, height=192, n_frames=10, steps_per_
         torch.set_rng_state(rng_state)
         torch.set_num_threads(threads0)
     both = "cpu" in runs and "hip" in runs
+    floor = "cpu" in runs and "cpu_perturbed" in runs
     cps = [{"step": s, **{f"{k}_db": round(x, 4) for k, x in v.items()}, **({"delta_db": round(v["hip"] - v["cpu"], 4)} if both else {}),
-            "map_size": m} for s, v, m in curve]
+            **({"noise_floor_db": round(v["cpu_perturbed"] - v["cpu"], 4)} if floor else {}), "map_size": m} for s, v, m in curve]
     return {"start_db": {k: round(v, 4) for k, v in start.items()}, "checkpoints": cps,
             "max_abs_delta_db": max(abs(cp["delta_db"]) for cp in cps) if both and cps else None,
+            "max_abs_noise_floor_db": max(abs(cp["noise_floor_db"]) for cp in cps) if floor and cps else None,
             "gaussians_true": n_true, "gaussians_start": n0, "width": W, "height": H, "frames": n_frames, "steps": total, "held_out_views": n_test,
             "densified": [{"frame": f, "side": s, "before": a, "after": b} for f, s, a, b in sizes], "learning_rate_scale": lr_scale,
             "seconds": round(time.perf_counter() - t_start, 1)}
@@ -346,6 +350,7 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--steps-per-frame", type=int, default=32)
     ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--noise-floor", action="store_true", help="--large: also the CPU oracle against itself from positions scaled by 1 + 1e-7 (doubles the CPU time)")
     a = ap.parse_args()
     if not a.cpu_only:
         import artdeco_amd
@@ -353,7 +358,7 @@ if __name__ == "__main__":
     devc = None if a.cpu_only else torch.device("cuda:0")
     if a.large:
         r = run_large(devc, a.gaussians, a.width, a.height, a.frames, a.steps_per_frame, cpu_threads=a.threads,
-                      sides=("cpu",) if a.cpu_only else ("cpu", "hip"), log=lambda *x: print(*x, file=sys.stderr, flush=True))
+                      sides=(("cpu",) if a.cpu_only else ("cpu", "hip")) + (("cpu_perturbed",) if a.noise_floor else ()), log=lambda *x: print(*x, file=sys.stderr, flush=True))
     else:
         r = run(devc, cpu_threads=a.threads)
     print(json.dumps(r))
