@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
         const float4 a = r4[0], b = r4[1];
         tile_range_bin(a.x, a.y, a.w, b.w, tile_w, tile_h, x0, x1, y0, y1);
     }
-    // Round 6 (finding 62): a Gaussian with more than 48 tiles is emitted by its whole WAVE (lane l writes entries l, l + 64, ...), not by
+    // Round 6 (finding 62): a Gaussian with more than BIN_BIG_TILES tiles is emitted by its whole WAVE (lane l writes entries l, l + 64, ...), not by
     // the one lane that owns it: a screen-filling splat is 8 160 serial store pairs at 1080p otherwise.  Same entries at the same offsets.
-    const bool big = c > 48u;
+    const bool big = c > 64u; // = BIN_BIG_TILES (defined below)
     unsigned long long bm = __ballot(big);
     while (bm) {
         const int src = __builtin_ctzll(bm);
@@ -193,16 +193,17 @@ __global__ __launch_bounds__(256) void count_isects_kernel(const int32_t* __rest
 // per slice: 16 waves share one LDS histogram (256 slices x 4 waves left most of the chip idle: 89 us -> see DESIGN)
 #define BIN_SORT_BIG 8192
 // Round 6 (finding 62): a Gaussian whose tile rectangle has more than BIN_BIG_TILES tiles is not walked by the one thread that owns it but
-// by the WHOLE workgroup, after the per-thread pass.  The per-thread walk is serial -- one LDS atomic (count) or one returning LDS atomic + an
-// 8 B store (scatter) per tile -- and the kernel ends with its slowest thread: over a 1 000-frame sequence the optimiser grows a handful
-// of Gaussians until they cover most of the frame (up to 8 160 tiles at 1080p), and those alone took bin_count from 0.03 to 0.26 ms and
-// bin_scatter from 0.07 to 0.68 ms per optimisation step by frame 500 (profiles/r06_sequence_drift.txt) -- +48 % on the whole step, invisible
-// on the benchmark clouds (radius 6-7 px).  Same counts, and the order inside a tile's segment was already arbitrary (the
-// per-tile sort fixes it): bit-identical lists.
+// by its whole WAVE (lane l takes tiles l, l + 64, ...; the owner's rectangle and key are read with v_readlane).  The per-thread walk is
+// serial -- one LDS atomic (count) or one returning LDS atomic + an 8 B store (scatter) per tile -- and the kernel ends with its slowest
+// thread: over a 1 000-frame sequence the optimiser grows a handful of Gaussians until they cover most of the frame (up to 8 160 tiles at
+// 1080p), and those alone took bin_count from 0.03 to 0.26 ms and bin_scatter from 0.07 to 0.68 ms per optimisation step by frame 500
+// (profiles/r06_sequence_drift.txt) -- +48 % on the whole step, invisible on the benchmark clouds (radius 6-7 px).  Wave-level,
+// not workgroup-level: it needs no list, no barrier and no cap, and a frame whose TYPICAL rectangle is above the threshold (a close-up)
+// costs what the per-thread walk costs (64 lanes x one pass each) instead of 1 024 threads idling behind 64.  Same counts, and the order
+// inside a tile's segment was already arbitrary (the per-tile sort fixes it): bit-identical lists.
 #ifndef BIN_BIG_TILES
-#define BIN_BIG_TILES 48
+#define BIN_BIG_TILES 64
 #endif
-#define BIN_BIG_MAX 1024   // per slice; a slice with more defers the rest to their own threads as before
 
 // Internal tiles may be WIDER than gsplat's 16x16 (round 3: one wave rasterises a 32x16 tile, so a splat costs one list entry, one
 // LDS record and -- in the backward -- one 64-lane reduction and one flush per 32x16 tile instead of per 16x16 tile).  A wide tile
@@ -227,44 +228,39 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const int32_t* _
                                                         WideGrid grid, uint32_t* __restrict__ table /* [BIN_SLICES][n_tiles] */)
 {
     extern __shared__ uint32_t hist[];
-    __shared__ int big_n;
-    __shared__ int big_g[BIN_BIG_MAX];
     const int tile_w = grid.wide_w;
     const int n_tiles = grid.wide_w * grid.wide_h;
     for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0u;
-    if (threadIdx.x == 0) big_n = 0;
     __syncthreads();
     const int chunk = (int)ceil_div(N, BIN_SLICES);
     const int g0 = blockIdx.x * chunk, g1 = min(N, g0 + chunk);
-    for (int g = g0 + threadIdx.x; g < g1; g += BIN_THREADS) {
-        if (tiles_per_gauss[g] == 0) continue;
-        const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
-        const float4 a = r4[0], b = r4[1];
-        int x0, x1, y0, y1;
-        tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
-        if ((x1 - x0) * (y1 - y0) > BIN_BIG_TILES) { // a large rectangle: left to the whole workgroup below
-            const int k = atomicAdd(&big_n, 1);
-            if (k < BIN_BIG_MAX) { big_g[k] = g; continue; }
-        }
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * tile_w + tx], 1u);
-    }
-    __syncthreads();
-    {
-        const int nb = min(big_n, BIN_BIG_MAX);
-        for (int k = 0; k < nb; ++k) { // workgroup-uniform
-            const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)big_g[k];
+    const int lane = threadIdx.x & 63;
+    for (int base = g0; base < g1; base += BIN_THREADS) { // uniform trip count: the ballot below needs the whole wave
+        const int g = base + (int)threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        if (g < g1 && tiles_per_gauss[g] != 0) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
             const float4 a = r4[0], b = r4[1];
-            int x0, x1, y0, y1;
             tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
-            const int w = x1 - x0, total = w * (y1 - y0);
-            for (int i = threadIdx.x; i < total; i += BIN_THREADS) {
+        }
+        const bool big = (x1 - x0) * (y1 - y0) > BIN_BIG_TILES;
+        if (!big)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * tile_w + tx], 1u);
+        unsigned long long bm = __ballot(big);
+        while (bm) { // a large rectangle: walked by the wave
+            const int src = __builtin_ctzll(bm);
+            bm &= bm - 1;
+            const int bx0 = __builtin_amdgcn_readlane(x0, src), bx1 = __builtin_amdgcn_readlane(x1, src);
+            const int by0 = __builtin_amdgcn_readlane(y0, src), by1 = __builtin_amdgcn_readlane(y1, src);
+            const int w = bx1 - bx0, total = w * (by1 - by0);
+            for (int i = lane; i < total; i += 64) {
                 const int r = i / w;
-                atomicAdd(&hist[(y0 + r) * tile_w + x0 + (i - r * w)], 1u);
+                atomicAdd(&hist[(by0 + r) * tile_w + bx0 + (i - r * w)], 1u);
             }
         }
-        if (nb) __syncthreads();
     }
+    __syncthreads();
     uint32_t* row = table + (int64_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) row[t] = hist[t];
 }
@@ -332,64 +328,63 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const int32_t*
                                                           int64_t capacity, unsigned long long* __restrict__ pairs)
 {
     extern __shared__ uint32_t cur[];
-    __shared__ int big_n;
-    __shared__ int big_g[BIN_BIG_MAX];
     const int tile_w = grid.wide_w;
     const int n_tiles = grid.wide_w * grid.wide_h;
     const uint32_t* row = table + (int64_t)blockIdx.x * n_tiles;
     for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) cur[t] = (uint32_t)offsets[t] + row[t];
-    if (threadIdx.x == 0) big_n = 0;
     __syncthreads();
     const int chunk = (int)ceil_div(N, BIN_SLICES);
     const int g0 = blockIdx.x * chunk, g1 = min(N, g0 + chunk);
 #ifdef BIN_LAB
     uint32_t lab_acc = 0; int lab_k = 0; (void)lab_acc; (void)lab_k;
 #endif
-    for (int g = g0 + threadIdx.x; g < g1; g += BIN_THREADS) {
-        if (tiles_per_gauss[g] == 0) continue;
-        const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
-        const float4 a = r4[0], b = r4[1];
-        int x0, x1, y0, y1;
-        tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
-#if !defined(BIN_LAB)
-        if ((x1 - x0) * (y1 - y0) > BIN_BIG_TILES) { // a large rectangle: left to the whole workgroup below (the same test as bin_count_kernel's)
-            const int k = atomicAdd(&big_n, 1);
-            if (k < BIN_BIG_MAX) { big_g[k] = g; continue; }
+    const int lane = threadIdx.x & 63;
+    for (int base = g0; base < g1; base += BIN_THREADS) { // uniform trip count: the ballot below needs the whole wave
+        const int g = base + (int)threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        uint32_t dkey = 0u;
+        if (g < g1 && tiles_per_gauss[g] != 0) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
+            const float4 a = r4[0], b = r4[1];
+            tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
+            dkey = depth_keys[g];
         }
-#endif
-        const unsigned long long key = ((unsigned long long)depth_keys[g] << 32) | (unsigned long long)(uint32_t)g;
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) {
-                const uint32_t pos = atomicAdd(&cur[ty * tile_w + tx], 1u);
-#if defined(BIN_LAB) && BIN_LAB == 1   // lab only: atomics without the scattered stores
-                lab_acc += pos;
-#elif defined(BIN_LAB) && BIN_LAB == 2 // lab only: the same number of 8-byte stores, to consecutive addresses per thread
-                if ((int64_t)pos < capacity) pairs[((int64_t)g * 4 + (lab_k++ & 3)) % capacity] = key + pos;
+        const unsigned long long key = ((unsigned long long)dkey << 32) | (unsigned long long)(uint32_t)g;
+#if defined(BIN_LAB)
+        const bool big = false;
 #else
-                if ((int64_t)pos < capacity) pairs[pos] = key;
+        const bool big = (x1 - x0) * (y1 - y0) > BIN_BIG_TILES; // the same test as bin_count_kernel's (any split gives the same lists)
 #endif
+        if (!big)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const uint32_t pos = atomicAdd(&cur[ty * tile_w + tx], 1u);
+#if defined(BIN_LAB) && BIN_LAB == 1   // lab only: atomics without the scattered stores
+                    lab_acc += pos;
+#elif defined(BIN_LAB) && BIN_LAB == 2 // lab only: the same number of 8-byte stores, to consecutive addresses per thread
+                    if ((int64_t)pos < capacity) pairs[((int64_t)g * 4 + (lab_k++ & 3)) % capacity] = key + pos;
+#else
+                    if ((int64_t)pos < capacity) pairs[pos] = key;
+#endif
+                }
+        unsigned long long bm = __ballot(big);
+        while (bm) { // a large rectangle: walked by the wave
+            const int src = __builtin_ctzll(bm);
+            bm &= bm - 1;
+            const int bx0 = __builtin_amdgcn_readlane(x0, src), bx1 = __builtin_amdgcn_readlane(x1, src);
+            const int by0 = __builtin_amdgcn_readlane(y0, src), by1 = __builtin_amdgcn_readlane(y1, src);
+            const unsigned long long bkey = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dkey, src) << 32) |
+                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(g, src);
+            const int w = bx1 - bx0, total = w * (by1 - by0);
+            for (int i = lane; i < total; i += 64) {
+                const int r = i / w;
+                const uint32_t pos = atomicAdd(&cur[(by0 + r) * tile_w + bx0 + (i - r * w)], 1u);
+                if ((int64_t)pos < capacity) pairs[pos] = bkey;
             }
+        }
     }
 #if defined(BIN_LAB) && BIN_LAB == 1
     if (lab_acc == 0xFFFFFFFFu) pairs[0] = lab_acc;
-#endif
-#if !defined(BIN_LAB)
-    __syncthreads();
-    const int nb = min(big_n, BIN_BIG_MAX);
-    for (int k = 0; k < nb; ++k) { // workgroup-uniform
-        const int g = big_g[k];
-        const float4* r4 = reinterpret_cast<const float4*>(rec) + 3 * (int64_t)g;
-        const float4 a = r4[0], b = r4[1];
-        int x0, x1, y0, y1;
-        tile_range_wide(a.x, a.y, a.w, b.w, grid, x0, x1, y0, y1);
-        const unsigned long long key = ((unsigned long long)depth_keys[g] << 32) | (unsigned long long)(uint32_t)g;
-        const int w = x1 - x0, total = w * (y1 - y0);
-        for (int i = threadIdx.x; i < total; i += BIN_THREADS) {
-            const int r = i / w;
-            const uint32_t pos = atomicAdd(&cur[(y0 + r) * tile_w + x0 + (i - r * w)], 1u);
-            if ((int64_t)pos < capacity) pairs[pos] = key;
-        }
-    }
 #endif
 }
 

@@ -276,12 +276,13 @@ def test_binning_is_bit_exact_at_northstar_sizes_on_every_route(N, W, H, route, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("route", ["local", "global"])
-@pytest.mark.parametrize("N,W,H,n_big,grow", [(30_000, 512, 384, 40, 40.0), (200_000, 1920, 1080, 12, 400.0)])
+@pytest.mark.parametrize("N,W,H,n_big,grow", [(30_000, 512, 384, 40, 40.0), (200_000, 1920, 1080, 12, 400.0), (6_000, 512, 384, 6_000, 10.0)])
 def test_binning_is_bit_exact_with_screen_filling_gaussians(N, W, H, n_big, grow, route, dev, monkeypatch):
     """Round 6 (finding 62): over a long sequence the optimiser grows a handful of Gaussians until they cover most of the frame.  Their tile
     rectangles (hundreds to thousands of tiles; ALL 8 160 at 1080p) are counted / scattered / emitted by a whole workgroup or wave instead of
     by the one thread that owns the Gaussian -- same lists: radii, tiles per Gaussian, sorted keys, sorted ids and offsets against the ORACLE,
-    bit for bit, on the tile-local and on the global route."""
+    bit for bit, on the tile-local and on the global route.  Third case: a close-up, EVERY Gaussian grown x10 (the typical rectangle is above
+    the threshold, every lane of a wave hands its Gaussian to the wave)."""
     sc = dict(_scene(N, W, H, 21), viewmat=_tilted_viewmat(4))
     idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:n_big]
     sc["scales"] = sc["scales"].clone()
@@ -296,7 +297,10 @@ def test_binning_is_bit_exact_with_screen_filling_gaussians(N, W, H, n_big, grow
     oi = go.isect_tiles(p["means2d"], p["radii"], p["depths"], W, H)
     n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     big = oi["tiles_per_gauss"][idx.numpy()]
-    assert (big > 48).sum() >= n_big // 2 and big.max() >= 0.5 * n_tiles, (big.max(), n_tiles)     # some rectangles cover most of the frame
+    if n_big < N:
+        assert (big > 64).sum() >= n_big // 2 and big.max() >= 0.5 * n_tiles, (big.max(), n_tiles)     # some rectangles cover most of the frame
+    else:
+        assert np.median(big[big > 0]) > 64, np.median(big[big > 0])                                   # the close-up: the typical one is large
     r, a, meta, _ = _run_hip(sc, dev)
     assert torch.equal(meta["radii"][0].cpu(), p["radii"])
     assert np.array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), oi["tiles_per_gauss"])
