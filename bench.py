@@ -363,12 +363,12 @@ def main():
                 busy = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / (1024 * bwd_ms * 1e-3 * 2.4e9)
                 out["roofline_valu"]["valu_busy"] = busy
                 out["roofline_valu"]["cycles_per_valu_inst"] = prof["raster_bwd_active_inst_valu_quadcycles"] * 4.0 / valu
-                # round 6 (FINDINGS 49, 52): SQ_ACTIVE_INST_VALU is 1.06 x SQ_INSTS_VALU in quad-cycles on every kernel of this library -- it ticks per
+                # round 6 (FINDINGS 49, 52): SQ_ACTIVE_INST_VALU is 1.00 - 1.08 x SQ_INSTS_VALU in quad-cycles on EVERY kernel of this library, stream_copy included -- it ticks per
                 # ISSUED instruction, so "valu_busy" ~ 1 does not show a saturated port.  Measured issue costs (tools/valu_cost_bench2.hip): 2.6
                 # cycles for VGPR-only mul / add / fma, 4.2 for compares / selects / min / DPP / SGPR operands, 8.2 for v_exp / v_rcp / permlane
                 # swaps; this kernel's mix issues in ~0.42 ms at full occupancy and the rest is latency at 7 waves per SIMD.
                 out["roofline_valu"]["note"] = ("valu_busy / cycles_per_valu_inst are derived from SQ_ACTIVE_INST_VALU, which counts issued instructions "
-                                                "(1.06 x SQ_INSTS_VALU), not port-busy time: see profiles/FINDINGS.md 49 and 52 for the measured "
+                                                "(1.00 - 1.08 x SQ_INSTS_VALU on every kernel, the HBM-bound ones included), not port-busy time: see profiles/FINDINGS.md 49 and 52 for the measured "
                                                 "per-class issue costs and the occupancy / padding probes")
         if frozen is not None:
             out["with_gc_freeze"] = {"frames_per_s": frozen["frames"] / frozen["seconds"], "frames": frozen["frames"],
