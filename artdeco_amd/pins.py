@@ -114,6 +114,15 @@ def verify(scene, pins: dict | None = None) -> dict:
 
 
 def warn_once(bad: dict) -> None:
+    """One line on stderr per (group, methods) -- and, with ARTDECO_AMD_REQUIRE_FUSED=1, an exception instead: a deployment that counts on
+    the fused path (5 frames/s without it, 36 with it at 1 M / 1080p) should stop at start-up when an upstream edit has unpinned a method,
+    not run eight times slower behind a warning."""
+    if bad and os.environ.get("ARTDECO_AMD_REQUIRE_FUSED", "0") == "1":
+        raise RuntimeError("artdeco_amd: ARTDECO_AMD_REQUIRE_FUSED=1 and the host methods "
+                           + "; ".join(f"{g}: {', '.join(n)}" for g, n in bad.items())
+                           + " differ from the pinned ARTDECO sources (artdeco_amd/reference_pins.json): the fused path(s) would not be "
+                             "installed.  Re-validate and re-pin with tools/make_reference_pins.py, or unset the variable to run ARTDECO's own code "
+                             "on the native operators.")
     for group, names in bad.items():
         key = (group, tuple(names))
         if key in _warned:

@@ -290,6 +290,11 @@ def test_autofuse_refuses_a_host_method_that_moved(ref_module, monkeypatch, tmp_
     assert scene.optimizer.step.__func__ is mod.SparseGaussianAdam.step
     assert scene.update_voxel.__func__ is fused.fused_update_voxel
     assert scene.optimizer.add_and_prune.__func__ is fused.fused_add_and_prune
+    # round 6: a deployment that counts on the fused path stops at start-up instead of running eight times slower behind a warning
+    monkeypatch.setenv("ARTDECO_AMD_REQUIRE_FUSED", "1")
+    with pytest.raises(RuntimeError, match="SceneModel.optimization_step"):
+        mod.SceneModel(64, 48, _K(64, 48, 51.2), _args(), device="cpu")
+    monkeypatch.delenv("ARTDECO_AMD_REQUIRE_FUSED")
     # the unperturbed class verifies clean
     good = ref_module().SceneModel(64, 48, _K(64, 48, 51.2), _args(), device="cpu")
     assert good._artdeco_amd_skipped == {} and good.optimization_step.__func__ is fused.fused_optimization_step
