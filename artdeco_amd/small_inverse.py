@@ -48,13 +48,14 @@ def allow_caller(filename: str) -> None:
 def _counter() -> torch.Tensor:
     if "t" not in _COUNTER:
         _COUNTER["t"] = torch.zeros(1, dtype=torch.int32).pin_memory()     # host-mapped: the kernel's system-scope atomic lands here
+        _COUNTER["np"] = _COUNTER["t"].numpy()                             # the same memory: check() reads it without building a tensor
         _COUNTER["seen"] = 0
     return _COUNTER["t"]
 
 
 def singular_seen() -> int:
     """Singular matrices met by the fast path since the process started (a plain read of pinned memory: exact after any wait on the stream)."""
-    return int(_COUNTER["t"][0]) if "t" in _COUNTER else 0
+    return int(_COUNTER["np"][0]) if "t" in _COUNTER else 0
 
 
 def check() -> None:
@@ -62,7 +63,7 @@ def check() -> None:
     call it behind a host wait that already exists (it does not synchronise)."""
     if "t" not in _COUNTER:
         return
-    n = int(_COUNTER["t"][0])
+    n = int(_COUNTER["np"][0])
     if n > _COUNTER["seen"]:
         new = n - _COUNTER["seen"]
         _COUNTER["seen"] = n
@@ -79,7 +80,10 @@ def _plain(A) -> bool:
 def _caller_ok() -> bool:
     if _ANY_CALLER:
         return True
-    f = sys._getframe(2)          # 0 = here, 1 = the wrapper, 2 = whoever called torch.linalg.inv / torch.inverse / Tensor.inverse
+    try:
+        f = sys._getframe(2)      # 0 = here, 1 = the wrapper, 2 = whoever called torch.linalg.inv / torch.inverse / Tensor.inverse
+    except ValueError:            # called from the top of a stack (an embedding interpreter): nobody we know
+        return False
     return os.path.basename(f.f_code.co_filename) in ALLOWED_CALLERS
 
 
