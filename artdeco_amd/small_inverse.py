@@ -19,8 +19,9 @@ with grad enabled) goes through `_Inv4x4` -- the same launch with the textbook b
 take one launch each in the script as written (round 5 sent that one to torch's LU).
 
 Singular input: there is no read-back in the call, so the result is NaN-filled there and then -- but the kernel bumps a counter in host-mapped
-pinned memory, and `check()` raises `torch.linalg.LinAlgError` at the process's next host wait (`native_step.step` calls it after the
-optimisation step's own wait; `rigid_transform_gs`'s fused form before it consumes the matrices).  The exception arrives late, never not at all.
+pinned memory, and `check()` raises `torch.linalg.LinAlgError` at the process's next host wait (`native_step.train_on_keyframe` calls it behind
+`adk_mapper_step`'s own wait, the per-stage rasteriser behind its intersection-count wait): within one optimisation step of the inversion.
+The exception arrives late, never not at all.
 `uninstall()` restores torch's functions.  Installed by `fused.patch_scene_model` (with the `pose` pin group verified), never by importing
 this package.
 """
