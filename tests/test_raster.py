@@ -312,6 +312,38 @@ def test_binning_is_bit_exact_with_screen_filling_gaussians(N, W, H, n_big, grow
 
 
 @pytest.mark.gpu
+def test_binning_time_does_not_blow_up_with_screen_filling_gaussians(dev):
+    """The PERFORMANCE side of finding 62, with a margin no box-to-box variation can eat: sixteen screen-filling Gaussians in a million took
+    `bin_count` + `bin_scatter` from 0.10 to 1.01 ms (10x) while one thread walked each rectangle; wave-cooperative they cost +16 %
+    (profiles/r06_bin_big_lab.txt).  Asserted: less than 2.5x."""
+    from artdeco_amd import rasterizer
+    from gsplat.rendering import rasterization
+    N, W, H = 1_000_000, 1920, 1080
+    times = {}
+    for name, n_big in (("base", 0), ("big", 16)):
+        sc = _scene(N, W, H, 0)
+        if n_big:
+            idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:n_big]
+            sc["scales"] = sc["scales"].clone()
+            sc["scales"][idx] *= 400.0
+        t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+        run = lambda: rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], t["viewmat"][None], t["K"][None], W, H,
+                                    render_mode="RGB+D", rasterize_mode="classic", absgrad=False, packed=False, sh_degree=3, eps2d=0.01)
+        for _ in range(3):
+            run()
+        tm = rasterizer.StageTimer(only=("bin_count", "bin_scatter"))
+        rasterizer.set_stage_timer(tm)
+        try:
+            for _ in range(6):
+                run()
+        finally:
+            rasterizer.set_stage_timer(None)
+        sm = tm.summary_ms()
+        times[name] = sm["bin_count"]["mean_ms"] + sm["bin_scatter"]["mean_ms"]
+    assert times["big"] < 2.5 * times["base"], times
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["dense-northstar", "pile", "equal-depths"])
 def test_binning_is_bit_exact_beyond_8192_entries_per_tile(case, dev, monkeypatch):
     """Tile lists ABOVE 8 192 entries stay on the tile-local route (round 5: bin_tile_sort_long_kernel, recursive partition on the key range
