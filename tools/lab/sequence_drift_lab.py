@@ -21,7 +21,8 @@ n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 breakdown = "--breakdown" in sys.argv
 stages = "--stages" in sys.argv
 dev = torch.device("cuda:0")
-scene = mapper.build_synthetic_mapper(1_000_000, 1920, 1080, dev, seed=0, n_keyframes=0, targets="random")
+NG, WW, HH = (int(x) for x in os.environ.get("DRIFT_SCENE", "1000000,1920,1080").split(","))
+scene = mapper.build_synthetic_mapper(NG, WW, HH, dev, seed=0, n_keyframes=0, targets="random")
 fused.patch_scene_model(scene)
 cadence = dict(kf_every=5, slam_every=15, test_hold=8)
 base = stream.synthetic_frames(scene, 48, seed=0, texture=0.05)
