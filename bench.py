@@ -597,7 +597,7 @@ def _full_sequence(n, w, h, dev, args, n_frames, batched, distinct=48):
            "optimisation_steps": r["steps"], "important_frames": r["important_frames"], "densified_frames": r["densified_frames"],
            "gaussians_start": r["gaussians_start"], "gaussians_end": r["gaussians_end"], "gaussians_added": r["gaussians_added"],
            "keyframes_at_end": len(scene.keyframes), "python_gc": "default (no gc.freeze())" if not fused._GC_FROZEN else "frozen earlier in this process",
-           "slam_pose_update": "batched (requires the INTEGRATION section 3c edit of run_system.py)" if batched else "run_system.py:194-227 as written (per-keyframe loop)"}
+           "slam_pose_update": "batched (requires the INTEGRATION section 3c edit of run_system.py)" if batched else "run_system.py:194-227 as written (per-keyframe loop; the new pose of each keyframe, which the script reads from the pypose SLAM graph with five LieTensor calls, is a clone + a small shift here: pypose is the script's own dependency and costs it more host time than this stand-in)"}
     del scene, frames, base
     torch.cuda.empty_cache()
     return res
